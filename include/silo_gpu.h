@@ -1,0 +1,203 @@
+/*
+ * silo_gpu.h — C ABI of the MI355X (gfx950) device side of the SILO mutation-filter hot path.
+ *
+ * This is the drop-in boundary described in SURVEY.md §8(b): plain pointers and sizes, no C++/torch
+ * types, 0 on success / negative silo_gpu_status on failure, never throws.  The reference has no FFI
+ * layer; each entry point below names the reference C++ interface (file:line under the reference
+ * tree) whose arithmetic it replaces.
+ *
+ * Data model: a *store* is one DatabasePartition (database_partition.h:39-112) with
+ * `sequence_count` rows.  Every sequence store in it (nucleotide segment or gene) is a
+ * SequenceStorePartition (sequence_store.h:34-88) restated as dense bitsets in HBM:
+ *   row_words  Wp = roundup(ceil(N/64), 32)   (256-byte aligned rows, tail bits zero)
+ *   scan planes   [position][valid mutation symbol][Wp]   uint64, bit i of word w = sequence 64*w+i
+ *   extra planes  [extra dense symbol][position][Wp]      (the missing symbol N / X, ...)
+ *   sparse symbols (IUPAC ambiguity codes) as sorted (position, symbol, sequence id) triples.
+ */
+#ifndef SILO_GPU_H
+#define SILO_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+   SILO_GPU_OK = 0,
+   SILO_GPU_ERR_INVALID_ARGUMENT = -1,
+   SILO_GPU_ERR_OUT_OF_MEMORY = -2,
+   SILO_GPU_ERR_HIP = -3,         /* a HIP runtime call failed; see silo_gpu_last_error() */
+   SILO_GPU_ERR_NO_DEVICE = -4,   /* no gfx950 device visible: the product path has no CPU fallback */
+   SILO_GPU_ERR_PROGRAM_TOO_LARGE = -5,
+   SILO_GPU_ERR_UNSUPPORTED = -6
+} silo_gpu_status;
+
+/* Alphabets.  Symbol ids are the reference enum values:
+ * nucleotide_symbols.h:15-32 (GAP A C G T R Y S W K M B D H V N = 0..15),
+ * aa_symbols.h:15-41 (GAP A C D E F G H I K L M N P Q R S T V W Y B Z STOP X = 0..24). */
+enum { SILO_GPU_ALPHABET_NUCLEOTIDE = 0, SILO_GPU_ALPHABET_AMINO_ACID = 1 };
+enum { SILO_GPU_NUC_SYMBOLS = 16, SILO_GPU_AA_SYMBOLS = 25, SILO_GPU_MAX_SYMBOLS = 25 };
+#define SILO_GPU_SYMBOL_NONE 0xFFu
+
+typedef struct silo_gpu_store silo_gpu_store; /* opaque; one per device shard */
+
+/* One SequenceStorePartition (sequence_store.h:51-56). */
+typedef struct {
+   uint32_t alphabet;         /* SILO_GPU_ALPHABET_* */
+   uint32_t positions;        /* reference_sequence.size() */
+   const uint8_t* reference;  /* [positions] symbol ids (reference_genomes.cpp) */
+   /* Dense planes to allocate.  scan_symbols must be the alphabet's VALID_MUTATION_SYMBOLS in
+    * their declared order (nucleotide_symbols.h:61-67, aa_symbols.h:56-79): they form the
+    * [position][symbol] block the Mutations scan streams.  extra_symbols are further dense planes
+    * (normally the missing symbol, SYMBOL_MISSING).  Symbols in neither list are kept sparse. */
+   uint32_t n_scan_symbols;
+   const uint8_t* scan_symbols;
+   uint32_t n_extra_symbols;
+   const uint8_t* extra_symbols;
+} silo_gpu_seqstore_desc;
+
+typedef struct {
+   int32_t device;            /* HIP device ordinal */
+   uint32_t sequence_count;   /* DatabasePartition::sequence_count (capacity; rows are 0..N-1) */
+   uint32_t n_seqstores;
+   const silo_gpu_seqstore_desc* seqstores;
+} silo_gpu_store_desc;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Allocates zeroed planes in HBM.  Replaces SequenceStorePartition's constructor
+ * (sequence_store.cpp:21-29).  Fails with SILO_GPU_ERR_NO_DEVICE when no GPU is present. */
+int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out);
+void silo_gpu_store_destroy(silo_gpu_store* store);
+
+uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store);
+uint32_t silo_gpu_store_row_words(const silo_gpu_store* store); /* Wp, in uint64 words */
+uint64_t silo_gpu_store_device_bytes(const silo_gpu_store* store);
+
+/* ---- index build: SequenceStorePartition::fill / interpret (sequence_store.cpp:31-66,100-220) - */
+
+/* Transposes a batch of aligned sequences into the planes on the device.
+ * `chars` is host memory, row-major [n_sequences][positions], the characters of the alignment
+ * (charToSymbol: nucleotide_symbols.cpp:46-85, aa_symbols.cpp:62-117).  `is_null[i] != 0` marks a
+ * missing genome: the missing symbol at every position (sequence_store.cpp:166-169); its chars are
+ * ignored.  is_null may be NULL.  first_sequence + n_sequences <= sequence_count.
+ * An illegal character fails with SILO_GPU_ERR_INVALID_ARGUMENT (sequence_store.cpp:118-122). */
+int silo_gpu_store_append_sequences(
+   silo_gpu_store* store, uint32_t seqstore_id, uint32_t first_sequence, uint32_t n_sequences,
+   const char* chars, const uint8_t* is_null
+);
+
+/* Sorts the sparse triples gathered by append/generate; call once after the last append and
+ * before any query.  (The reference's optimizeBitmaps, sequence_store.cpp:192-211, has no dense
+ * analogue: flipped/deleted bitmaps are storage tricks) */
+int silo_gpu_store_finalize(silo_gpu_store* store);
+
+/* Synthetic SARS-CoV-2-shaped data written straight into the planes (bench / parity tests only;
+ * the model is specified in DESIGN.md §6 and restated on the CPU in oracle/synth.py).
+ * All arrays are host memory.  lineage_symbol is [positions][n_lineages], 0xFF = "reference". */
+typedef struct {
+   uint64_t seed;
+   uint32_t n_lineages;
+   const uint16_t* lineage_of_sequence; /* [N] */
+   const uint32_t* lead_gap;            /* [N] positions [0, lead_gap) are GAP */
+   const uint32_t* trail_gap;           /* [N] positions [P - trail_gap, P) are GAP */
+   const uint32_t* missing_start;       /* [N] run of the missing symbol */
+   const uint32_t* missing_len;         /* [N] */
+   const uint8_t* lineage_symbol;       /* [positions][n_lineages] */
+   uint32_t private_threshold;          /* of 2^20: P(private substitution) per cell */
+   uint32_t ambiguous_threshold;        /* of 2^24: P(sparse ambiguity code) per cell */
+} silo_gpu_synth_desc;
+int silo_gpu_store_generate_synthetic(
+   silo_gpu_store* store, uint32_t seqstore_id, const silo_gpu_synth_desc* synth
+);
+
+/* ---- device buffers owned by the caller -------------------------------------------------------- */
+
+/* Row-sized (Wp words) bitset in HBM, zero-initialised.  Used for filter results and for host-built
+ * metadata bitsets (pango lineage sets: pango_lineage_column.cpp:57-77, uploaded once). */
+int silo_gpu_bitset_alloc(const silo_gpu_store* store, uint64_t** out_dev);
+int silo_gpu_bitset_upload(const silo_gpu_store* store, uint64_t* dst_dev, const uint64_t* src_host, size_t n_words, void* stream);
+int silo_gpu_bitset_download(const silo_gpu_store* store, uint64_t* dst_host, const uint64_t* src_dev, size_t n_words, void* stream);
+/* bit i = membership_by_lineage[lineage_of_sequence[i]] for a store filled by generate_synthetic. */
+int silo_gpu_bitset_from_lineages(const silo_gpu_store* store, uint64_t* dst_dev, const uint8_t* membership_by_lineage, uint32_t n_lineages, void* stream);
+void silo_gpu_free(void* dev_ptr);
+int silo_gpu_malloc(size_t bytes, void** out_dev);
+int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int silo_gpu_stream_synchronize(void* stream);
+
+/* Device pointer of the dense plane of (seqstore, position, symbol), or NULL when that symbol is
+ * sparse / not stored.  Replaces SequenceStorePartition::getBitmap (sequence_store.cpp:92-98);
+ * positions are 0-based as there. */
+const uint64_t* silo_gpu_store_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol);
+
+/* Materialises the bitset of a sparse symbol at a position into dst_dev (Wp words, overwritten). */
+int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol, uint64_t* dst_dev, void* stream);
+
+/* ---- K3: fused filter-expression evaluator --------------------------------------------------------
+ * Replaces Operator::evaluate() of IndexScan / Complement / Intersection / Union / Threshold /
+ * Full / Empty / BitmapSelection (operators/index_scan.cpp:28-30, complement.cpp:50-54,
+ * intersection.cpp:62-127, union.cpp:35-45, threshold.cpp:64-138, full.cpp:24-28, empty.cpp,
+ * bitmap_selection.cpp:33-52): the whole operator tree of one partition is one launch.
+ *
+ * A bit-program is a register machine over 64-bit slots, one program run per bitset word.
+ * Instruction word 0: op | dst<<8 | a<<16 | b<<24, word 1: imm.   Slot 0 holds the result. */
+enum {
+   SILO_GPU_OP_LOAD = 0,     /* dst = leaves[imm][w]                                  (IndexScan) */
+   SILO_GPU_OP_ZERO = 1,     /* dst = 0                                               (Empty)     */
+   SILO_GPU_OP_ONES = 2,     /* dst = valid(w): all rows < sequence_count             (Full)      */
+   SILO_GPU_OP_NOT = 3,      /* dst = ~a & valid(w)                                   (Complement)*/
+   SILO_GPU_OP_AND = 4,      /* dst = a & b                                           (Intersection) */
+   SILO_GPU_OP_OR = 5,       /* dst = a | b                                           (Union)     */
+   SILO_GPU_OP_ANDNOT = 6,   /* dst = a & ~b                                          (Intersection, negated child) */
+   SILO_GPU_OP_CNT_ADD = 7,  /* bit-sliced counter in slots dst..dst+b-1 += slot a    (Threshold) */
+   SILO_GPU_OP_CNT_GE = 8,   /* dst = (counter in slots a..a+b-1) >= imm                           */
+   SILO_GPU_OP_CNT_EQ = 9,   /* dst = (counter in slots a..a+b-1) == imm                           */
+   SILO_GPU_OP_MOV = 10      /* dst = a */
+};
+enum { SILO_GPU_MAX_INSTRUCTIONS = 192, SILO_GPU_MAX_LEAVES = 128, SILO_GPU_MAX_SLOTS = 32 };
+
+typedef struct {
+   uint32_t n_instructions;
+   const uint32_t* code;            /* 2 * n_instructions words, host memory */
+   uint32_t n_leaves;
+   const uint64_t* const* leaves;   /* device pointers, each Wp words, host array */
+   uint32_t n_slots;                /* slots used, <= SILO_GPU_MAX_SLOTS */
+} silo_gpu_bitprog;
+
+/* out_bitset_dev (Wp words) and/or out_count_dev (one uint64, ACCUMULATED into, so the caller can
+ * sum partitions like aggregated.cpp:58-66) may be NULL. */
+int silo_gpu_filter_eval(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program,
+   uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream
+);
+
+/* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
+int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* accumulated */, void* stream);
+
+/* ---- K1: Mutations scan (mutations.cpp:64-164) ---------------------------------------------------
+ * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & plane[p][scan_symbols[s]])
+ * for p in [pos_begin, pos_end).  The buffer is ACCUMULATED into (the reference sums partitions into
+ * one table, mutations.cpp:71,108); zero it with silo_gpu_memset_async before the first partition.
+ * filter_dev == NULL means the full filter (mutations.cpp:98-136). */
+int silo_gpu_mutations_scan(
+   const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev,
+   uint32_t pos_begin, uint32_t pos_end, uint32_t* counts_out_dev, void* stream
+);
+int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream);
+
+/* Tuning knobs of K1 (0 = default); returns the previous value.  For benchmarks only. */
+enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1 };
+int silo_gpu_tune(int knob, int value);
+
+/* Name of the last kernel variant silo_gpu_mutations_scan launched (for roofline attribution). */
+const char* silo_gpu_last_scan_kernel(void);
+
+/* Thread-local description of the last error. */
+const char* silo_gpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SILO_GPU_H */

@@ -1,0 +1,1286 @@
+// silo_gpu.hip — CDNA4 (gfx950) kernels + C ABI of the SILO mutation-filter hot path.
+//
+// Kernels:
+//   K1  k_scan_tiled / k_scan_rowwave   Mutations scan: counts[p][s] += popcount(F & C[p][s])
+//                                        (reference: actions/mutations.cpp:64-164)
+//   K2  k_popcount                      |F|            (actions/aggregated.cpp:61)
+//   K3  k_filter_eval                   fused operator tree -> bitset (+ count)
+//                                        (operators/{index_scan,complement,intersection,union,
+//                                         threshold,full,empty,bitmap_selection}.cpp)
+//   B1  k_transpose_sequences           aligned sequences -> bit planes (storage/sequence_store.cpp:100-190)
+//   B2  k_generate_synthetic            synthetic planes for the benchmarks
+// Everything is 64-bit integer AND / OR / popcount: HBM-bound, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/silo_gpu.h"
+#include "bitprog.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local const char* g_last_scan_kernel = "none";
+
+std::atomic<int> g_tune_rows_per_block{0};
+std::atomic<int> g_tune_scan_variant{0};
+
+int fail(int code, const std::string& msg) {
+   g_last_error = msg;
+   return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+   do {                                                                                        \
+      hipError_t err_ = (expr);                                                                \
+      if (err_ != hipSuccess) {                                                                \
+         return fail(                                                                          \
+            err_ == hipErrorOutOfMemory ? SILO_GPU_ERR_OUT_OF_MEMORY : SILO_GPU_ERR_HIP,       \
+            std::string(#expr) + ": " + hipGetErrorString(err_)                                \
+         );                                                                                    \
+      }                                                                                        \
+   } while (0)
+
+constexpr uint32_t ROW_ALIGN_WORDS = 32;  // 256-byte rows
+
+// ------------------------------------------------------------------------------------------------
+// alphabets (host side tables; ids = reference enum values)
+// nucleotide_symbols.cpp:46-85  /  aa_symbols.cpp:62-117
+// ------------------------------------------------------------------------------------------------
+void fillCharTable(uint32_t alphabet, uint8_t table[256]) {
+   memset(table, SILO_GPU_SYMBOL_NONE, 256);
+   if (alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE) {
+      const char* symbols = "-ACGTRYSWKMBDHVN";
+      for (int i = 0; i < 16; ++i) {
+         table[static_cast<uint8_t>(symbols[i])] = static_cast<uint8_t>(i);
+      }
+      table[static_cast<uint8_t>('.')] = 0;  // '.' -> GAP   (nucleotide_symbols.cpp:48-50)
+      table[static_cast<uint8_t>('U')] = 4;  // 'U' -> T     (nucleotide_symbols.cpp:58-60)
+   } else {
+      const char* symbols = "-ACDEFGHIKLMNPQRSTVWYBZ*X";  // enum order, STOP = 23, X = 24
+      for (int i = 0; i < 25; ++i) {
+         table[static_cast<uint8_t>(symbols[i])] = static_cast<uint8_t>(i);
+      }
+   }
+}
+
+uint32_t alphabetSize(uint32_t alphabet) {
+   return alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE ? SILO_GPU_NUC_SYMBOLS : SILO_GPU_AA_SYMBOLS;
+}
+uint32_t missingSymbol(uint32_t alphabet) {
+   return alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE ? 15u : 24u;  // N / X
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side description of one sequence store (passed to kernels by value)
+// ------------------------------------------------------------------------------------------------
+enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
+
+struct SeqStoreDev {
+   uint64_t* scan;   // [P][n_scan][Wp]
+   uint64_t* extra;  // [n_extra][P][Wp]
+   uint32_t positions;
+   uint32_t n_symbols;  // alphabet size
+   uint32_t n_scan;
+   uint32_t n_extra;
+   uint32_t row_words;  // Wp
+   uint32_t missing_symbol;
+   uint8_t kind[SILO_GPU_MAX_SYMBOLS];
+   uint8_t index[SILO_GPU_MAX_SYMBOLS];
+};
+
+__host__ __device__ inline uint64_t* planePtr(const SeqStoreDev& s, uint32_t position, uint32_t symbol) {
+   const uint8_t kind = s.kind[symbol];
+   if (kind == PLANE_SCAN) {
+      return s.scan + (static_cast<size_t>(position) * s.n_scan + s.index[symbol]) * s.row_words;
+   }
+   if (kind == PLANE_EXTRA) {
+      return s.extra + (static_cast<size_t>(s.index[symbol]) * s.positions + position) * s.row_words;
+   }
+   return nullptr;
+}
+
+struct SeqStoreHost {
+   SeqStoreDev dev{};
+   uint32_t alphabet = 0;
+   std::vector<uint8_t> reference;
+   uint8_t* d_reference = nullptr;
+   // sparse symbols: key = position << 37 | symbol << 32 | sequence id
+   uint64_t* d_sparse = nullptr;
+   uint32_t sparse_capacity = 0;
+   uint32_t* d_sparse_count = nullptr;  // device counter
+   std::vector<uint64_t> sparse_sorted;  // host copy after finalize
+   bool finalized = false;
+};
+
+}  // namespace
+
+struct silo_gpu_store {
+   int device = 0;
+   uint32_t sequence_count = 0;
+   uint32_t row_words = 0;
+   uint64_t device_bytes = 0;
+   std::vector<SeqStoreHost> seqstores;
+   uint64_t* d_ones = nullptr;       // the Full bitset
+   uint16_t* d_lineage = nullptr;    // synthetic stores only
+   uint32_t n_lineages = 0;
+   uint32_t* d_error_flag = nullptr;
+   std::mutex mutex;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------------
+// Inclusive DPP scan within rows of 16, then row broadcasts: lane 63 ends up with the wave sum.
+// 6 VALU instructions, no LDS traffic (ds_bpermute-based __shfl costs an LDS round trip per step).
+__device__ __forceinline__ uint32_t waveSumToLane63(uint32_t v) {
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+   v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+   return v;
+}
+
+__device__ __forceinline__ uint32_t popc128(const ulonglong2& v, const ulonglong2& f) {
+   return static_cast<uint32_t>(__popcll(v.x & f.x)) + static_cast<uint32_t>(__popcll(v.y & f.y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a: tiled Mutations scan for long rows.
+//
+// Grid: blockIdx.x = row_group * n_tiles + tile.  A block owns a column tile of
+// TILE_WORDS = 256 threads * WPT words of the filter, held in registers for the whole block lifetime
+// (the "filter staged once and reused across all position columns" of the north star: registers
+// are the first-level staging, LDS only carries the per-row partial counts), and streams that
+// tile's slice of `rows_per_block` consecutive plane rows.  Every load instruction is a fully
+// coalesced 16 B/lane access (4 KiB per block, 1 KiB per wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ROWS_BATCH = 64;
+
+template <int WPT, bool GUARDED>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiled(
+   const uint64_t* __restrict__ planes,
+   const uint64_t* __restrict__ filter,
+   uint32_t* __restrict__ counts,
+   uint32_t row_words,
+   uint32_t n_rows,
+   uint32_t rows_per_block,
+   uint32_t n_tiles,
+   uint32_t first_tile
+) {
+   constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread
+   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
+   constexpr int WAVES = SCAN_THREADS / 64;
+   // per-wave partial counts of one batch of rows, double-buffered so one barrier per batch suffices
+   __shared__ uint32_t s_partial[2][WAVES][SCAN_ROWS_BATCH];
+
+   const uint32_t tid = threadIdx.x;
+   const uint32_t wave = tid >> 6;
+   const bool writer = (tid & 63u) == 63u;  // waveSumToLane63 leaves the total in lane 63
+   const uint32_t tile = first_tile + blockIdx.x % n_tiles;
+   const uint32_t row_group = blockIdx.x / n_tiles;
+   const uint32_t row_begin = row_group * rows_per_block;
+   const uint32_t row_end = min(n_rows, row_begin + rows_per_block);
+   const uint32_t last_row = row_end - 1;
+
+   // this thread's 16-byte chunks of the tile; the filter words stay in registers for all rows
+   uint32_t word[CHUNKS];
+   ulonglong2 f[CHUNKS];
+#pragma unroll
+   for (int j = 0; j < CHUNKS; ++j) {
+      word[j] = tile * TILE_WORDS + (j * SCAN_THREADS + tid) * 2;
+      if (GUARDED && word[j] >= row_words) {
+         // out-of-row chunks read word 0 (always valid) against a zero filter: no branch in the loop
+         word[j] = 0;
+         f[j] = make_ulonglong2(0, 0);
+      } else {
+         f[j] = *reinterpret_cast<const ulonglong2*>(filter + word[j]);
+      }
+   }
+
+   auto load_row = [&](uint32_t row, ulonglong2 (&dst)[CHUNKS]) {
+      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
+#pragma unroll
+      for (int j = 0; j < CHUNKS; ++j) {
+         dst[j] = *reinterpret_cast<const ulonglong2*>(row_ptr + word[j]);
+      }
+   };
+   auto reduce_row = [&](const ulonglong2 (&src)[CHUNKS]) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < CHUNKS; ++j) {
+         acc += popc128(src[j], f[j]);
+      }
+      return waveSumToLane63(acc);
+   };
+   auto flush = [&](uint32_t batch_first_row, uint32_t n_batch, uint32_t buffer) {
+      __syncthreads();
+      if (tid < n_batch) {
+         uint32_t total = 0;
+#pragma unroll
+         for (int w = 0; w < WAVES; ++w) {
+            total += s_partial[buffer][w][tid];
+         }
+         if (total != 0) {
+            atomicAdd(&counts[batch_first_row + tid], total);
+         }
+      }
+   };
+
+   // Software pipeline over rows with two register buffers: while row r is reduced, the loads of
+   // row r+1 are in flight.  Loads past the block's last row are clamped to it (an L2 hit, result
+   // unused) so that the loop body has no load under a branch and s_waitcnt can stay at vmcnt(4).
+   ulonglong2 buf_a[CHUNKS];
+   ulonglong2 buf_b[CHUNKS];
+   load_row(row_begin, buf_a);
+   uint32_t buffer = 0;
+   uint32_t batch_first_row = row_begin;
+   for (uint32_t row = row_begin; row < row_end; row += 2) {
+      load_row(min(row + 1, last_row), buf_b);
+      const uint32_t sum_a = reduce_row(buf_a);
+      if (writer) {
+         s_partial[buffer][wave][row - batch_first_row] = sum_a;
+      }
+      load_row(min(row + 2, last_row), buf_a);
+      const uint32_t sum_b = reduce_row(buf_b);
+      if (writer && row + 1 < row_end) {
+         s_partial[buffer][wave][row + 1 - batch_first_row] = sum_b;
+      }
+      const uint32_t done = min(row + 2, row_end) - batch_first_row;
+      if (done >= SCAN_ROWS_BATCH || row + 2 >= row_end) {  // SCAN_ROWS_BATCH is even
+         flush(batch_first_row, done, buffer);
+         batch_first_row += done;
+         buffer ^= 1u;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: one wave per row, for short rows (small N) where a 256-thread column tile would be empty.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_rowwave(
+   const uint64_t* __restrict__ planes,
+   const uint64_t* __restrict__ filter,
+   uint32_t* __restrict__ counts,
+   uint32_t row_words,
+   uint32_t n_rows
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+   const uint32_t n_chunks = row_words / 2;
+
+   // the first chunk of the filter stays in registers across rows (covers N <= 8192 entirely)
+   const ulonglong2 f0 =
+      lane < n_chunks ? *reinterpret_cast<const ulonglong2*>(filter + 2 * lane) : make_ulonglong2(0, 0);
+
+   for (uint32_t row = wave; row < n_rows; row += n_waves) {
+      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
+      uint32_t acc = 0;
+      if (lane < n_chunks) {
+         acc = popc128(*reinterpret_cast<const ulonglong2*>(row_ptr + 2 * lane), f0);
+      }
+      for (uint32_t chunk = lane + 64; chunk < n_chunks; chunk += 64) {
+         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(row_ptr + 2 * chunk);
+         const ulonglong2 f = *reinterpret_cast<const ulonglong2*>(filter + 2 * chunk);
+         acc += popc128(v, f);
+      }
+      acc = waveSumToLane63(acc);
+      if (lane == 63u && acc != 0) {
+         atomicAdd(&counts[row], acc);
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: popcount of one row-sized bitset, accumulated into *out
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_popcount(
+   const uint64_t* __restrict__ bitset, uint32_t row_words, unsigned long long* __restrict__ out
+) {
+   const uint32_t n_chunks = row_words / 2;
+   uint32_t acc = 0;
+   for (uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x; chunk < n_chunks; chunk += gridDim.x * blockDim.x) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(bitset + 2 * chunk);
+      acc += static_cast<uint32_t>(__popcll(v.x)) + static_cast<uint32_t>(__popcll(v.y));
+   }
+   acc = waveSumToLane63(acc);
+   if ((threadIdx.x & 63u) == 63u && acc != 0) {
+      atomicAdd(out, static_cast<unsigned long long>(acc));
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: fused filter evaluator.  One program run per bitset word; slots live in LDS as
+// [slot][thread] so every ds_read_b64 / ds_write_b64 is conflict-free; the program itself sits in
+// the kernel-argument segment and is fetched with scalar loads (uniform control flow).
+// ------------------------------------------------------------------------------------------------
+constexpr int EVAL_THREADS = 256;
+
+struct FilterEvalArgs {
+   uint32_t n_instructions;
+   uint32_t sequence_count;
+   uint32_t row_words;
+   uint32_t n_slots;
+   uint64_t* out;
+   unsigned long long* out_count;
+   const uint64_t* leaves[SILO_GPU_MAX_LEAVES];
+   uint32_t code[2 * SILO_GPU_MAX_INSTRUCTIONS];
+};
+
+__global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
+   extern __shared__ uint64_t s_slots[];  // [n_slots][EVAL_THREADS]
+   const uint32_t tid = threadIdx.x;
+   uint32_t local_count = 0;
+   for (uint32_t w = blockIdx.x * EVAL_THREADS + tid; w < args.row_words; w += gridDim.x * EVAL_THREADS) {
+      const uint64_t valid = silo_gpu::valid_mask(w, args.sequence_count);
+      const uint64_t result = silo_gpu::bitprog_run_word(
+         args.code,
+         args.n_instructions,
+         valid,
+         [&](uint32_t slot) -> uint64_t& { return s_slots[slot * EVAL_THREADS + tid]; },
+         [&](uint32_t leaf) -> uint64_t { return args.leaves[leaf][w]; }
+      ) & valid;
+      if (args.out != nullptr) {
+         args.out[w] = result;
+      }
+      local_count += static_cast<uint32_t>(__popcll(result));
+   }
+   if (args.out_count != nullptr) {
+      local_count = waveSumToLane63(local_count);
+      if ((tid & 63u) == 63u && local_count != 0) {
+         atomicAdd(args.out_count, static_cast<unsigned long long>(local_count));
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane writers shared by B1 / B2: `symbol` is this lane's symbol for sequence 64*word+lane
+// (SILO_GPU_SYMBOL_NONE contributes no bit).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emitWord(
+   const SeqStoreDev& store, uint32_t position, uint32_t word, uint32_t symbol, bool whole_word,
+   uint64_t* sparse, uint32_t* sparse_count, uint32_t sparse_capacity
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   for (uint32_t s = 0; s < store.n_symbols; ++s) {
+      const uint64_t mask = __ballot(symbol == s);
+      if (mask == 0) {
+         continue;
+      }
+      const uint8_t kind = store.kind[s];
+      if (kind != PLANE_SPARSE) {
+         if (lane == 0) {
+            uint64_t* dst = planePtr(store, position, s) + word;
+            if (whole_word) {
+               *dst = mask;
+            } else {
+               atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(mask));
+            }
+         }
+      } else if (symbol == s) {
+         const uint32_t slot = atomicAdd(sparse_count, 1u);
+         if (slot < sparse_capacity) {
+            sparse[slot] = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(s) << 32) |
+                           (static_cast<uint64_t>(word) * 64u + lane);
+         }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1: transpose a batch of aligned sequences.  A wave owns one 64-sequence word and a range of
+// positions; each lane reads 4 positions of its own sequence per load from the pitched staging
+// buffer, so consecutive loads of a lane walk the same cache lines.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TRANSPOSE_POSITIONS_PER_WAVE = 256;
+
+__global__ __launch_bounds__(256) void k_transpose_sequences(
+   const SeqStoreDev store,
+   const uint8_t* __restrict__ chars,  // [n][pitch]
+   const uint8_t* __restrict__ is_null,
+   uint32_t pitch,
+   uint32_t first_sequence,
+   uint32_t n_sequences,
+   uint32_t first_word,
+   uint32_t n_words,
+   const uint8_t* __restrict__ char_table,  // [256]
+   uint64_t* sparse,
+   uint32_t* sparse_count,
+   uint32_t sparse_capacity,
+   uint32_t* error_flag
+) {
+   __shared__ uint8_t s_table[256];
+   s_table[threadIdx.x] = char_table[threadIdx.x];
+   __syncthreads();
+
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t wave_in_block = threadIdx.x >> 6;
+   const uint32_t word_index = blockIdx.x * 4 + wave_in_block;
+   if (word_index >= n_words) {
+      return;
+   }
+   const uint32_t word = first_word + word_index;
+   const uint64_t sequence = static_cast<uint64_t>(word) * 64u + lane;
+   const bool active = sequence >= first_sequence && sequence < static_cast<uint64_t>(first_sequence) + n_sequences;
+   const uint32_t local = active ? static_cast<uint32_t>(sequence - first_sequence) : 0;
+   const bool null_genome = active && is_null != nullptr && is_null[local] != 0;
+   // the word is overwritten only if all 64 of its sequences are in this batch
+   const bool whole_word = static_cast<uint64_t>(word) * 64u >= first_sequence &&
+                           static_cast<uint64_t>(word) * 64u + 64u <= static_cast<uint64_t>(first_sequence) + n_sequences;
+
+   const uint32_t pos_begin = blockIdx.y * TRANSPOSE_POSITIONS_PER_WAVE;
+   const uint32_t pos_end = min(store.positions, pos_begin + TRANSPOSE_POSITIONS_PER_WAVE);
+   const uint8_t* row = chars + static_cast<size_t>(local) * pitch;
+   for (uint32_t p4 = pos_begin; p4 < pos_end; p4 += 4) {
+      uint32_t packed = 0;
+      if (active && !null_genome) {
+         packed = *reinterpret_cast<const uint32_t*>(row + p4);  // pitch is a multiple of 16, p4 of 4
+      }
+      for (uint32_t k = 0; k < 4 && p4 + k < pos_end; ++k) {
+         uint32_t symbol = SILO_GPU_SYMBOL_NONE;
+         if (null_genome) {
+            symbol = store.missing_symbol;
+         } else if (active) {
+            symbol = s_table[(packed >> (8 * k)) & 0xFFu];
+            if (symbol == SILO_GPU_SYMBOL_NONE) {
+               atomicOr(error_flag, 1u);
+            }
+         }
+         emitWord(store, p4 + k, word, symbol, whole_word, sparse, sparse_count, sparse_capacity);
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B2: synthetic planes (CPU twin: oracle/synth.py symbol_matrix()).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+   return z ^ (z >> 31);
+}
+
+struct SynthArgs {
+   uint64_t seed;
+   uint32_t n_lineages;
+   uint32_t sequence_count;
+   const uint16_t* lineage;
+   const uint32_t* lead_gap;
+   const uint32_t* trail_gap;
+   const uint32_t* missing_start;
+   const uint32_t* missing_len;
+   const uint8_t* lineage_symbol;  // [P][L]
+   const uint8_t* reference;       // [P]
+   uint32_t private_threshold;
+   uint32_t ambiguous_threshold;
+   uint32_t private_base, private_count;      // nuc: 1,4 (A C G T)   aa: 1,20 (A..Y)
+   uint32_t ambiguous_base, ambiguous_count;  // nuc: 5,10 (R..V)     aa: 21,2 (B Z)
+};
+
+constexpr uint32_t SYNTH_POSITIONS_PER_WAVE = 128;
+
+__global__ __launch_bounds__(256) void k_generate_synthetic(
+   const SeqStoreDev store, const SynthArgs args, uint32_t n_words, uint64_t* sparse, uint32_t* sparse_count,
+   uint32_t sparse_capacity
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t word = blockIdx.x * 4 + (threadIdx.x >> 6);
+   if (word >= n_words) {
+      return;
+   }
+   const uint64_t sequence = static_cast<uint64_t>(word) * 64u + lane;
+   const bool active = sequence < args.sequence_count;
+   const uint32_t i = active ? static_cast<uint32_t>(sequence) : 0;
+   const uint32_t lineage = args.lineage[i];
+   const uint32_t lead = args.lead_gap[i];
+   const uint32_t trail = args.trail_gap[i];
+   const uint32_t mstart = args.missing_start[i];
+   const uint32_t mlen = args.missing_len[i];
+   const uint32_t positions = store.positions;
+   const uint64_t seq_hash = args.seed ^ (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull);
+
+   const uint32_t pos_begin = blockIdx.y * SYNTH_POSITIONS_PER_WAVE;
+   const uint32_t pos_end = min(positions, pos_begin + SYNTH_POSITIONS_PER_WAVE);
+   for (uint32_t p = pos_begin; p < pos_end; ++p) {
+      uint32_t symbol;
+      if (p < lead || p >= positions - trail) {
+         symbol = 0;  // GAP
+      } else if (p >= mstart && p - mstart < mlen) {
+         symbol = store.missing_symbol;
+      } else {
+         const uint64_t h = mix64(seq_hash ^ (static_cast<uint64_t>(p) * 0xC2B2AE3D27D4EB4Full));
+         if ((h & 0xFFFFFu) < args.private_threshold) {
+            symbol = args.private_base + static_cast<uint32_t>((h >> 20) & 0xFFFu) % args.private_count;
+         } else if (((h >> 32) & 0xFFFFFFu) < args.ambiguous_threshold) {
+            symbol = args.ambiguous_base + static_cast<uint32_t>(h >> 56) % args.ambiguous_count;
+         } else {
+            const uint8_t ls = args.lineage_symbol[static_cast<size_t>(p) * args.n_lineages + lineage];
+            symbol = ls != SILO_GPU_SYMBOL_NONE ? ls : args.reference[p];
+         }
+      }
+      if (!active) {
+         symbol = SILO_GPU_SYMBOL_NONE;
+      }
+      emitWord(store, p, word, symbol, /*whole_word=*/true, sparse, sparse_count, sparse_capacity);
+   }
+}
+
+__global__ __launch_bounds__(256) void k_bitset_from_lineages(
+   const uint16_t* __restrict__ lineage, const uint8_t* __restrict__ membership, uint32_t sequence_count,
+   uint32_t row_words, uint64_t* __restrict__ out
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t word = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   if (word >= row_words) {
+      return;
+   }
+   const uint64_t sequence = static_cast<uint64_t>(word) * 64u + lane;
+   const bool member = sequence < sequence_count && membership[lineage[sequence]] != 0;
+   const uint64_t mask = __ballot(member);
+   if (lane == 0) {
+      out[word] = mask;
+   }
+}
+
+__global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence_count) {
+   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+   if (w < row_words) {
+      out[w] = silo_gpu::valid_mask(w, sequence_count);
+   }
+}
+
+__global__ void k_scatter_sparse(const uint64_t* __restrict__ keys, uint32_t begin, uint32_t end, uint64_t* out) {
+   const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
+   if (k < end) {
+      const uint32_t sequence = static_cast<uint32_t>(keys[k] & 0xFFFFFFFFull);
+      atomicOr(reinterpret_cast<unsigned long long*>(out + (sequence >> 6)), 1ull << (sequence & 63u));
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+int ensureDevice(int device) {
+   int count = 0;
+   hipError_t err = hipGetDeviceCount(&count);
+   if (err != hipSuccess || count == 0) {
+      return fail(
+         SILO_GPU_ERR_NO_DEVICE,
+         "no HIP device visible (hipGetDeviceCount: " + std::string(hipGetErrorString(err)) +
+            "); the silo_gpu product path has no CPU fallback"
+      );
+   }
+   if (device < 0 || device >= count) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+   }
+   HIP_TRY(hipSetDevice(device));
+   return SILO_GPU_OK;
+}
+
+int growSparse(SeqStoreHost& seqstore, uint32_t needed) {
+   if (needed <= seqstore.sparse_capacity) {
+      return SILO_GPU_OK;
+   }
+   uint32_t capacity = std::max<uint32_t>(1u << 16, seqstore.sparse_capacity);
+   while (capacity < needed) {
+      capacity *= 2;
+   }
+   uint64_t* bigger = nullptr;
+   HIP_TRY(hipMalloc(&bigger, static_cast<size_t>(capacity) * sizeof(uint64_t)));
+   if (seqstore.d_sparse != nullptr) {
+      HIP_TRY(hipMemcpy(bigger, seqstore.d_sparse, static_cast<size_t>(seqstore.sparse_capacity) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+      HIP_TRY(hipFree(seqstore.d_sparse));
+   }
+   seqstore.d_sparse = bigger;
+   seqstore.sparse_capacity = capacity;
+   return SILO_GPU_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* silo_gpu_last_error(void) {
+   return g_last_error.c_str();
+}
+
+const char* silo_gpu_last_scan_kernel(void) {
+   return g_last_scan_kernel;
+}
+
+int silo_gpu_tune(int knob, int value) {
+   if (knob == SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK) {
+      return g_tune_rows_per_block.exchange(value);
+   }
+   if (knob == SILO_GPU_TUNE_SCAN_VARIANT) {
+      return g_tune_scan_variant.exchange(value);
+   }
+   return -1;
+}
+
+int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out) {
+   if (desc == nullptr || out == nullptr || desc->n_seqstores == 0 || desc->seqstores == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_create: null descriptor");
+   }
+   *out = nullptr;
+   if (int rc = ensureDevice(desc->device); rc != SILO_GPU_OK) {
+      return rc;
+   }
+   auto* store = new (std::nothrow) silo_gpu_store();
+   if (store == nullptr) {
+      return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "host allocation failed");
+   }
+   store->device = desc->device;
+   store->sequence_count = desc->sequence_count;
+   const uint32_t words = (desc->sequence_count + 63u) / 64u;
+   store->row_words = std::max(ROW_ALIGN_WORDS, (words + ROW_ALIGN_WORDS - 1) / ROW_ALIGN_WORDS * ROW_ALIGN_WORDS);
+   const uint32_t row_words = store->row_words;
+
+   auto cleanup = [&](int code) {
+      silo_gpu_store_destroy(store);
+      return code;
+   };
+
+   store->seqstores.resize(desc->n_seqstores);
+   for (uint32_t k = 0; k < desc->n_seqstores; ++k) {
+      const silo_gpu_seqstore_desc& in = desc->seqstores[k];
+      SeqStoreHost& seqstore = store->seqstores[k];
+      if (in.alphabet > SILO_GPU_ALPHABET_AMINO_ACID || in.positions == 0 || in.reference == nullptr) {
+         return cleanup(fail(SILO_GPU_ERR_INVALID_ARGUMENT, "invalid sequence store descriptor"));
+      }
+      seqstore.alphabet = in.alphabet;
+      seqstore.reference.assign(in.reference, in.reference + in.positions);
+      SeqStoreDev& dev = seqstore.dev;
+      dev.positions = in.positions;
+      dev.n_symbols = alphabetSize(in.alphabet);
+      dev.n_scan = in.n_scan_symbols;
+      dev.n_extra = in.n_extra_symbols;
+      dev.row_words = row_words;
+      dev.missing_symbol = missingSymbol(in.alphabet);
+      for (uint32_t s = 0; s < SILO_GPU_MAX_SYMBOLS; ++s) {
+         dev.kind[s] = PLANE_SPARSE;
+         dev.index[s] = 0;
+      }
+      for (uint32_t s = 0; s < in.n_scan_symbols; ++s) {
+         if (in.scan_symbols[s] >= dev.n_symbols) {
+            return cleanup(fail(SILO_GPU_ERR_INVALID_ARGUMENT, "scan symbol out of range"));
+         }
+         dev.kind[in.scan_symbols[s]] = PLANE_SCAN;
+         dev.index[in.scan_symbols[s]] = static_cast<uint8_t>(s);
+      }
+      for (uint32_t s = 0; s < in.n_extra_symbols; ++s) {
+         if (in.extra_symbols[s] >= dev.n_symbols || dev.kind[in.extra_symbols[s]] != PLANE_SPARSE) {
+            return cleanup(fail(SILO_GPU_ERR_INVALID_ARGUMENT, "extra symbol out of range or duplicated"));
+         }
+         dev.kind[in.extra_symbols[s]] = PLANE_EXTRA;
+         dev.index[in.extra_symbols[s]] = static_cast<uint8_t>(s);
+      }
+      const size_t scan_bytes = static_cast<size_t>(in.positions) * dev.n_scan * row_words * sizeof(uint64_t);
+      const size_t extra_bytes = static_cast<size_t>(in.positions) * dev.n_extra * row_words * sizeof(uint64_t);
+      hipError_t err = hipSuccess;
+      if (scan_bytes > 0) {
+         err = hipMalloc(&dev.scan, scan_bytes);
+         if (err == hipSuccess) {
+            err = hipMemset(dev.scan, 0, scan_bytes);
+         }
+      }
+      if (err == hipSuccess && extra_bytes > 0) {
+         err = hipMalloc(&dev.extra, extra_bytes);
+         if (err == hipSuccess) {
+            err = hipMemset(dev.extra, 0, extra_bytes);
+         }
+      }
+      if (err == hipSuccess) {
+         err = hipMalloc(&seqstore.d_reference, in.positions);
+      }
+      if (err == hipSuccess) {
+         err = hipMemcpy(seqstore.d_reference, in.reference, in.positions, hipMemcpyHostToDevice);
+      }
+      if (err == hipSuccess) {
+         err = hipMalloc(&seqstore.d_sparse_count, sizeof(uint32_t));
+      }
+      if (err == hipSuccess) {
+         err = hipMemset(seqstore.d_sparse_count, 0, sizeof(uint32_t));
+      }
+      if (err != hipSuccess) {
+         return cleanup(fail(
+            err == hipErrorOutOfMemory ? SILO_GPU_ERR_OUT_OF_MEMORY : SILO_GPU_ERR_HIP,
+            std::string("allocating planes: ") + hipGetErrorString(err)
+         ));
+      }
+      store->device_bytes += scan_bytes + extra_bytes;
+   }
+   hipError_t err = hipMalloc(&store->d_ones, static_cast<size_t>(row_words) * sizeof(uint64_t));
+   if (err == hipSuccess) {
+      err = hipMalloc(&store->d_error_flag, sizeof(uint32_t));
+   }
+   if (err == hipSuccess) {
+      err = hipMemset(store->d_error_flag, 0, sizeof(uint32_t));
+   }
+   if (err != hipSuccess) {
+      return cleanup(fail(SILO_GPU_ERR_HIP, std::string("allocating store: ") + hipGetErrorString(err)));
+   }
+   k_fill_ones<<<(row_words + 255) / 256, 256>>>(store->d_ones, row_words, store->sequence_count);
+   err = hipDeviceSynchronize();
+   if (err != hipSuccess) {
+      return cleanup(fail(SILO_GPU_ERR_HIP, std::string("k_fill_ones: ") + hipGetErrorString(err)));
+   }
+   *out = store;
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_store_destroy(silo_gpu_store* store) {
+   if (store == nullptr) {
+      return;
+   }
+   (void)hipSetDevice(store->device);
+   for (SeqStoreHost& seqstore : store->seqstores) {
+      (void)hipFree(seqstore.dev.scan);
+      (void)hipFree(seqstore.dev.extra);
+      (void)hipFree(seqstore.d_reference);
+      (void)hipFree(seqstore.d_sparse);
+      (void)hipFree(seqstore.d_sparse_count);
+   }
+   (void)hipFree(store->d_ones);
+   (void)hipFree(store->d_lineage);
+   (void)hipFree(store->d_error_flag);
+   delete store;
+}
+
+uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store) {
+   return store != nullptr ? store->sequence_count : 0;
+}
+uint32_t silo_gpu_store_row_words(const silo_gpu_store* store) {
+   return store != nullptr ? store->row_words : 0;
+}
+uint64_t silo_gpu_store_device_bytes(const silo_gpu_store* store) {
+   return store != nullptr ? store->device_bytes : 0;
+}
+
+int silo_gpu_store_append_sequences(
+   silo_gpu_store* store, uint32_t seqstore_id, uint32_t first_sequence, uint32_t n_sequences, const char* chars,
+   const uint8_t* is_null
+) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || (chars == nullptr && n_sequences > 0)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_append_sequences: bad arguments");
+   }
+   if (static_cast<uint64_t>(first_sequence) + n_sequences > store->sequence_count) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "append beyond sequence_count");
+   }
+   if (n_sequences == 0) {
+      return SILO_GPU_OK;
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   HIP_TRY(hipSetDevice(store->device));
+   SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   seqstore.finalized = false;
+   const uint32_t positions = seqstore.dev.positions;
+   const uint32_t pitch = (positions + 15u) / 16u * 16u;
+
+   uint8_t table[256];
+   fillCharTable(seqstore.alphabet, table);
+
+   uint8_t* d_chars = nullptr;
+   uint8_t* d_null = nullptr;
+   uint8_t* d_table = nullptr;
+   auto release = [&]() {
+      (void)hipFree(d_chars);
+      (void)hipFree(d_null);
+      (void)hipFree(d_table);
+   };
+   hipError_t err = hipMalloc(&d_chars, static_cast<size_t>(n_sequences) * pitch);
+   if (err == hipSuccess) {
+      err = hipMemset(d_chars, 0, static_cast<size_t>(n_sequences) * pitch);
+   }
+   if (err == hipSuccess) {
+      err = hipMemcpy2D(d_chars, pitch, chars, positions, positions, n_sequences, hipMemcpyHostToDevice);
+   }
+   if (err == hipSuccess && is_null != nullptr) {
+      err = hipMalloc(&d_null, n_sequences);
+      if (err == hipSuccess) {
+         err = hipMemcpy(d_null, is_null, n_sequences, hipMemcpyHostToDevice);
+      }
+   }
+   if (err == hipSuccess) {
+      err = hipMalloc(&d_table, 256);
+   }
+   if (err == hipSuccess) {
+      err = hipMemcpy(d_table, table, 256, hipMemcpyHostToDevice);
+   }
+   if (err != hipSuccess) {
+      release();
+      return fail(SILO_GPU_ERR_HIP, std::string("staging sequences: ") + hipGetErrorString(err));
+   }
+
+   const uint32_t first_word = first_sequence / 64u;
+   const uint32_t last_word = (first_sequence + n_sequences - 1u) / 64u;
+   const uint32_t n_words = last_word - first_word + 1u;
+   const dim3 grid((n_words + 3) / 4, (positions + TRANSPOSE_POSITIONS_PER_WAVE - 1) / TRANSPOSE_POSITIONS_PER_WAVE);
+
+   uint32_t count_before = 0;
+   err = hipMemcpy(&count_before, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+   if (err != hipSuccess) {
+      release();
+      return fail(SILO_GPU_ERR_HIP, std::string("reading sparse counter: ") + hipGetErrorString(err));
+   }
+   if (int rc = growSparse(seqstore, count_before + (1u << 16)); rc != SILO_GPU_OK) {
+      release();
+      return rc;
+   }
+   // The dense writes are idempotent (atomicOr / whole-word stores); if the sparse buffer overflows
+   // the counter is rewound, the buffer grown and the batch replayed.
+   for (int attempt = 0; attempt < 8; ++attempt) {
+      k_transpose_sequences<<<grid, 256>>>(
+         seqstore.dev, d_chars, d_null, pitch, first_sequence, n_sequences, first_word, n_words, d_table,
+         seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity, store->d_error_flag
+      );
+      err = hipDeviceSynchronize();
+      uint32_t count_after = 0;
+      if (err == hipSuccess) {
+         err = hipMemcpy(&count_after, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+      }
+      if (err != hipSuccess) {
+         release();
+         return fail(SILO_GPU_ERR_HIP, std::string("k_transpose_sequences: ") + hipGetErrorString(err));
+      }
+      if (count_after <= seqstore.sparse_capacity) {
+         break;
+      }
+      err = hipMemcpy(seqstore.d_sparse_count, &count_before, sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (err != hipSuccess) {
+         release();
+         return fail(SILO_GPU_ERR_HIP, std::string("rewinding sparse counter: ") + hipGetErrorString(err));
+      }
+      if (int rc = growSparse(seqstore, count_after); rc != SILO_GPU_OK) {
+         release();
+         return rc;
+      }
+   }
+   release();
+   uint32_t error_flag = 0;
+   HIP_TRY(hipMemcpy(&error_flag, store->d_error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+   if (error_flag != 0) {
+      HIP_TRY(hipMemset(store->d_error_flag, 0, sizeof(uint32_t)));
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "Illegal character contained in sequence.");
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_id, const silo_gpu_synth_desc* synth) {
+   if (store == nullptr || synth == nullptr || seqstore_id >= store->seqstores.size() || synth->n_lineages == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_generate_synthetic: bad arguments");
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   HIP_TRY(hipSetDevice(store->device));
+   SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   seqstore.finalized = false;
+   const uint32_t n = store->sequence_count;
+   const uint32_t positions = seqstore.dev.positions;
+
+   uint32_t* d_u32[4] = {nullptr, nullptr, nullptr, nullptr};
+   uint8_t* d_lineage_symbol = nullptr;
+   auto release = [&]() {
+      for (auto* ptr : d_u32) {
+         (void)hipFree(ptr);
+      }
+      (void)hipFree(d_lineage_symbol);
+   };
+   hipError_t err = hipSuccess;
+   if (store->d_lineage == nullptr) {
+      err = hipMalloc(&store->d_lineage, static_cast<size_t>(n) * sizeof(uint16_t));
+   }
+   if (err == hipSuccess) {
+      err = hipMemcpy(store->d_lineage, synth->lineage_of_sequence, static_cast<size_t>(n) * sizeof(uint16_t), hipMemcpyHostToDevice);
+      store->n_lineages = synth->n_lineages;
+   }
+   const uint32_t* host_u32[4] = {synth->lead_gap, synth->trail_gap, synth->missing_start, synth->missing_len};
+   for (int k = 0; k < 4 && err == hipSuccess; ++k) {
+      err = hipMalloc(&d_u32[k], static_cast<size_t>(n) * sizeof(uint32_t));
+      if (err == hipSuccess) {
+         err = hipMemcpy(d_u32[k], host_u32[k], static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice);
+      }
+   }
+   const size_t table_bytes = static_cast<size_t>(positions) * synth->n_lineages;
+   if (err == hipSuccess) {
+      err = hipMalloc(&d_lineage_symbol, table_bytes);
+   }
+   if (err == hipSuccess) {
+      err = hipMemcpy(d_lineage_symbol, synth->lineage_symbol, table_bytes, hipMemcpyHostToDevice);
+   }
+   if (err != hipSuccess) {
+      release();
+      return fail(SILO_GPU_ERR_HIP, std::string("staging synthetic model: ") + hipGetErrorString(err));
+   }
+
+   SynthArgs args{};
+   args.seed = synth->seed;
+   args.n_lineages = synth->n_lineages;
+   args.sequence_count = n;
+   args.lineage = store->d_lineage;
+   args.lead_gap = d_u32[0];
+   args.trail_gap = d_u32[1];
+   args.missing_start = d_u32[2];
+   args.missing_len = d_u32[3];
+   args.lineage_symbol = d_lineage_symbol;
+   args.reference = seqstore.d_reference;
+   args.private_threshold = synth->private_threshold;
+   args.ambiguous_threshold = synth->ambiguous_threshold;
+   if (seqstore.alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE) {
+      args.private_base = 1;
+      args.private_count = 4;
+      args.ambiguous_base = 5;
+      args.ambiguous_count = 10;
+   } else {
+      args.private_base = 1;
+      args.private_count = 20;
+      args.ambiguous_base = 21;
+      args.ambiguous_count = 2;
+   }
+
+   const uint32_t n_words = (n + 63u) / 64u;
+   const dim3 grid((n_words + 3) / 4, (positions + SYNTH_POSITIONS_PER_WAVE - 1) / SYNTH_POSITIONS_PER_WAVE);
+   // expected sparse entries: cells * ambiguous_threshold / 2^24 (+ slack)
+   const double expected = static_cast<double>(n) * positions * (static_cast<double>(synth->ambiguous_threshold) / 16777216.0);
+   uint32_t zero = 0;
+   err = hipMemcpy(seqstore.d_sparse_count, &zero, sizeof(uint32_t), hipMemcpyHostToDevice);
+   if (err != hipSuccess) {
+      release();
+      return fail(SILO_GPU_ERR_HIP, std::string("resetting sparse counter: ") + hipGetErrorString(err));
+   }
+   const double wanted = expected * 1.25 + 65536.0;
+   if (wanted > 4.0e9) {
+      release();
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "ambiguous_threshold too large for the sparse store");
+   }
+   if (int rc = growSparse(seqstore, static_cast<uint32_t>(wanted)); rc != SILO_GPU_OK) {
+      release();
+      return rc;
+   }
+   for (int attempt = 0; attempt < 4; ++attempt) {
+      k_generate_synthetic<<<grid, 256>>>(
+         seqstore.dev, args, n_words, seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity
+      );
+      err = hipDeviceSynchronize();
+      uint32_t count_after = 0;
+      if (err == hipSuccess) {
+         err = hipMemcpy(&count_after, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+      }
+      if (err != hipSuccess) {
+         release();
+         return fail(SILO_GPU_ERR_HIP, std::string("k_generate_synthetic: ") + hipGetErrorString(err));
+      }
+      if (count_after <= seqstore.sparse_capacity) {
+         break;
+      }
+      err = hipMemcpy(seqstore.d_sparse_count, &zero, sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (err != hipSuccess) {
+         release();
+         return fail(SILO_GPU_ERR_HIP, std::string("rewinding sparse counter: ") + hipGetErrorString(err));
+      }
+      if (int rc = growSparse(seqstore, count_after); rc != SILO_GPU_OK) {
+         release();
+         return rc;
+      }
+   }
+   release();
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_store_finalize(silo_gpu_store* store) {
+   if (store == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_finalize: null store");
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   HIP_TRY(hipSetDevice(store->device));
+   for (SeqStoreHost& seqstore : store->seqstores) {
+      uint32_t count = 0;
+      HIP_TRY(hipMemcpy(&count, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      count = std::min(count, seqstore.sparse_capacity);
+      seqstore.sparse_sorted.resize(count);
+      if (count > 0) {
+         HIP_TRY(hipMemcpy(seqstore.sparse_sorted.data(), seqstore.d_sparse, static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+         std::sort(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end());
+         // a replayed batch may have appended duplicates
+         seqstore.sparse_sorted.erase(
+            std::unique(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end()), seqstore.sparse_sorted.end()
+         );
+         count = static_cast<uint32_t>(seqstore.sparse_sorted.size());
+         HIP_TRY(hipMemcpy(seqstore.d_sparse, seqstore.sparse_sorted.data(), static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyHostToDevice));
+         HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
+      }
+      seqstore.finalized = true;
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_malloc(size_t bytes, void** out_dev) {
+   if (out_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_malloc: null out pointer");
+   }
+   HIP_TRY(hipMalloc(out_dev, bytes));
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_free(void* dev_ptr) {
+   (void)hipFree(dev_ptr);
+}
+
+int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) {
+   HIP_TRY(hipMemsetAsync(dev_ptr, value, bytes, static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_stream_synchronize(void* stream) {
+   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_alloc(const silo_gpu_store* store, uint64_t** out_dev) {
+   if (store == nullptr || out_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_alloc: bad arguments");
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   const size_t bytes = static_cast<size_t>(store->row_words) * sizeof(uint64_t);
+   HIP_TRY(hipMalloc(out_dev, bytes));
+   HIP_TRY(hipMemset(*out_dev, 0, bytes));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_upload(const silo_gpu_store* store, uint64_t* dst_dev, const uint64_t* src_host, size_t n_words, void* stream) {
+   if (store == nullptr || dst_dev == nullptr || src_host == nullptr || n_words > store->row_words) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_upload: bad arguments");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(store->row_words) * sizeof(uint64_t), hip_stream));
+   HIP_TRY(hipMemcpyAsync(dst_dev, src_host, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, hip_stream));
+   HIP_TRY(hipStreamSynchronize(hip_stream));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_download(const silo_gpu_store* store, uint64_t* dst_host, const uint64_t* src_dev, size_t n_words, void* stream) {
+   if (store == nullptr || dst_host == nullptr || src_dev == nullptr || n_words > store->row_words) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_download: bad arguments");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, hip_stream));
+   HIP_TRY(hipStreamSynchronize(hip_stream));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_from_lineages(const silo_gpu_store* store, uint64_t* dst_dev, const uint8_t* membership_by_lineage, uint32_t n_lineages, void* stream) {
+   if (store == nullptr || dst_dev == nullptr || membership_by_lineage == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_from_lineages: bad arguments");
+   }
+   if (store->d_lineage == nullptr || n_lineages != store->n_lineages) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "store holds no synthetic lineage assignment of that size");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   uint8_t* d_membership = nullptr;
+   HIP_TRY(hipMalloc(&d_membership, n_lineages));
+   hipError_t err = hipMemcpyAsync(d_membership, membership_by_lineage, n_lineages, hipMemcpyHostToDevice, hip_stream);
+   if (err == hipSuccess) {
+      const uint32_t threads = store->row_words * 64u;
+      k_bitset_from_lineages<<<(threads + 255) / 256, 256, 0, hip_stream>>>(
+         store->d_lineage, d_membership, store->sequence_count, store->row_words, dst_dev
+      );
+      err = hipStreamSynchronize(hip_stream);
+   }
+   (void)hipFree(d_membership);
+   if (err != hipSuccess) {
+      return fail(SILO_GPU_ERR_HIP, std::string("k_bitset_from_lineages: ") + hipGetErrorString(err));
+   }
+   return SILO_GPU_OK;
+}
+
+const uint64_t* silo_gpu_store_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size()) {
+      return nullptr;
+   }
+   const SeqStoreDev& dev = store->seqstores[seqstore_id].dev;
+   if (position >= dev.positions || symbol >= dev.n_symbols) {
+      return nullptr;
+   }
+   return planePtr(dev, position, symbol);
+}
+
+int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol, uint64_t* dst_dev, void* stream) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || dst_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_sparse_plane: bad arguments");
+   }
+   const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   if (position >= seqstore.dev.positions || symbol >= seqstore.dev.n_symbols) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position or symbol out of range");
+   }
+   if (!seqstore.finalized) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "store not finalized");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(store->row_words) * sizeof(uint64_t), hip_stream));
+   const uint64_t key_begin = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32);
+   const uint64_t key_end = key_begin + (1ull << 32);
+   const auto lo = std::lower_bound(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end(), key_begin);
+   const auto hi = std::lower_bound(lo, seqstore.sparse_sorted.end(), key_end);
+   const uint32_t begin = static_cast<uint32_t>(lo - seqstore.sparse_sorted.begin());
+   const uint32_t end = static_cast<uint32_t>(hi - seqstore.sparse_sorted.begin());
+   if (end > begin) {
+      k_scatter_sparse<<<(end - begin + 255) / 256, 256, 0, hip_stream>>>(seqstore.d_sparse, begin, end, dst_dev);
+      HIP_TRY(hipGetLastError());
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream) {
+   if (store == nullptr || program == nullptr || program->code == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
+   }
+   if (program->n_instructions == 0 || program->n_instructions > SILO_GPU_MAX_INSTRUCTIONS ||
+       program->n_leaves > SILO_GPU_MAX_LEAVES || program->n_slots == 0 || program->n_slots > SILO_GPU_MAX_SLOTS) {
+      return fail(SILO_GPU_ERR_PROGRAM_TOO_LARGE, "bit-program exceeds the instruction / leaf / slot limits");
+   }
+   // validate operands on the host: a bad slot or leaf index would be an out-of-bounds LDS / global access
+   for (uint32_t pc = 0; pc < program->n_instructions; ++pc) {
+      const uint32_t w0 = program->code[2 * pc];
+      const uint32_t imm = program->code[2 * pc + 1];
+      const uint32_t op = w0 & 0xFFu, dst = (w0 >> 8) & 0xFFu, a = (w0 >> 16) & 0xFFu, b = (w0 >> 24) & 0xFFu;
+      bool ok = true;
+      switch (op) {
+         case SILO_GPU_OP_LOAD:
+            ok = dst < program->n_slots && imm < program->n_leaves && program->leaves != nullptr && program->leaves[imm] != nullptr;
+            break;
+         case SILO_GPU_OP_ZERO:
+         case SILO_GPU_OP_ONES:
+            ok = dst < program->n_slots;
+            break;
+         case SILO_GPU_OP_NOT:
+         case SILO_GPU_OP_MOV:
+            ok = dst < program->n_slots && a < program->n_slots;
+            break;
+         case SILO_GPU_OP_AND:
+         case SILO_GPU_OP_OR:
+         case SILO_GPU_OP_ANDNOT:
+            ok = dst < program->n_slots && a < program->n_slots && b < program->n_slots;
+            break;
+         case SILO_GPU_OP_CNT_ADD:
+            ok = a < program->n_slots && b >= 1 && dst + b <= program->n_slots;
+            break;
+         case SILO_GPU_OP_CNT_GE:
+         case SILO_GPU_OP_CNT_EQ:
+            ok = dst < program->n_slots && b >= 1 && a + b <= program->n_slots;
+            break;
+         default:
+            ok = false;
+      }
+      if (!ok) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "bit-program instruction " + std::to_string(pc) + " has an invalid operand");
+      }
+   }
+   FilterEvalArgs args{};
+   args.n_instructions = program->n_instructions;
+   args.sequence_count = store->sequence_count;
+   args.row_words = store->row_words;
+   args.n_slots = program->n_slots;
+   args.out = out_bitset_dev;
+   args.out_count = reinterpret_cast<unsigned long long*>(out_count_dev);
+   for (uint32_t k = 0; k < program->n_leaves; ++k) {
+      args.leaves[k] = program->leaves[k];
+   }
+   memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
+   const uint32_t blocks = std::min<uint32_t>((store->row_words + EVAL_THREADS - 1) / EVAL_THREADS, 2048u);
+   const size_t lds_bytes = static_cast<size_t>(program->n_slots) * EVAL_THREADS * sizeof(uint64_t);
+   k_filter_eval<<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
+   HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev, void* stream) {
+   if (store == nullptr || bitset_dev == nullptr || out_count_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_popcount: bad arguments");
+   }
+   const uint32_t chunks = store->row_words / 2;
+   const uint32_t blocks = std::min<uint32_t>((chunks + 255) / 256, 1024u);
+   k_popcount<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      bitset_dev, store->row_words, reinterpret_cast<unsigned long long*>(out_count_dev)
+   );
+   HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_mutations_scan(
+   const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev, uint32_t pos_begin, uint32_t pos_end,
+   uint32_t* counts_out_dev, void* stream
+) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || counts_out_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan: bad arguments");
+   }
+   const SeqStoreDev& dev = store->seqstores[seqstore_id].dev;
+   if (pos_begin > pos_end || pos_end > dev.positions) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");
+   }
+   if (pos_begin == pos_end || dev.n_scan == 0) {
+      return SILO_GPU_OK;
+   }
+   const uint64_t* filter = filter_dev != nullptr ? filter_dev : store->d_ones;
+   const uint32_t row_words = dev.row_words;
+   const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
+   const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
+   auto hip_stream = static_cast<hipStream_t>(stream);
+
+   constexpr int WPT = 8;
+   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
+   const int variant = g_tune_scan_variant.load();
+   const bool tiled = variant == 1 || (variant == 0 && row_words >= TILE_WORDS);
+   if (!tiled) {
+      const uint32_t waves = std::min<uint32_t>(n_rows, 256u * 32u);
+      const uint32_t blocks = (waves + 3) / 4;
+      k_scan_rowwave<<<blocks, 256, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows);
+      g_last_scan_kernel = "k_scan_rowwave";
+      HIP_TRY(hipGetLastError());
+      return SILO_GPU_OK;
+   }
+   int rows_per_block = g_tune_rows_per_block.load();
+   if (rows_per_block <= 0) {
+      rows_per_block = 256;
+   }
+   const uint32_t full_tiles = row_words / TILE_WORDS;
+   const bool ragged = row_words % TILE_WORDS != 0;
+   const uint32_t row_groups = (n_rows + rows_per_block - 1) / rows_per_block;
+   if (full_tiles > 0) {
+      k_scan_tiled<WPT, false><<<full_tiles * row_groups, SCAN_THREADS, 0, hip_stream>>>(
+         planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, full_tiles, 0
+      );
+      HIP_TRY(hipGetLastError());
+   }
+   if (ragged) {
+      k_scan_tiled<WPT, true><<<row_groups, SCAN_THREADS, 0, hip_stream>>>(
+         planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, 1, full_tiles
+      );
+      HIP_TRY(hipGetLastError());
+   }
+   g_last_scan_kernel = "k_scan_tiled";
+   return SILO_GPU_OK;
+}
+
+}  // extern "C"

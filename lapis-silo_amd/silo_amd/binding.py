@@ -1,0 +1,364 @@
+"""ctypes binding of include/silo_gpu.h (the C-ABI drop-in boundary).
+
+This is the stub a maintainer of a Python host would write; the reference's own host is C++ and binds
+the same symbols directly.  There is no CPU fallback: if the HIP library is missing or
+no GPU is visible every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import alphabet
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+_LIB_PATH = os.path.join(_LIB_DIR, "libsilo_gpu.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_u16p = ctypes.POINTER(ctypes.c_uint16)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class SiloGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"silo_gpu error {code}: {message}")
+        self.code = code
+
+
+class SeqStoreDesc(ctypes.Structure):
+    _fields_ = [
+        ("alphabet", ctypes.c_uint32),
+        ("positions", ctypes.c_uint32),
+        ("reference", c_u8p),
+        ("n_scan_symbols", ctypes.c_uint32),
+        ("scan_symbols", c_u8p),
+        ("n_extra_symbols", ctypes.c_uint32),
+        ("extra_symbols", c_u8p),
+    ]
+
+
+class StoreDesc(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32),
+        ("sequence_count", ctypes.c_uint32),
+        ("n_seqstores", ctypes.c_uint32),
+        ("seqstores", ctypes.POINTER(SeqStoreDesc)),
+    ]
+
+
+class SynthDesc(ctypes.Structure):
+    _fields_ = [
+        ("seed", ctypes.c_uint64),
+        ("n_lineages", ctypes.c_uint32),
+        ("lineage_of_sequence", c_u16p),
+        ("lead_gap", c_u32p),
+        ("trail_gap", c_u32p),
+        ("missing_start", c_u32p),
+        ("missing_len", c_u32p),
+        ("lineage_symbol", c_u8p),
+        ("private_threshold", ctypes.c_uint32),
+        ("ambiguous_threshold", ctypes.c_uint32),
+    ]
+
+
+class BitProg(ctypes.Structure):
+    _fields_ = [
+        ("n_instructions", ctypes.c_uint32),
+        ("code", c_u32p),
+        ("n_leaves", ctypes.c_uint32),
+        ("leaves", ctypes.POINTER(ctypes.c_void_p)),
+        ("n_slots", ctypes.c_uint32),
+    ]
+
+
+# every symbol include/silo_gpu.h declares; tests check the library exports all of them
+EXPORTED_SYMBOLS = [
+    "silo_gpu_store_create", "silo_gpu_store_destroy", "silo_gpu_store_sequence_count",
+    "silo_gpu_store_row_words", "silo_gpu_store_device_bytes", "silo_gpu_store_append_sequences",
+    "silo_gpu_store_finalize", "silo_gpu_store_generate_synthetic", "silo_gpu_bitset_alloc",
+    "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_free",
+    "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_stream_synchronize", "silo_gpu_store_plane",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan",
+    "silo_gpu_memset_async", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads lib/libsilo_gpu.so; raises loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The product path has no CPU fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp = ctypes.c_void_p
+    lib.silo_gpu_store_create.argtypes = [ctypes.POINTER(StoreDesc), ctypes.POINTER(vp)]
+    lib.silo_gpu_store_destroy.argtypes = [vp]
+    lib.silo_gpu_store_destroy.restype = None
+    lib.silo_gpu_store_sequence_count.argtypes = [vp]
+    lib.silo_gpu_store_sequence_count.restype = ctypes.c_uint32
+    lib.silo_gpu_store_row_words.argtypes = [vp]
+    lib.silo_gpu_store_row_words.restype = ctypes.c_uint32
+    lib.silo_gpu_store_device_bytes.argtypes = [vp]
+    lib.silo_gpu_store_device_bytes.restype = ctypes.c_uint64
+    lib.silo_gpu_store_append_sequences.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_store_finalize.argtypes = [vp]
+    lib.silo_gpu_store_generate_synthetic.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(SynthDesc)]
+    lib.silo_gpu_bitset_alloc.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.silo_gpu_bitset_upload.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_bitset_download.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_bitset_from_lineages.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
+    lib.silo_gpu_free.argtypes = [vp]
+    lib.silo_gpu_free.restype = None
+    lib.silo_gpu_malloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.silo_gpu_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_stream_synchronize.argtypes = [vp]
+    lib.silo_gpu_store_plane.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.silo_gpu_store_plane.restype = vp
+    lib.silo_gpu_store_sparse_plane.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_filter_eval.argtypes = [vp, ctypes.POINTER(BitProg), vp, vp, vp]
+    lib.silo_gpu_popcount.argtypes = [vp, vp, vp, vp]
+    lib.silo_gpu_mutations_scan.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_memset_async.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
+    lib.silo_gpu_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.silo_gpu_last_scan_kernel.restype = ctypes.c_char_p
+    lib.silo_gpu_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SiloGpuError(rc, load_library().silo_gpu_last_error().decode())
+
+
+def _ptr(array):
+    return array.ctypes.data_as(ctypes.c_void_p)
+
+
+# bit-program opcodes (include/silo_gpu.h)
+OP_LOAD, OP_ZERO, OP_ONES, OP_NOT, OP_AND, OP_OR, OP_ANDNOT, OP_CNT_ADD, OP_CNT_GE, OP_CNT_EQ, OP_MOV = range(11)
+
+
+def encode(op, dst=0, a=0, b=0, imm=0):
+    return [op | (dst << 8) | (a << 16) | (b << 24), imm]
+
+
+class GpuStore:
+    """One device shard: the dense restatement of a DatabasePartition's sequence stores."""
+
+    def __init__(self, sequence_count, seqstores, device=0):
+        """seqstores: list of dicts {name, alphabet ('nuc'|'aa'), reference (np.uint8 symbol ids)}."""
+        self.lib = load_library()
+        self.sequence_count = int(sequence_count)
+        self.names = [s["name"] for s in seqstores]
+        self.alphabets = [s["alphabet"] for s in seqstores]
+        self.references = [np.ascontiguousarray(s["reference"], dtype=np.uint8) for s in seqstores]
+        self._keep = []
+        descs = (SeqStoreDesc * len(seqstores))()
+        self.scan_symbols = []
+        for k, s in enumerate(seqstores):
+            alpha = alphabet.ALPHABETS[s["alphabet"]]
+            scan = np.array(s.get("scan_symbols", alpha.valid_mutation_symbols), dtype=np.uint8)
+            extra = np.array(s.get("extra_symbols", [alpha.missing]), dtype=np.uint8)
+            self._keep += [scan, extra]
+            self.scan_symbols.append(scan)
+            descs[k].alphabet = alpha.abi_id
+            descs[k].positions = len(self.references[k])
+            descs[k].reference = self.references[k].ctypes.data_as(c_u8p)
+            descs[k].n_scan_symbols = len(scan)
+            descs[k].scan_symbols = scan.ctypes.data_as(c_u8p)
+            descs[k].n_extra_symbols = len(extra)
+            descs[k].extra_symbols = extra.ctypes.data_as(c_u8p)
+        desc = StoreDesc(device, self.sequence_count, len(seqstores), descs)
+        handle = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_store_create(ctypes.byref(desc), ctypes.byref(handle)))
+        self.handle = handle
+        self.row_words = self.lib.silo_gpu_store_row_words(handle)
+        self._owned = []
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None):
+            for ptr in self._owned:
+                self.lib.silo_gpu_free(ptr)
+            self._owned = []
+            self.lib.silo_gpu_store_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def device_bytes(self):
+        return self.lib.silo_gpu_store_device_bytes(self.handle)
+
+    def seqstore_id(self, name):
+        return self.names.index(name)
+
+    def positions(self, seqstore_id):
+        return len(self.references[seqstore_id])
+
+    # -- build ----------------------------------------------------------------------------------
+    def append_sequences(self, seqstore_id, first_sequence, sequences, is_null=None):
+        """sequences: list of str/bytes (None = missing genome) or uint8 array [n][P] of characters."""
+        positions = self.positions(seqstore_id)
+        if isinstance(sequences, np.ndarray):
+            chars = np.ascontiguousarray(sequences, dtype=np.uint8)
+            n = chars.shape[0]
+        else:
+            n = len(sequences)
+            chars = np.zeros((n, positions), dtype=np.uint8)
+            if is_null is None:
+                is_null = np.zeros(n, dtype=np.uint8)
+            for i, seq in enumerate(sequences):
+                if seq is None:
+                    is_null[i] = 1
+                    continue
+                raw = seq.encode() if isinstance(seq, str) else bytes(seq)
+                if len(raw) != positions:
+                    raise ValueError(f"sequence {i} has length {len(raw)}, expected {positions}")
+                chars[i] = np.frombuffer(raw, dtype=np.uint8)
+        assert chars.shape == (n, positions)
+        null_ptr = None
+        if is_null is not None:
+            is_null = np.ascontiguousarray(is_null, dtype=np.uint8)
+            null_ptr = _ptr(is_null)
+        _check(self.lib.silo_gpu_store_append_sequences(self.handle, seqstore_id, first_sequence, n, _ptr(chars), null_ptr))
+
+    def generate_synthetic(self, seqstore_id, model):
+        """model: silo_amd.synth.SynthModel for this sequence store."""
+        arrays = dict(
+            lineage=np.ascontiguousarray(model.lineage_of_sequence, dtype=np.uint16),
+            lead=np.ascontiguousarray(model.lead_gap, dtype=np.uint32),
+            trail=np.ascontiguousarray(model.trail_gap, dtype=np.uint32),
+            mstart=np.ascontiguousarray(model.missing_start, dtype=np.uint32),
+            mlen=np.ascontiguousarray(model.missing_len, dtype=np.uint32),
+            table=np.ascontiguousarray(model.lineage_symbol, dtype=np.uint8),
+        )
+        assert len(arrays["lineage"]) == self.sequence_count
+        assert arrays["table"].shape == (self.positions(seqstore_id), model.n_lineages)
+        desc = SynthDesc(
+            model.seed, model.n_lineages,
+            arrays["lineage"].ctypes.data_as(c_u16p), arrays["lead"].ctypes.data_as(c_u32p),
+            arrays["trail"].ctypes.data_as(c_u32p), arrays["mstart"].ctypes.data_as(c_u32p),
+            arrays["mlen"].ctypes.data_as(c_u32p), arrays["table"].ctypes.data_as(c_u8p),
+            model.private_threshold, model.ambiguous_threshold,
+        )
+        _check(self.lib.silo_gpu_store_generate_synthetic(self.handle, seqstore_id, ctypes.byref(desc)))
+
+    def finalize(self):
+        _check(self.lib.silo_gpu_store_finalize(self.handle))
+
+    # -- device buffers -------------------------------------------------------------------------
+    def bitset_alloc(self):
+        ptr = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_bitset_alloc(self.handle, ctypes.byref(ptr)))
+        self._owned.append(ptr)
+        return ptr
+
+    def malloc(self, nbytes):
+        ptr = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_malloc(nbytes, ctypes.byref(ptr)))
+        self._owned.append(ptr)
+        return ptr
+
+    def free(self, ptr):
+        self._owned = [p for p in self._owned if p.value != ptr.value]
+        self.lib.silo_gpu_free(ptr)
+
+    def bitset_upload(self, ptr, words, stream=None):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        _check(self.lib.silo_gpu_bitset_upload(self.handle, ptr, _ptr(words), len(words), stream))
+
+    def bitset_download(self, ptr, stream=None):
+        out = np.empty(self.row_words, dtype=np.uint64)
+        _check(self.lib.silo_gpu_bitset_download(self.handle, _ptr(out), ptr, self.row_words, stream))
+        return out
+
+    def bitset_from_lineages(self, ptr, membership, stream=None):
+        membership = np.ascontiguousarray(membership, dtype=np.uint8)
+        _check(self.lib.silo_gpu_bitset_from_lineages(self.handle, ptr, _ptr(membership), len(membership), stream))
+
+    def plane(self, seqstore_id, position, symbol):
+        """Device pointer (int) of a dense plane or None for a sparse symbol."""
+        return self.lib.silo_gpu_store_plane(self.handle, seqstore_id, position, symbol)
+
+    def plane_download(self, seqstore_id, position, symbol):
+        ptr = self.plane(seqstore_id, position, symbol)
+        if ptr is None:
+            tmp = self.bitset_alloc()
+            _check(self.lib.silo_gpu_store_sparse_plane(self.handle, seqstore_id, position, symbol, tmp, None))
+            out = self.bitset_download(tmp)
+            self.free(tmp)
+            return out
+        return self.bitset_download(ctypes.c_void_p(ptr))
+
+    def sparse_plane(self, seqstore_id, position, symbol, dst, stream=None):
+        _check(self.lib.silo_gpu_store_sparse_plane(self.handle, seqstore_id, position, symbol, dst, stream))
+
+    def memset(self, ptr, value, nbytes, stream=None):
+        _check(self.lib.silo_gpu_memset_async(ptr, value, nbytes, stream))
+
+    def read(self, ptr, dtype, count, stream=None):
+        out = np.empty(count, dtype=dtype)
+        _check(self.lib.silo_gpu_memcpy_d2h(_ptr(out), ptr, out.nbytes, stream))
+        return out
+
+    def synchronize(self, stream=None):
+        _check(self.lib.silo_gpu_stream_synchronize(stream))
+
+    # -- kernels --------------------------------------------------------------------------------
+    def filter_eval(self, code, leaves, n_slots, out_bitset=None, out_count=None, stream=None):
+        """code: flat list of uint32 (2 per instruction); leaves: list of device pointers (int)."""
+        code = np.ascontiguousarray(code, dtype=np.uint32)
+        leaf_array = (ctypes.c_void_p * max(1, len(leaves)))(*[
+            (l.value if isinstance(l, ctypes.c_void_p) else l) for l in leaves
+        ])
+        prog = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
+        _check(self.lib.silo_gpu_filter_eval(self.handle, ctypes.byref(prog), out_bitset, out_count, stream))
+
+    def popcount(self, bitset, stream=None):
+        counter = self.malloc(8)
+        self.memset(counter, 0, 8, stream)
+        _check(self.lib.silo_gpu_popcount(self.handle, bitset, counter, stream))
+        value = int(self.read(counter, np.uint64, 1, stream)[0])
+        self.free(counter)
+        return value
+
+    def mutations_scan_async(self, seqstore_id, filter_ptr, pos_begin, pos_end, counts_ptr, stream=None):
+        _check(self.lib.silo_gpu_mutations_scan(self.handle, seqstore_id, filter_ptr, pos_begin, pos_end, counts_ptr, stream))
+
+    def mutations_scan(self, seqstore_id, filter_ptr=None, pos_begin=0, pos_end=None, stream=None):
+        """Returns uint32 counts [pos_end - pos_begin][n_scan_symbols]."""
+        if pos_end is None:
+            pos_end = self.positions(seqstore_id)
+        n_scan = len(self.scan_symbols[seqstore_id])
+        n = (pos_end - pos_begin) * n_scan
+        counts = self.malloc(max(4, 4 * n))
+        self.memset(counts, 0, max(4, 4 * n), stream)
+        self.mutations_scan_async(seqstore_id, filter_ptr, pos_begin, pos_end, counts, stream)
+        out = self.read(counts, np.uint32, n, stream).reshape(pos_end - pos_begin, n_scan)
+        self.free(counts)
+        return out
+
+    def last_scan_kernel(self):
+        return self.lib.silo_gpu_last_scan_kernel().decode()
+
+    def tune(self, knob, value):
+        return self.lib.silo_gpu_tune(knob, value)

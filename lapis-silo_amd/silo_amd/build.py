@@ -1,0 +1,96 @@
+"""Compile the native pieces in-tree.
+
+  lib/libsilo_gpu.so     HIP kernels + C ABI (include/silo_gpu.h), hipcc --offload-arch=gfx950
+  lib/libsilo_engine.so  C++ host mirror of silo::query_engine (include/silo_engine.h), links libsilo_gpu
+  lib/bitprog_host       g++ build of the bit-program interpreter for host-logic unit tests
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container and the resulting
+.so files travel to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # .../lapis-silo_amd
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "lib")
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError("build step failed: " + " ".join(cmd))
+    return proc
+
+
+def _glob(directory, suffixes):
+    out = []
+    if os.path.isdir(directory):
+        for name in sorted(os.listdir(directory)):
+            if name.endswith(suffixes):
+                out.append(os.path.join(directory, name))
+    return out
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_gpu(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libsilo_gpu.so")
+    sources = [os.path.join(CSRC, "silo_gpu.hip")]
+    deps = sources + _glob(CSRC, (".h",)) + _glob(INCLUDE, (".h",))
+    if force or _newer(target, deps):
+        _run([
+            hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            "-Wall", "-Wextra", "-I", INCLUDE, *sources, "-o", target, "-Wl,-rpath,/opt/rocm/lib",
+        ])
+    return target
+
+
+def build_engine(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libsilo_engine.so")
+    sources = _glob(HOST, (".cpp",))
+    if not sources:
+        return None
+    deps = sources + _glob(HOST, (".h",)) + _glob(INCLUDE, (".h",)) + [os.path.join(LIB, "libsilo_gpu.so")]
+    if force or _newer(target, deps):
+        _run([
+            "g++", "-O2", "-g", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", HOST,
+            *sources, "-o", target, "-L", LIB, "-lsilo_gpu", "-Wl,-rpath,$ORIGIN", "-pthread",
+        ])
+    return target
+
+
+def build_host_tools(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    src = os.path.join(ROOT, "tests", "host_tools", "bitprog_host.cpp")
+    if not os.path.exists(src):
+        return None
+    target = os.path.join(LIB, "libbitprog_host.so")
+    if force or _newer(target, [src, os.path.join(CSRC, "bitprog.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, src, "-o", target])
+    return target
+
+
+def build_all(force=False):
+    return [build_gpu(force), build_engine(force), build_host_tools(force)]
+
+
+if __name__ == "__main__":
+    for path in build_all(force="--force" in sys.argv):
+        print(path)

@@ -1,0 +1,171 @@
+"""Parity of the HIP kernels (through the C ABI) against the naive per-character oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense  # noqa: E402
+from oracle import synth as oracle_synth  # noqa: E402
+
+NUC_CHARS = np.frombuffer(b"-ACGTRYSWKMBDHVN", dtype=np.uint8)
+AA_CHARS = np.frombuffer(b"-ACDEFGHIKLMNPQRSTVWYBZ*X", dtype=np.uint8)
+
+
+def random_symbols(rng, n, positions, alphabet):
+    """Random alignment with a skewed symbol distribution (mostly the 'reference')."""
+    if alphabet == "nuc":
+        probs = np.array([0.05, 0.3, 0.2, 0.2, 0.15] + [0.005] * 10 + [0.05])
+    else:
+        probs = np.array([0.04] + [0.04] * 20 + [0.01, 0.01, 0.04, 0.1])
+    probs = probs / probs.sum()
+    return rng.choice(len(probs), size=(n, positions), p=probs).astype(np.uint8)
+
+
+def make_store(n, stores):
+    from silo_amd.binding import GpuStore
+
+    return GpuStore(n, stores)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 100, 1000, 4097])
+def test_transpose_planes_match_naive(built, n):
+    rng = np.random.default_rng(n)
+    positions = 37
+    sym = random_symbols(rng, n, positions, "nuc")
+    is_null = (rng.random(n) < 0.05).astype(np.uint8)
+    sym_effective = sym.copy()
+    sym_effective[is_null.astype(bool)] = 15
+    ref = rng.integers(1, 5, size=positions).astype(np.uint8)
+    with make_store(n, [dict(name="main", alphabet="nuc", reference=ref)]) as store:
+        # two batches with an unaligned boundary exercise the atomicOr path
+        cut = n // 3
+        store.append_sequences(0, 0, NUC_CHARS[sym[:cut]], is_null[:cut])
+        store.append_sequences(0, cut, NUC_CHARS[sym[cut:]], is_null[cut:])
+        store.finalize()
+        for p in [0, 1, positions // 2, positions - 1]:
+            for s in range(16):
+                got = store.plane_download(0, p, s)
+                want = dense.pack_bits(sym_effective[:, p] == s)
+                assert np.array_equal(got[: len(want)], want), (p, s)
+                assert not got[len(want):].any()
+
+
+def test_transpose_rejects_illegal_character(built):
+    from silo_amd.binding import SiloGpuError
+
+    ref = np.ones(8, dtype=np.uint8)
+    with make_store(4, [dict(name="main", alphabet="nuc", reference=ref)]) as store:
+        with pytest.raises(SiloGpuError):
+            store.append_sequences(0, 0, ["ACGTACGT", "ACGTACGJ", "ACGTACGT", "ACGTACGT"])
+
+
+@pytest.mark.parametrize("n,alphabet", [(100, "nuc"), (100, "aa"), (5000, "nuc"), (70000, "aa"), (140000, "nuc"), (300001, "nuc")])
+def test_mutations_scan_matches_naive(built, n, alphabet):
+    rng = np.random.default_rng(n + 7)
+    positions = 23
+    sym = random_symbols(rng, n, positions, alphabet)
+    chars = (NUC_CHARS if alphabet == "nuc" else AA_CHARS)[sym]
+    ref = sym[0].copy()
+    with make_store(n, [dict(name="s", alphabet=alphabet, reference=ref)]) as store:
+        store.append_sequences(0, 0, chars)
+        store.finalize()
+        scan_symbols = list(store.scan_symbols[0])
+        filt = rng.random(n) < 0.37
+        fptr = store.bitset_alloc()
+        store.bitset_upload(fptr, dense.pack_bits(filt))
+        for variant in (0, 1, 2):
+            store.tune(1, variant)
+            got = store.mutations_scan(0, fptr)
+            want = dense.mutation_counts(sym, filt, scan_symbols)
+            assert np.array_equal(got, want), (variant, store.last_scan_kernel())
+            # sub-range + full filter
+            got = store.mutations_scan(0, None, 3, 11)
+            want = dense.mutation_counts(sym, np.ones(n, bool), scan_symbols, 3, 11)
+            assert np.array_equal(got, want)
+        store.tune(1, 0)
+        assert store.popcount(fptr) == int(filt.sum())
+
+
+def _eval(store, code, leaves, n_slots):
+    from silo_amd.binding import encode  # noqa: F401
+
+    out = store.bitset_alloc()
+    cnt = store.malloc(8)
+    store.memset(cnt, 0, 8)
+    store.filter_eval(code, leaves, n_slots, out, cnt)
+    words = store.bitset_download(out)
+    count = int(store.read(cnt, np.uint64, 1)[0])
+    store.free(out)
+    store.free(cnt)
+    return words, count
+
+
+@pytest.mark.parametrize("n", [100, 777, 100000])
+def test_filter_eval_ops(built, n):
+    from silo_amd import binding as b
+
+    rng = np.random.default_rng(n)
+    masks = [rng.random(n) < p for p in (0.5, 0.2, 0.7, 0.05, 0.9)]
+    ref = np.ones(4, dtype=np.uint8)
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        leaves = []
+        for m in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(m))
+            leaves.append(ptr)
+        full = np.ones(n, bool)
+
+        def check(code, n_slots, want):
+            words, count = _eval(store, code, leaves, n_slots)
+            assert np.array_equal(dense.unpack_bits(words, n), want)
+            assert not dense.unpack_bits(words, store.row_words * 64)[n:].any()
+            assert count == int(want.sum())
+
+        # (m0 & m1) | ~m2, minus m3
+        code = (b.encode(b.OP_LOAD, 0, imm=0) + b.encode(b.OP_LOAD, 1, imm=1) + b.encode(b.OP_AND, 0, 0, 1)
+                + b.encode(b.OP_LOAD, 1, imm=2) + b.encode(b.OP_NOT, 1, 1) + b.encode(b.OP_OR, 0, 0, 1)
+                + b.encode(b.OP_LOAD, 1, imm=3) + b.encode(b.OP_ANDNOT, 0, 0, 1))
+        check(code, 2, ((masks[0] & masks[1]) | ~masks[2]) & ~masks[3])
+        check(b.encode(b.OP_ONES, 0), 1, full)
+        check(b.encode(b.OP_ZERO, 0), 1, ~full)
+        check(b.encode(b.OP_ZERO, 0) + b.encode(b.OP_NOT, 0, 0), 1, full)
+        # n-of-5 thresholds with a 3-bit counter in slots 1..3
+        total = sum(m.astype(int) for m in masks)
+        for k in range(0, 7):
+            code = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3)
+            for leaf in range(5):
+                code += b.encode(b.OP_LOAD, 0, imm=leaf) + b.encode(b.OP_CNT_ADD, 1, 0, 3)
+            check(code + b.encode(b.OP_CNT_GE, 0, 1, 3, imm=k), 4, total >= k)
+            check(code + b.encode(b.OP_CNT_EQ, 0, 1, 3, imm=k), 4, total == k)
+
+
+def test_synthetic_store_matches_cpu_twin(built):
+    from silo_amd import synth
+
+    n, positions = 3000, 211
+    tree = synth.make_lineage_tree(40)
+    lineage = synth.assign_lineages(n, tree, 1234)
+    for k, alphabet in enumerate(["nuc", "aa"]):
+        ref = synth.random_reference(positions, alphabet, 99 + k)
+        model = synth.make_model(n, ref, alphabet, tree, lineage, seed=4321, store_index=k)
+        # raise the ambiguity rate so the sparse path is exercised at this size
+        model.ambiguous_threshold = 1 << 14
+        sym = oracle_synth.symbol_matrix(model, np.arange(n), np.arange(positions))
+        with make_store(n, [dict(name="s", alphabet=alphabet, reference=ref)]) as store:
+            store.generate_synthetic(0, model)
+            store.finalize()
+            n_symbols = 16 if alphabet == "nuc" else 25
+            for p in [0, 1, 57, 100, positions - 1]:
+                for s in range(n_symbols):
+                    got = store.plane_download(0, p, s)
+                    want = dense.pack_bits(sym[:, p] == s)
+                    assert np.array_equal(got[: len(want)], want), (alphabet, p, s)
+            filt = tree.subtree(1)[lineage].astype(bool)
+            fptr = store.bitset_alloc()
+            store.bitset_from_lineages(fptr, tree.subtree(1))
+            assert np.array_equal(dense.unpack_bits(store.bitset_download(fptr), n), filt)
+            got = store.mutations_scan(0, fptr)
+            want = dense.mutation_counts(sym, filt, list(store.scan_symbols[0]))
+            assert np.array_equal(got, want)
