@@ -191,6 +191,13 @@ int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream);
 enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1 };
 int silo_gpu_tune(int knob, int value);
 
+/* HIP events on the caller's stream, so a host without the HIP headers can time the kernels
+ * (bench.py measures the roofline numbers with these, on the stream the kernels are launched on). */
+int silo_gpu_event_create(void** out_event);
+int silo_gpu_event_record(void* event, void* stream);
+int silo_gpu_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop */
+void silo_gpu_event_destroy(void* event);
+
 /* Name of the last kernel variant silo_gpu_mutations_scan launched (for roofline attribution). */
 const char* silo_gpu_last_scan_kernel(void);
 

@@ -1053,6 +1053,31 @@ int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void*
    return SILO_GPU_OK;
 }
 
+int silo_gpu_event_create(void** out_event) {
+   if (out_event == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_event_create: null out pointer");
+   }
+   hipEvent_t event = nullptr;
+   HIP_TRY(hipEventCreate(&event));
+   *out_event = event;
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_event_record(void* event, void* stream) {
+   HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms) {
+   HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop_event)));
+   HIP_TRY(hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)));
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_event_destroy(void* event) {
+   (void)hipEventDestroy(static_cast<hipEvent_t>(event));
+}
+
 int silo_gpu_stream_synchronize(void* stream) {
    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
    return SILO_GPU_OK;

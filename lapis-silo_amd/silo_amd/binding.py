@@ -80,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_stream_synchronize", "silo_gpu_store_plane",
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan",
-    "silo_gpu_memset_async", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
+    "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
+    "silo_gpu_event_destroy", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
 ]
 
 _lib = None
@@ -126,6 +127,11 @@ def load_library():
     lib.silo_gpu_popcount.argtypes = [vp, vp, vp, vp]
     lib.silo_gpu_mutations_scan.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
     lib.silo_gpu_memset_async.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
+    lib.silo_gpu_event_create.argtypes = [ctypes.POINTER(vp)]
+    lib.silo_gpu_event_record.argtypes = [vp, vp]
+    lib.silo_gpu_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.silo_gpu_event_destroy.argtypes = [vp]
+    lib.silo_gpu_event_destroy.restype = None
     lib.silo_gpu_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.silo_gpu_last_scan_kernel.restype = ctypes.c_char_p
     lib.silo_gpu_last_error.restype = ctypes.c_char_p
@@ -140,6 +146,28 @@ def _check(rc):
 
 def _ptr(array):
     return array.ctypes.data_as(ctypes.c_void_p)
+
+
+class GpuEvent:
+    """hipEvent on a caller-chosen stream (None = the null stream)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_event_create(ctypes.byref(self.handle)))
+
+    def record(self, stream=None):
+        _check(self.lib.silo_gpu_event_record(self.handle, stream))
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float()
+        _check(self.lib.silo_gpu_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.silo_gpu_event_destroy(self.handle)
+            self.handle = None
 
 
 # bit-program opcodes (include/silo_gpu.h)

@@ -1,0 +1,58 @@
+"""Quick K1 probe: synthetic nucleotide store, time the Mutations scan with HIP events."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "lapis-silo_amd")]
+from silo_amd import binding, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sequences", type=int, default=1_000_000)
+ap.add_argument("--positions", type=int, default=29903)
+ap.add_argument("--lineages", type=int, default=2000)
+ap.add_argument("--rows", type=str, default="64,128,256,512,1024")
+ap.add_argument("--reps", type=int, default=5)
+args = ap.parse_args()
+
+n, positions = args.sequences, args.positions
+t0 = time.time()
+tree = synth.make_lineage_tree(args.lineages)
+lineage = synth.assign_lineages(n, tree, synth.DEFAULT_SEED)
+ref = synth.random_reference(positions, "nuc", 1)
+model = synth.make_model(n, ref, "nuc", tree, lineage)
+print(f"model built in {time.time() - t0:.1f}s", flush=True)
+t0 = time.time()
+store = binding.GpuStore(n, [dict(name="main", alphabet="nuc", reference=ref)])
+print(f"store allocated {store.device_bytes / 1e9:.1f} GB in {time.time() - t0:.1f}s", flush=True)
+t0 = time.time()
+store.generate_synthetic(0, model)
+store.finalize()
+print(f"generated in {time.time() - t0:.1f}s", flush=True)
+
+member = tree.subtree(1)
+fptr = store.bitset_alloc()
+store.bitset_from_lineages(fptr, member)
+print("filter cardinality", store.popcount(fptr), "of", n)
+w8 = 8 * ((n + 63) // 64)
+alg_bytes = positions * 5 * w8 + w8
+counts = store.malloc(4 * positions * 5)
+start, stop = binding.GpuEvent(), binding.GpuEvent()
+for rows in [int(x) for x in args.rows.split(",")]:
+    store.tune(0, rows)
+    best = 1e9
+    for rep in range(args.reps + 1):
+        store.memset(counts, 0, 4 * positions * 5)
+        start.record()
+        store.mutations_scan_async(0, fptr, 0, positions, counts)
+        stop.record()
+        ms = start.elapsed_ms(stop)
+        if rep > 0:
+            best = min(best, ms)
+    print(f"rows_per_block={rows:5d}  {best:8.3f} ms  {alg_bytes / best / 1e6:8.1f} GB/s  "
+          f"{n * positions / best / 1e9 * 1e3:.3e} pos*seq/s  kernel={store.last_scan_kernel()}", flush=True)
+c = store.read(counts, np.uint32, positions * 5).reshape(positions, 5)
+print("checksum", int(c.sum()), "total@pos1000", c[1000])
