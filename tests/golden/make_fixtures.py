@@ -1,0 +1,122 @@
+"""Copies the DATA the reference's own tests hold for this path into tests/golden/ (run in the build
+container, where /root/reference is mounted; the GPU box has no reference tree).
+
+Nothing here executes or copies reference *code*: inputs are the e2e test data set
+(testBaseData/exampleDataset: aligned FASTA files, metadata TSV, reference genomes, lineage aliases),
+the 1000-sequence ndjson sample, and the query/expected-result JSON fixtures of
+endToEndTests/test/{queries,invalidQueries}.  Sequence files are re-compressed with lzma (stdlib) so
+the tests need neither zstd nor the reference tree.
+"""
+import ctypes
+import json
+import lzma
+import os
+import shutil
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# filter / action types on the hot path
+HOT_FILTERS = {
+    "True", "False", "And", "Or", "Not", "N-Of", "Maybe", "Exact", "NucleotideEquals", "AminoAcidEquals",
+    "HasNucleotideMutation", "HasAminoAcidMutation", "PangoLineage",
+}
+HOT_ACTIONS = {"Aggregated", "Mutations", "AminoAcidMutations"}
+HOT_INVALID = {
+    "sequencePos0Filter.json", "invalidMutationsMinProportion.json", "nuc_mutations_no_proportion.json",
+    "aa_mutations_no_proportion.json", "invalidAction.json",
+}
+
+
+def zstd_decompress(data: bytes) -> bytes:
+    lib = ctypes.CDLL("/opt/conda/lib/libzstd.so")
+    lib.ZSTD_getFrameContentSize.restype = ctypes.c_ulonglong
+    lib.ZSTD_getFrameContentSize.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.ZSTD_decompress.restype = ctypes.c_size_t
+    lib.ZSTD_decompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    size = lib.ZSTD_getFrameContentSize(data, len(data))
+    if size >= 0xFFFFFFFFFFFFFFFE:  # unknown: grow a buffer
+        size = 256 * len(data)
+    out = ctypes.create_string_buffer(size)
+    n = lib.ZSTD_decompress(out, size, data, len(data))
+    if lib.ZSTD_isError(n):
+        raise RuntimeError("zstd decompression failed")
+    return out.raw[:n]
+
+
+def filter_types(node, acc):
+    if isinstance(node, dict):
+        if "type" in node:
+            acc.add(node["type"])
+        for value in node.values():
+            filter_types(value, acc)
+    elif isinstance(node, list):
+        for value in node:
+            filter_types(value, acc)
+
+
+def main():
+    src = os.path.join(REF, "testBaseData", "exampleDataset")
+    dst = os.path.join(HERE, "exampleDataset")
+    os.makedirs(dst, exist_ok=True)
+    for name in ["reference_genomes.json", "pangolineage_alias.json", "small_metadata_set.tsv", "database_config.yaml"]:
+        shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
+    for name in sorted(os.listdir(src)):
+        path = os.path.join(src, name)
+        if name.startswith("unaligned"):
+            continue
+        if name.endswith(".fasta"):
+            raw = open(path, "rb").read()
+            base = name
+        elif name.endswith(".fasta.zst"):
+            raw = zstd_decompress(open(path, "rb").read())
+            base = name[: -len(".zst")]
+        elif name.endswith(".fasta.xz"):
+            raw = lzma.decompress(open(path, "rb").read())
+            base = name[: -len(".xz")]
+        else:
+            continue
+        with lzma.open(os.path.join(dst, base + ".xz"), "wb", preset=9) as out:
+            out.write(raw)
+
+    # 1000-sequence sample (BASELINE config 1): keep only what the path reads
+    sample = zstd_decompress(open(os.path.join(REF, "testBaseData", "exampleDataset1000Sequences", "sample.ndjson.zst"), "rb").read())
+    dst1000 = os.path.join(HERE, "exampleDataset1000Sequences")
+    os.makedirs(dst1000, exist_ok=True)
+    with lzma.open(os.path.join(dst1000, "main_aligned.txt.xz"), "wt", preset=9) as out:
+        for line in sample.decode().splitlines():
+            if not line.strip():
+                continue
+            record = json.loads(line)
+            seq = record["alignedNucleotideSequences"]["main"]
+            lineage = record["metadata"].get("pango_lineage") if "metadata" in record else None
+            out.write(f"{lineage or ''}\t{seq if seq is not None else ''}\n")
+    shutil.copyfile(
+        os.path.join(REF, "testBaseData", "exampleDataset1000Sequences", "reference_genomes.json"),
+        os.path.join(dst1000, "reference_genomes.json"),
+    )
+
+    qsrc = os.path.join(REF, "endToEndTests", "test", "queries")
+    qdst = os.path.join(HERE, "queries")
+    os.makedirs(qdst, exist_ok=True)
+    kept = []
+    for name in sorted(os.listdir(qsrc)):
+        case = json.load(open(os.path.join(qsrc, name)))
+        types = set()
+        filter_types(case["query"].get("filterExpression"), types)
+        action = case["query"]["action"]
+        if not types <= HOT_FILTERS or action.get("type") not in HOT_ACTIONS or action.get("groupByFields"):
+            continue
+        shutil.copyfile(os.path.join(qsrc, name), os.path.join(qdst, name))
+        kept.append(name)
+    isrc = os.path.join(REF, "endToEndTests", "test", "invalidQueries")
+    idst = os.path.join(HERE, "invalidQueries")
+    os.makedirs(idst, exist_ok=True)
+    for name in sorted(HOT_INVALID):
+        shutil.copyfile(os.path.join(isrc, name), os.path.join(idst, name))
+    print(f"kept {len(kept)} query fixtures:", " ".join(kept))
+
+
+if __name__ == "__main__":
+    main()
