@@ -1,0 +1,86 @@
+/*
+ * silo_engine.h — C ABI of the C++ host side (libsilo_engine.so): the QueryEngine-shaped layer that a
+ * patched silo::Database::executeQuery (reference src/silo/database.cpp:710-714) would instantiate,
+ * exported with plain C types so that non-C++ hosts (the Python tests / bench here) can drive it.
+ *
+ * One engine = one silo::Database whose partitions live on one GPU.  JSON in, JSON out:
+ *   query   : the body of POST /query       (reference src/silo_api/query_handler.cpp:22-41)
+ *   result  : {"queryResult":[...]}         (reference src/silo/query_engine/query_result.cpp:10-25)
+ *   errors  : {"error":"Bad request"|"Internal Server Error","message":...} with HTTP status 400 / 500
+ *             (reference src/silo_api/query_handler.cpp:42-73)
+ */
+#ifndef SILO_ENGINE_H
+#define SILO_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "silo_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct silo_engine silo_engine;
+
+/* reference_genomes_json: contents of reference_genomes.json (reference_genomes.cpp);
+ * alias_json: contents of pangolineage_alias.json or NULL (pango_lineage_alias.cpp:88-102);
+ * default_nucleotide_sequence: NULL = "main" (database_config.cpp:70-75). */
+int silo_engine_create(
+   const char* reference_genomes_json, const char* alias_json, const char* default_nucleotide_sequence, int device, silo_engine** out
+);
+void silo_engine_destroy(silo_engine* engine);
+
+/* Adds a DatabasePartition of `sequence_count` rows; returns its index (>= 0) or a negative status. */
+int silo_engine_add_partition(silo_engine* engine, uint32_t sequence_count);
+
+/* Aligned sequences of one sequence store (nucleotide segment when is_amino_acid == 0, else gene),
+ * row-major chars [n_sequences][length]; see silo_gpu_store_append_sequences. */
+int silo_engine_append_sequences(
+   silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, uint32_t first_sequence, uint32_t n_sequences,
+   const char* chars, const uint8_t* is_null
+);
+int silo_engine_generate_synthetic(
+   silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, const silo_gpu_synth_desc* synth
+);
+
+/* A pango lineage metadata column: one raw (possibly aliased) value per row, NULL or "" = null. */
+int silo_engine_set_lineage_column(silo_engine* engine, int partition, const char* column, const char* const* values, uint32_t n_rows);
+/* Bulk form: dictionary of unaliased lineage names + one dictionary index per row. */
+int silo_engine_set_lineage_column_ids(
+   silo_engine* engine, int partition, const char* column, const char* const* dictionary, uint32_t n_dictionary, const uint32_t* value_ids,
+   uint32_t n_rows
+);
+
+/* Call once after loading, before the first query. */
+int silo_engine_finalize(silo_engine* engine);
+
+/* Multi-GPU (one process per GPU).  shard_by_position != 0: this rank scans only its slice of the
+ * position range and counts are all-reduced; otherwise the partitions of this rank are a
+ * sequence-id shard and counts / cardinalities are all-reduced.  all_reduce sums n uint32 in place on
+ * the device across ranks (RCCL over xGMI in production). */
+typedef int (*silo_engine_all_reduce_u32)(void* context, uint32_t* device_values, size_t n, void* stream);
+int silo_engine_set_sharding(
+   silo_engine* engine, uint32_t rank, uint32_t world, int shard_by_position, silo_engine_all_reduce_u32 all_reduce, void* context
+);
+
+/* Executes one query.  *out_json is malloc'ed (free with silo_engine_free_string) and holds either the
+ * result or the error document; *out_http_status is 200, 400 or 500.  Returns 0 unless the arguments
+ * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */
+int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status);
+void silo_engine_free_string(char* text);
+
+/* The reference's two per-query timings (query_engine.cpp:63-65) of the last query on this thread. */
+void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_microseconds);
+
+/* Device store of a partition, for callers that drive the kernels directly (bench roofline leg). */
+silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int partition);
+/* silo_gpu sequence-store index of a named store inside a partition, or -1. */
+int silo_engine_seqstore_id(const silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid);
+
+const char* silo_engine_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SILO_ENGINE_H */

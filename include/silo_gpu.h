@@ -122,9 +122,14 @@ int silo_gpu_bitset_upload(const silo_gpu_store* store, uint64_t* dst_dev, const
 int silo_gpu_bitset_download(const silo_gpu_store* store, uint64_t* dst_host, const uint64_t* src_dev, size_t n_words, void* stream);
 /* bit i = membership_by_lineage[lineage_of_sequence[i]] for a store filled by generate_synthetic. */
 int silo_gpu_bitset_from_lineages(const silo_gpu_store* store, uint64_t* dst_dev, const uint8_t* membership_by_lineage, uint32_t n_lineages, void* stream);
+/* Dictionary-encoded metadata column kept on the device: bit i = membership_by_value[value_ids_dev[i]].
+ * This is how a metadata predicate (pango lineage, pango_lineage_filter.cpp:37-59) enters the device path. */
+int silo_gpu_upload_u32(const uint32_t* src_host, size_t n, uint32_t** out_dev);
+int silo_gpu_bitset_from_value_ids(const silo_gpu_store* store, uint64_t* dst_dev, const uint32_t* value_ids_dev, const uint8_t* membership_by_value, uint32_t n_values, void* stream);
 void silo_gpu_free(void* dev_ptr);
 int silo_gpu_malloc(size_t bytes, void** out_dev);
-int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream); /* synchronises */
+int silo_gpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream); /* synchronises */
 int silo_gpu_stream_synchronize(void* stream);
 
 /* Device pointer of the dense plane of (seqstore, position, symbol), or NULL when that symbol is
@@ -156,7 +161,7 @@ enum {
    SILO_GPU_OP_CNT_EQ = 9,   /* dst = (counter in slots a..a+b-1) == imm                           */
    SILO_GPU_OP_MOV = 10      /* dst = a */
 };
-enum { SILO_GPU_MAX_INSTRUCTIONS = 192, SILO_GPU_MAX_LEAVES = 128, SILO_GPU_MAX_SLOTS = 32 };
+enum { SILO_GPU_MAX_INSTRUCTIONS = 320, SILO_GPU_MAX_LEAVES = 128, SILO_GPU_MAX_SLOTS = 32 };
 
 typedef struct {
    uint32_t n_instructions;

@@ -556,6 +556,27 @@ __global__ __launch_bounds__(256) void k_bitset_from_lineages(
    }
 }
 
+__global__ __launch_bounds__(256) void k_bitset_from_value_ids(
+   const uint32_t* __restrict__ value_ids, const uint8_t* __restrict__ membership, uint32_t n_values,
+   uint32_t sequence_count, uint32_t row_words, uint64_t* __restrict__ out
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t word = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   if (word >= row_words) {
+      return;
+   }
+   const uint64_t sequence = static_cast<uint64_t>(word) * 64u + lane;
+   bool member = false;
+   if (sequence < sequence_count) {
+      const uint32_t value = value_ids[sequence];
+      member = value < n_values && membership[value] != 0;
+   }
+   const uint64_t mask = __ballot(member);
+   if (lane == 0) {
+      out[word] = mask;
+   }
+}
+
 __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence_count) {
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
    if (w < row_words) {
@@ -1053,6 +1074,12 @@ int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void*
    return SILO_GPU_OK;
 }
 
+int silo_gpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+   HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
 int silo_gpu_event_create(void** out_event) {
    if (out_event == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_event_create: null out pointer");
@@ -1136,6 +1163,43 @@ int silo_gpu_bitset_from_lineages(const silo_gpu_store* store, uint64_t* dst_dev
    (void)hipFree(d_membership);
    if (err != hipSuccess) {
       return fail(SILO_GPU_ERR_HIP, std::string("k_bitset_from_lineages: ") + hipGetErrorString(err));
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_upload_u32(const uint32_t* src_host, size_t n, uint32_t** out_dev) {
+   if (out_dev == nullptr || (src_host == nullptr && n > 0)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_upload_u32: bad arguments");
+   }
+   uint32_t* ptr = nullptr;
+   HIP_TRY(hipMalloc(&ptr, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+   hipError_t err = hipMemcpy(ptr, src_host, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+   if (err != hipSuccess) {
+      (void)hipFree(ptr);
+      return fail(SILO_GPU_ERR_HIP, std::string("silo_gpu_upload_u32: ") + hipGetErrorString(err));
+   }
+   *out_dev = ptr;
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_from_value_ids(const silo_gpu_store* store, uint64_t* dst_dev, const uint32_t* value_ids_dev, const uint8_t* membership_by_value, uint32_t n_values, void* stream) {
+   if (store == nullptr || dst_dev == nullptr || value_ids_dev == nullptr || membership_by_value == nullptr || n_values == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_from_value_ids: bad arguments");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   uint8_t* d_membership = nullptr;
+   HIP_TRY(hipMalloc(&d_membership, n_values));
+   hipError_t err = hipMemcpyAsync(d_membership, membership_by_value, n_values, hipMemcpyHostToDevice, hip_stream);
+   if (err == hipSuccess) {
+      const uint32_t threads = store->row_words * 64u;
+      k_bitset_from_value_ids<<<(threads + 255) / 256, 256, 0, hip_stream>>>(
+         value_ids_dev, d_membership, n_values, store->sequence_count, store->row_words, dst_dev
+      );
+      err = hipStreamSynchronize(hip_stream);
+   }
+   (void)hipFree(d_membership);
+   if (err != hipSuccess) {
+      return fail(SILO_GPU_ERR_HIP, std::string("k_bitset_from_value_ids: ") + hipGetErrorString(err));
    }
    return SILO_GPU_OK;
 }

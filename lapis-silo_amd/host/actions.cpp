@@ -1,0 +1,352 @@
+// actions.cpp — Action base (ordering / limit / offset), Aggregated (count) and Mutations<SymbolType>.
+// Reference: src/silo/query_engine/actions/{action,aggregated,mutations}.cpp.
+#include <algorithm>
+#include <cmath>
+
+#include "query_engine.h"
+
+namespace silo::query_engine::actions {
+
+// ---- Action (action.cpp:37-117) ------------------------------------------------------------------
+void Action::applySort(QueryResult& result) const {
+   auto& result_vector = result.query_result;
+   auto cmp = [&](const QueryResultEntry& entry1, const QueryResultEntry& entry2) {
+      for (const OrderByField& field : order_by_fields) {
+         if (entry1.fields.at(field.name) == entry2.fields.at(field.name)) {
+            continue;
+         }
+         return entry1.fields.at(field.name) < entry2.fields.at(field.name) ? field.ascending : !field.ascending;
+      }
+      return false;
+   };
+   const size_t end_of_sort =
+      std::min(static_cast<size_t>(limit.value_or(result_vector.size()) + offset.value_or(0UL)), result_vector.size());
+   if (!order_by_fields.empty()) {
+      if (end_of_sort < result_vector.size()) {
+         std::partial_sort(result_vector.begin(), result_vector.begin() + static_cast<int64_t>(end_of_sort), result_vector.end(), cmp);
+      } else {
+         std::sort(result_vector.begin(), result_vector.end(), cmp);
+      }
+   }
+}
+
+void Action::applyOffsetAndLimit(QueryResult& result) const {
+   auto& result_vector = result.query_result;
+   size_t end_of_sort =
+      std::min(static_cast<size_t>(limit.value_or(result_vector.size()) + offset.value_or(0UL)), result_vector.size());
+   if (offset.has_value() && offset.value() >= end_of_sort) {
+      result = {};
+      return;
+   }
+   if (offset.has_value() && offset.value() > 0) {
+      auto begin = result_vector.begin() + offset.value();
+      auto end = end_of_sort < result_vector.size() ? result_vector.begin() + static_cast<int64_t>(end_of_sort) : result_vector.end();
+      std::copy(begin, end, result_vector.begin());
+      end_of_sort -= offset.value();
+   }
+   if (end_of_sort < result_vector.size()) {
+      result_vector.resize(end_of_sort);
+   }
+}
+
+void Action::setOrdering(const std::vector<OrderByField>& order_by_fields_, std::optional<uint32_t> limit_, std::optional<uint32_t> offset_) {
+   order_by_fields = order_by_fields_;
+   limit = limit_;
+   offset = offset_;
+}
+
+QueryResult Action::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
+   validateOrderByFields(database);
+   QueryResult result = execute(database, std::move(bitmap_filter));
+   if (offset.has_value() && offset.value() >= result.query_result.size()) {
+      return {};
+   }
+   applySort(result);
+   applyOffsetAndLimit(result);
+   return result;
+}
+
+namespace {
+
+/// Sums `n` uint32 across ranks in place on the device (no-op for a single rank).
+void allReduce(const Database& database, uint32_t* device_values, size_t n) {
+   if (database.shard_world > 1 && database.all_reduce != nullptr) {
+      const int status = database.all_reduce(database.all_reduce_context, device_values, n, nullptr);
+      if (status != 0) {
+         throw DeviceException("all-reduce of counts failed with status " + std::to_string(status));
+      }
+   }
+}
+
+}  // namespace
+
+// ---- Aggregated (aggregated.cpp:58-96; group-by is outside the hot path) -----------------------------
+void Aggregated::validateOrderByFields(const Database& /*database*/) const {
+   if (!group_by_fields.empty()) {
+      throw std::runtime_error("Aggregated with groupByFields is not supported by the MI355X filter engine");
+   }
+   for (const OrderByField& field : order_by_fields) {
+      CHECK_SILO_QUERY(
+         field.name == "count", "The orderByField '" + field.name + "' cannot be ordered by, as it does not appear in the groupByFields."
+      )
+   }
+}
+
+QueryResult Aggregated::execute(const Database& database, std::vector<OperatorResult> bitmap_filters) const {
+   uint32_t count = 0;  // aggregateWithoutGrouping, aggregated.cpp:58-66
+   for (const auto& filter : bitmap_filters) {
+      count += filter.cardinality();
+   }
+   if (database.shard_world > 1 && !database.shard_by_position && database.all_reduce != nullptr && !database.partitions.empty()) {
+      // sequence-id sharding: every rank holds different rows
+      const DatabasePartition& partition = database.partitions.front();
+      DeviceBuffer buffer = partition.pool.acquire(sizeof(uint32_t));
+      checkGpu(silo_gpu_memcpy_h2d(buffer.get(), &count, sizeof(count), nullptr), "silo_gpu_memcpy_h2d");
+      allReduce(database, buffer.as<uint32_t>(), 1);
+      checkGpu(silo_gpu_memcpy_d2h(&count, buffer.get(), sizeof(count), nullptr), "silo_gpu_memcpy_d2h");
+   }
+   std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> tuple_fields;
+   tuple_fields["count"] = static_cast<int32_t>(count);
+   return QueryResult{std::vector<QueryResultEntry>{{tuple_fields}}};
+}
+
+// ---- Mutations<SymbolType> (mutations.cpp) ---------------------------------------------------------
+template <typename SymbolType>
+std::map<std::string, typename Mutations<SymbolType>::PrefilteredBitmaps> Mutations<SymbolType>::preFilterBitmaps(
+   const Database& database, std::vector<OperatorResult>& bitmap_filter
+) {  // mutations.cpp:35-62
+   std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate;
+   for (size_t i = 0; i < database.partitions.size(); ++i) {
+      const DatabasePartition& database_partition = database.partitions.at(i);
+      OperatorResult& filter = bitmap_filter[i];
+      filter.materialize();  // one launch yields both the bitset and its cardinality
+      const size_t cardinality = filter.cardinality();
+      if (cardinality == 0) {
+         continue;
+      }
+      const bool full = cardinality == database_partition.sequence_count;
+      for (const auto& [sequence_name, sequence_store] : database_partition.getSequenceStores<SymbolType>()) {
+         auto& target = bitmaps_to_evaluate[sequence_name];
+         (full ? target.full_bitmaps : target.bitmaps).emplace_back(filter, sequence_store);
+      }
+   }
+   return bitmaps_to_evaluate;
+}
+
+template <typename SymbolType>
+std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
+   const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
+) {
+   // mutations.cpp:139-164 runs and_cardinality(filter, column) per position x symbol under
+   // tbb::parallel_for; here each (partition, sequence store) is ONE scan kernel (K1) that accumulates
+   // into a single device table, exactly as the reference sums partitions into one table (:71,:108).
+   const auto sequence_length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
+   constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
+   const size_t n_counts = static_cast<size_t>(sequence_length) * n_symbols;
+   std::vector<uint32_t> counts(n_counts, 0);
+   if (database.partitions.empty() || n_counts == 0) {
+      return counts;
+   }
+   // position-range shard of this rank; [0, P) when not sharded by position
+   uint32_t pos_begin = 0;
+   uint32_t pos_end = sequence_length;
+   if (database.shard_by_position && database.shard_world > 1) {
+      pos_begin = static_cast<uint32_t>(static_cast<uint64_t>(sequence_length) * database.shard_rank / database.shard_world);
+      pos_end = static_cast<uint32_t>(static_cast<uint64_t>(sequence_length) * (database.shard_rank + 1) / database.shard_world);
+   }
+   const DatabasePartition& home = database.partitions.front();
+   DeviceBuffer device_counts = home.pool.acquire(n_counts * sizeof(uint32_t));
+   checkGpu(silo_gpu_memset_async(device_counts.get(), 0, n_counts * sizeof(uint32_t), nullptr), "silo_gpu_memset_async");
+   uint32_t* window = device_counts.as<uint32_t>() + static_cast<size_t>(pos_begin) * n_symbols;
+   for (const auto& [filter, store] : bitmap_filter.bitmaps) {
+      checkGpu(
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), pos_begin, pos_end, window, nullptr),
+         "silo_gpu_mutations_scan"
+      );
+   }
+   for (const auto& [filter, store] : bitmap_filter.full_bitmaps) {
+      // full filter: the reference reads plain cardinalities (mutations.cpp:98-136); NULL = all rows
+      checkGpu(
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, pos_begin, pos_end, window, nullptr), "silo_gpu_mutations_scan"
+      );
+   }
+   allReduce(database, device_counts.as<uint32_t>(), n_counts);
+   checkGpu(silo_gpu_memcpy_d2h(counts.data(), device_counts.get(), n_counts * sizeof(uint32_t), nullptr), "silo_gpu_memcpy_d2h");
+   return counts;
+}
+
+template <typename SymbolType>
+void Mutations<SymbolType>::validateOrderByFields(const Database& /*database*/) const {  // mutations.cpp:166-182
+   const std::vector<std::string> result_field_names{{MUTATION_FIELD_NAME, PROPORTION_FIELD_NAME, COUNT_FIELD_NAME}};
+   for (const OrderByField& field : order_by_fields) {
+      CHECK_SILO_QUERY(
+         std::any_of(result_field_names.begin(), result_field_names.end(), [&](const std::string& result_field) { return result_field == field.name; }),
+         "OrderByField " + field.name + " is not contained in the result of this operation."
+      )
+   }
+}
+
+template <typename SymbolType>
+void Mutations<SymbolType>::addMutationsToOutput(
+   const Database& database, const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store,
+   const PrefilteredBitmaps& bitmap_filter, std::vector<QueryResultEntry>& output
+) const {  // mutations.cpp:184-232
+   const size_t sequence_length = sequence_store.reference_sequence.size();
+   constexpr size_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
+   const std::vector<uint32_t> count_of_mutations_per_position = calculateMutationsPerPosition(database, sequence_store, bitmap_filter);
+
+   for (size_t pos = 0; pos < sequence_length; ++pos) {
+      const uint32_t* counts_at_position = count_of_mutations_per_position.data() + pos * n_symbols;
+      uint32_t total = 0;
+      for (size_t s = 0; s < n_symbols; ++s) {
+         total += counts_at_position[s];
+      }
+      if (total == 0) {
+         continue;
+      }
+      const auto threshold_count =
+         min_proportion == 0 ? 0 : static_cast<uint32_t>(std::ceil(static_cast<double>(total) * min_proportion) - 1);
+      const typename SymbolType::Symbol symbol_in_reference_genome = sequence_store.reference_sequence.at(pos);
+      for (size_t s = 0; s < n_symbols; ++s) {
+         const auto symbol = SymbolType::VALID_MUTATION_SYMBOLS[s];
+         if (symbol_in_reference_genome != symbol) {
+            const uint32_t count = counts_at_position[s];
+            if (count > threshold_count) {
+               const double proportion = static_cast<double>(count) / static_cast<double>(total);
+               const std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> fields{
+                  {MUTATION_FIELD_NAME,
+                   SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(pos + 1) + SymbolType::symbolToChar(symbol)},
+                  {SEQUENCE_FIELD_NAME, sequence_name},
+                  {PROPORTION_FIELD_NAME, proportion},
+                  {COUNT_FIELD_NAME, static_cast<int32_t>(count)}};
+               output.push_back({fields});
+            }
+         }
+      }
+   }
+}
+
+template <typename SymbolType>
+QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // mutations.cpp:234-272
+   std::vector<std::string> sequence_names_to_evaluate;
+   for (const auto& sequence_name : sequence_names) {
+      CHECK_SILO_QUERY(
+         database.getSequenceStores<SymbolType>().count(sequence_name) != 0,
+         "Database does not contain the " + std::string(SymbolType::SYMBOL_NAME_LOWER_CASE) + " sequence with name: '" + sequence_name + "'"
+      )
+      sequence_names_to_evaluate.emplace_back(sequence_name);
+   }
+   if (sequence_names.empty()) {
+      for (const auto& [sequence_name, _] : database.getSequenceStores<SymbolType>()) {
+         sequence_names_to_evaluate.emplace_back(sequence_name);
+      }
+   }
+   std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, bitmap_filter);
+
+   std::vector<QueryResultEntry> mutation_proportions;
+   for (const auto& sequence_name : sequence_names_to_evaluate) {
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+      const bool sharded = database.shard_world > 1 && database.all_reduce != nullptr;
+      if (bitmaps_to_evaluate.count(sequence_name) != 0) {
+         addMutationsToOutput(database, sequence_name, sequence_store, bitmaps_to_evaluate.at(sequence_name), mutation_proportions);
+      } else if (sharded) {
+         // this rank's filter is empty but other ranks may contribute: take part in the collective
+         addMutationsToOutput(database, sequence_name, sequence_store, PrefilteredBitmaps{}, mutation_proportions);
+      }
+   }
+   return {mutation_proportions};
+}
+
+template class Mutations<Nucleotide>;
+template class Mutations<AminoAcid>;
+
+// ---- JSON -> Action -----------------------------------------------------------------------------------
+namespace {
+
+OrderByField parseOrderByField(const json::Value& json) {  // action.cpp:119-142
+   if (json.is_string()) {
+      return {json.as_string(), true};
+   }
+   const std::string message = "The orderByField '" + json.dump() +
+                               "' must be either a string or an object containing the fields 'field':string and "
+                               "'order':string, where the value of order is 'ascending' or 'descending'";
+   CHECK_SILO_QUERY(
+      json.is_object() && json.contains("field") && json.contains("order") && json["field"].is_string() && json["order"].is_string(), message
+   )
+   const std::string field_name = json["field"].as_string();
+   const std::string order_string = json["order"].as_string();
+   CHECK_SILO_QUERY(order_string == "ascending" || order_string == "descending", message)
+   return {field_name, order_string == "ascending"};
+}
+
+template <typename SymbolType>
+std::unique_ptr<Action> parseMutations(const json::Value& json) {  // mutations.cpp:274-316
+   CHECK_SILO_QUERY(
+      !json.contains("sequenceName") || (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
+      "Mutations action can have the field sequenceName of type string or an array of strings, but no other type"
+   )
+   std::vector<std::string> sequence_names;
+   if (json.contains("sequenceName") && json["sequenceName"].is_array()) {
+      for (const auto& child : json["sequenceName"].items()) {
+         CHECK_SILO_QUERY(
+            child.is_string(),
+            "The field sequenceName of Mutations action must have type string or an array, if present. Found:" + child.dump()
+         )
+         sequence_names.emplace_back(child.as_string());
+      }
+   } else if (json.contains("sequenceName") && json["sequenceName"].is_string()) {
+      sequence_names.emplace_back(json["sequenceName"].as_string());
+   }
+   CHECK_SILO_QUERY(
+      json.contains("minProportion") && json["minProportion"].is_number(),
+      "Mutations action must contain the field minProportion of type number with limits [0.0, 1.0]. Only mutations are returned if the "
+      "proportion of sequences having this mutation, is at least minProportion"
+   )
+   const double min_proportion = json["minProportion"].as_double();
+   if (min_proportion < 0 || min_proportion > 1) {
+      throw QueryParseException("Invalid proportion: minProportion must be in interval [0.0, 1.0]");
+   }
+   return std::make_unique<Mutations<SymbolType>>(std::move(sequence_names), min_proportion);
+}
+
+}  // namespace
+
+std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:144-187
+   CHECK_SILO_QUERY(json.contains("type"), "The field 'type' is required in any action")
+   CHECK_SILO_QUERY(json["type"].is_string(), "The field 'type' in all actions needs to be a string, but is: " + json["type"].dump())
+   const std::string expression_type = json["type"].as_string();
+   std::unique_ptr<Action> action;
+   if (expression_type == "Aggregated") {
+      std::vector<std::string> group_by_fields;
+      if (json.contains("groupByFields")) {
+         for (const auto& field : json["groupByFields"].items()) {
+            group_by_fields.push_back(field.as_string());
+         }
+      }
+      action = std::make_unique<Aggregated>(std::move(group_by_fields));
+   } else if (expression_type == "Mutations") {
+      action = parseMutations<Nucleotide>(json);
+   } else if (expression_type == "AminoAcidMutations") {
+      action = parseMutations<AminoAcid>(json);
+   } else if (expression_type == "Details" || expression_type == "Fasta" || expression_type == "FastaAligned" ||
+              expression_type == "Insertions" || expression_type == "AminoAcidInsertions") {
+      // row materialisation / string work: outside the device hot path
+      throw std::runtime_error("action '" + expression_type + "' is not supported by the MI355X filter engine");
+   } else {
+      throw QueryParseException(expression_type + " is not a valid action");
+   }
+   std::vector<OrderByField> order_by_fields;
+   if (json.contains("orderByFields")) {
+      for (const auto& field : json["orderByFields"].items()) {
+         order_by_fields.push_back(parseOrderByField(field));
+      }
+   }
+   CHECK_SILO_QUERY(!json.contains("limit") || json["limit"].is_number_unsigned(), "If the action contains a limit, it must be a non-negative number")
+   CHECK_SILO_QUERY(!json.contains("offset") || json["offset"].is_number_unsigned(), "If the action contains an offset, it must be a non-negative number")
+   auto limit = json.contains("limit") ? std::optional<uint32_t>(json["limit"].as_uint32()) : std::nullopt;
+   auto offset = json.contains("offset") ? std::optional<uint32_t>(json["offset"].as_uint32()) : std::nullopt;
+   action->setOrdering(order_by_fields, limit, offset);
+   return action;
+}
+
+}  // namespace silo::query_engine::actions

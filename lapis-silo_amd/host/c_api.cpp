@@ -1,0 +1,264 @@
+// c_api.cpp — extern "C" surface of the C++ host (include/silo_engine.h).
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "query_engine.h"
+#include "silo_engine.h"
+
+struct silo_engine {
+   silo::Database database;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& message) {
+   g_error = message;
+   return code;
+}
+
+char* duplicate(const std::string& text) {
+   char* out = static_cast<char*>(std::malloc(text.size() + 1));
+   if (out != nullptr) {
+      std::memcpy(out, text.c_str(), text.size() + 1);
+   }
+   return out;
+}
+
+std::string errorDocument(const char* error, const std::string& message) {  // src/silo_api/error_request_handler.h ErrorResponse
+   silo::json::Value doc = silo::json::Value::object();
+   doc.set("error", silo::json::Value(error));
+   doc.set("message", silo::json::Value(message));
+   return doc.dump();
+}
+
+silo::DatabasePartition* partitionOf(silo_engine* engine, int partition) {
+   if (engine == nullptr || partition < 0 || static_cast<size_t>(partition) >= engine->database.partitions.size()) {
+      return nullptr;
+   }
+   return &engine->database.partitions[static_cast<size_t>(partition)];
+}
+
+template <typename Function>
+int guarded(Function&& function) {
+   try {
+      return function();
+   } catch (const std::exception& ex) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, ex.what());
+   } catch (...) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "unknown exception");
+   }
+}
+
+int seqstoreId(const silo::DatabasePartition& partition, const char* sequence_name, int is_amino_acid) {
+   if (sequence_name == nullptr) {
+      return -1;
+   }
+   if (is_amino_acid != 0) {
+      const auto found = partition.aa_sequences.find(sequence_name);
+      return found == partition.aa_sequences.end() ? -1 : static_cast<int>(found->second.seqstore_id);
+   }
+   const auto found = partition.nuc_sequences.find(sequence_name);
+   return found == partition.nuc_sequences.end() ? -1 : static_cast<int>(found->second.seqstore_id);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* silo_engine_last_error(void) {
+   return g_error.c_str();
+}
+
+int silo_engine_create(
+   const char* reference_genomes_json, const char* alias_json, const char* default_nucleotide_sequence, int device, silo_engine** out
+) {
+   if (reference_genomes_json == nullptr || out == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_create: null argument");
+   }
+   *out = nullptr;
+   return guarded([&] {
+      auto engine = std::make_unique<silo_engine>();
+      engine->database.device = device;
+      engine->database.setReferenceGenomes(silo::json::parse(reference_genomes_json));
+      if (alias_json != nullptr) {
+         engine->database.alias_key = silo::PangoLineageAliasLookup::fromJson(silo::json::parse(alias_json));
+      }
+      if (default_nucleotide_sequence != nullptr) {
+         engine->database.database_config.default_nucleotide_sequence = default_nucleotide_sequence;
+      }
+      *out = engine.release();
+      return 0;
+   });
+}
+
+void silo_engine_destroy(silo_engine* engine) {
+   delete engine;
+}
+
+int silo_engine_add_partition(silo_engine* engine, uint32_t sequence_count) {
+   if (engine == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_add_partition: null engine");
+   }
+   return guarded([&] {
+      engine->database.addPartition(sequence_count);
+      return static_cast<int>(engine->database.partitions.size() - 1);
+   });
+}
+
+int silo_engine_append_sequences(
+   silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, uint32_t first_sequence, uint32_t n_sequences,
+   const char* chars, const uint8_t* is_null
+) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such partition");
+   }
+   const int id = seqstoreId(*part, sequence_name, is_amino_acid);
+   if (id < 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
+   }
+   const int status = silo_gpu_store_append_sequences(part->store, static_cast<uint32_t>(id), first_sequence, n_sequences, chars, is_null);
+   return status == 0 ? 0 : fail(status, silo_gpu_last_error());
+}
+
+int silo_engine_generate_synthetic(silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, const silo_gpu_synth_desc* synth) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such partition");
+   }
+   const int id = seqstoreId(*part, sequence_name, is_amino_acid);
+   if (id < 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
+   }
+   const int status = silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
+   return status == 0 ? 0 : fail(status, silo_gpu_last_error());
+}
+
+int silo_engine_set_lineage_column(silo_engine* engine, int partition, const char* column, const char* const* values, uint32_t n_rows) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr || column == nullptr || (values == nullptr && n_rows > 0)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_lineage_column: bad arguments");
+   }
+   if (n_rows != part->sequence_count) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "lineage column must have one value per row");
+   }
+   return guarded([&] {
+      part->columns.pango_lineage_columns.erase(column);
+      auto& col = part->columns.pango_lineage_columns
+                     .emplace(std::piecewise_construct, std::forward_as_tuple(column), std::forward_as_tuple(engine->database.alias_key, *part))
+                     .first->second;
+      for (uint32_t row = 0; row < n_rows; ++row) {
+         if (values[row] == nullptr) {
+            col.insertNull();
+         } else {
+            col.insert(values[row]);
+         }
+      }
+      return 0;
+   });
+}
+
+int silo_engine_set_lineage_column_ids(
+   silo_engine* engine, int partition, const char* column, const char* const* dictionary, uint32_t n_dictionary, const uint32_t* value_ids,
+   uint32_t n_rows
+) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr || column == nullptr || dictionary == nullptr || value_ids == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_lineage_column_ids: bad arguments");
+   }
+   if (n_rows != part->sequence_count) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "lineage column must have one value per row");
+   }
+   return guarded([&] {
+      std::vector<std::string> names;
+      names.reserve(n_dictionary);
+      for (uint32_t i = 0; i < n_dictionary; ++i) {
+         names.emplace_back(dictionary[i]);
+      }
+      part->columns.pango_lineage_columns.erase(column);
+      auto& col = part->columns.pango_lineage_columns
+                     .emplace(std::piecewise_construct, std::forward_as_tuple(column), std::forward_as_tuple(engine->database.alias_key, *part))
+                     .first->second;
+      col.setValues(std::move(names), value_ids, n_rows);
+      return 0;
+   });
+}
+
+int silo_engine_finalize(silo_engine* engine) {
+   if (engine == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_finalize: null engine");
+   }
+   return guarded([&] {
+      engine->database.finalize();
+      return 0;
+   });
+}
+
+int silo_engine_set_sharding(
+   silo_engine* engine, uint32_t rank, uint32_t world, int shard_by_position, silo_engine_all_reduce_u32 all_reduce, void* context
+) {
+   if (engine == nullptr || world == 0 || rank >= world) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_sharding: bad arguments");
+   }
+   engine->database.shard_rank = rank;
+   engine->database.shard_world = world;
+   engine->database.shard_by_position = shard_by_position != 0;
+   engine->database.all_reduce = all_reduce;
+   engine->database.all_reduce_context = context;
+   return 0;
+}
+
+int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status) {
+   if (engine == nullptr || query_json == nullptr || out_json == nullptr || out_http_status == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_execute_query: null argument");
+   }
+   // the exception -> HTTP mapping of src/silo_api/query_handler.cpp:42-73
+   try {
+      const auto query_result = engine->database.executeQuery(query_json);
+      *out_json = duplicate(silo::query_engine::toJson(query_result).dump());
+      *out_http_status = 200;
+   } catch (const silo::QueryParseException& ex) {
+      *out_json = duplicate(errorDocument("Bad request", ex.what()));
+      *out_http_status = 400;
+   } catch (const std::exception& ex) {
+      *out_json = duplicate(errorDocument("Internal Server Error", ex.what()));
+      *out_http_status = 500;
+   } catch (...) {
+      *out_json = duplicate(errorDocument("Internal Server Error", "non recoverable error message"));
+      *out_http_status = 500;
+   }
+   return *out_json != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+}
+
+void silo_engine_free_string(char* text) {
+   std::free(text);
+}
+
+void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_microseconds) {
+   const auto& timings = silo::Database::lastTimings();
+   if (filter_microseconds != nullptr) {
+      *filter_microseconds = timings.filter_microseconds;
+   }
+   if (action_microseconds != nullptr) {
+      *action_microseconds = timings.action_microseconds;
+   }
+}
+
+silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int partition) {
+   if (engine == nullptr || partition < 0 || static_cast<size_t>(partition) >= engine->database.partitions.size()) {
+      return nullptr;
+   }
+   return engine->database.partitions[static_cast<size_t>(partition)].store;
+}
+
+int silo_engine_seqstore_id(const silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid) {
+   if (engine == nullptr || partition < 0 || static_cast<size_t>(partition) >= engine->database.partitions.size()) {
+      return -1;
+   }
+   return seqstoreId(engine->database.partitions[static_cast<size_t>(partition)], sequence_name, is_amino_acid);
+}
+
+}  // extern "C"

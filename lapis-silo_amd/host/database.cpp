@@ -1,0 +1,323 @@
+#include "database.h"
+
+#include <algorithm>
+#include <sstream>
+
+#include "query_engine.h"
+
+namespace silo {
+
+void checkGpu(int status, const char* what) {
+   if (status != SILO_GPU_OK) {
+      throw DeviceException(std::string(what) + ": " + silo_gpu_last_error());
+   }
+}
+
+// ---- device pool --------------------------------------------------------------------------------
+DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& other) noexcept {
+   if (this != &other) {
+      if (ptr_ != nullptr && pool_ != nullptr) {
+         pool_->release(ptr_, bytes_);
+      }
+      pool_ = other.pool_;
+      ptr_ = other.ptr_;
+      bytes_ = other.bytes_;
+      other.ptr_ = nullptr;
+      other.pool_ = nullptr;
+      other.bytes_ = 0;
+   }
+   return *this;
+}
+
+DeviceBuffer::~DeviceBuffer() {
+   if (ptr_ != nullptr && pool_ != nullptr) {
+      pool_->release(ptr_, bytes_);
+   }
+}
+
+DevicePool::~DevicePool() {
+   for (auto& [bytes, ptr] : free_) {
+      silo_gpu_free(ptr);
+   }
+}
+
+DeviceBuffer DevicePool::acquire(size_t bytes) {
+   bytes = std::max<size_t>(bytes, 256);
+   {
+      const std::lock_guard<std::mutex> lock(mutex_);
+      const auto found = free_.find(bytes);
+      if (found != free_.end()) {
+         void* ptr = found->second;
+         free_.erase(found);
+         return {this, ptr, bytes};
+      }
+   }
+   void* ptr = nullptr;
+   checkGpu(silo_gpu_malloc(bytes, &ptr), "silo_gpu_malloc");
+   return {this, ptr, bytes};
+}
+
+void DevicePool::release(void* ptr, size_t bytes) {
+   const std::lock_guard<std::mutex> lock(mutex_);
+   free_.emplace(bytes, ptr);
+}
+
+// ---- pango lineage aliases (pango_lineage_alias.cpp:21-41, 88-102) -------------------------------
+PangoLineageAliasLookup PangoLineageAliasLookup::fromJson(const json::Value& json) {
+   std::unordered_map<std::string, std::vector<std::string>> alias_keys;
+   for (const auto& [key, value] : json.members()) {
+      if (value.is_array()) {
+         std::vector<std::string> values;
+         for (const auto& item : value.items()) {
+            values.push_back(item.as_string());
+         }
+         alias_keys[key] = std::move(values);
+      } else if (value.is_string() && !value.as_string().empty()) {
+         alias_keys[key] = {value.as_string()};
+      }
+   }
+   return PangoLineageAliasLookup(std::move(alias_keys));
+}
+
+std::string PangoLineageAliasLookup::unaliasPangoLineage(const std::string& pango_lineage) const {
+   const auto dot = pango_lineage.find('.');
+   const std::string prefix = pango_lineage.substr(0, dot);
+   const auto found = alias_key.find(prefix);
+   if (found == alias_key.end() || found->second.size() != 1) {
+      return pango_lineage;
+   }
+   if (dot == std::string::npos) {
+      return found->second.at(0);
+   }
+   // the reference reads the suffix through istream_iterator<char>, which skips whitespace
+   std::string suffix;
+   for (const char c : pango_lineage.substr(dot + 1)) {
+      if (!std::isspace(static_cast<unsigned char>(c))) {
+         suffix.push_back(c);
+      }
+   }
+   return found->second.at(0) + '.' + suffix;
+}
+
+std::vector<std::string> getParentLineages(const std::string& value) {  // pango_lineage.cpp:25-35
+   std::vector<std::string> parent_lineages;
+   std::string::size_type pos = 0;
+   while (pos != std::string::npos) {
+      pos = value.find('.', pos + 1);
+      parent_lineages.push_back(value.substr(0, pos));
+   }
+   return parent_lineages;
+}
+
+// ---- pango lineage column ---------------------------------------------------------------------------
+namespace storage::column {
+
+PangoLineageColumnPartition::PangoLineageColumnPartition(const PangoLineageAliasLookup& alias_key, const DatabasePartition& partition)
+    : alias_key(alias_key), partition(partition) {}
+
+PangoLineageColumnPartition::~PangoLineageColumnPartition() {
+   silo_gpu_free(d_value_ids_);
+   for (auto& [key, ptr] : cache_) {
+      silo_gpu_free(ptr);
+   }
+}
+
+void PangoLineageColumnPartition::insert(const std::string& value) {  // pango_lineage_column.cpp:21-38
+   const std::string resolved = alias_key.unaliasPangoLineage(value);
+   auto found = lookup_unaliased_.find(resolved);
+   if (found == lookup_unaliased_.end()) {
+      found = lookup_unaliased_.emplace(resolved, static_cast<uint32_t>(dictionary_.size())).first;
+      dictionary_.push_back(resolved);
+   }
+   value_ids_.push_back(found->second);
+   ++n_rows_;
+}
+
+void PangoLineageColumnPartition::setValues(std::vector<std::string> dictionary, const uint32_t* value_ids, size_t n_rows) {
+   dictionary_ = std::move(dictionary);
+   lookup_unaliased_.clear();
+   for (uint32_t id = 0; id < dictionary_.size(); ++id) {
+      lookup_unaliased_.emplace(dictionary_[id], id);
+   }
+   value_ids_.assign(value_ids, value_ids + n_rows);
+   n_rows_ = n_rows;
+}
+
+void PangoLineageColumnPartition::finalize() {
+   if (d_value_ids_ != nullptr) {
+      silo_gpu_free(d_value_ids_);
+      d_value_ids_ = nullptr;
+   }
+   checkGpu(silo_gpu_upload_u32(value_ids_.data(), value_ids_.size(), &d_value_ids_), "silo_gpu_upload_u32");
+   value_ids_.clear();
+   value_ids_.shrink_to_fit();
+}
+
+std::optional<const uint64_t*> PangoLineageColumnPartition::lookup(const std::string& value, bool sublineages) const {
+   const std::string resolved = alias_key.unaliasPangoLineage(value);
+   const std::lock_guard<std::mutex> lock(mutex_);
+   const auto key = std::make_pair(resolved, sublineages);
+   if (const auto cached = cache_.find(key); cached != cache_.end()) {
+      return cached->second;
+   }
+   // membership per dictionary entry: the entry itself, or (sublineages) every entry that has
+   // `resolved` in its chain of dotted parents (pango_lineage_column.cpp:44-55).
+   std::vector<uint8_t> membership(dictionary_.size(), 0);
+   bool any = false;
+   for (uint32_t id = 0; id < dictionary_.size(); ++id) {
+      const std::string& entry = dictionary_[id];
+      bool member = entry == resolved;
+      if (!member && sublineages && entry.size() > resolved.size() && entry.compare(0, resolved.size(), resolved) == 0) {
+         member = entry[resolved.size()] == '.' && !resolved.empty();
+      }
+      membership[id] = member ? 1 : 0;
+      any = any || member;
+   }
+   if (!any || d_value_ids_ == nullptr) {
+      return std::nullopt;  // unknown lineage -> Empty (pango_lineage_filter.cpp:55-57)
+   }
+   uint64_t* bitset = nullptr;
+   checkGpu(silo_gpu_bitset_alloc(partition.store, &bitset), "silo_gpu_bitset_alloc");
+   const int status = silo_gpu_bitset_from_value_ids(
+      partition.store, bitset, d_value_ids_, membership.data(), static_cast<uint32_t>(membership.size()), nullptr
+   );
+   if (status != SILO_GPU_OK) {
+      silo_gpu_free(bitset);
+      checkGpu(status, "silo_gpu_bitset_from_value_ids");
+   }
+   cache_.emplace(key, bitset);
+   return bitset;
+}
+
+std::optional<const uint64_t*> PangoLineageColumnPartition::filter(const std::string& value) const {
+   return lookup(value, false);
+}
+
+std::optional<const uint64_t*> PangoLineageColumnPartition::filterIncludingSublineages(const std::string& value) const {
+   return lookup(value, true);
+}
+
+}  // namespace storage::column
+
+// ---- partitions / database ----------------------------------------------------------------------------
+DatabasePartition::~DatabasePartition() {
+   columns.pango_lineage_columns.clear();
+   silo_gpu_store_destroy(store);
+}
+
+Database::Timings& Database::lastTimings() {
+   thread_local Timings timings;
+   return timings;
+}
+
+query_engine::QueryResult Database::executeQuery(const std::string& query) const {
+   const query_engine::QueryEngine query_engine(*this);
+   return query_engine.executeQuery(query);
+}
+
+void Database::setReferenceGenomes(const json::Value& reference_genomes) {  // reference_genomes.cpp
+   nuc_sequences.clear();
+   aa_sequences.clear();
+   const auto read = [](const json::Value& list, auto& target, auto char_to_symbol, const char* what) {
+      for (const auto& entry : list.items()) {
+         const std::string& name = entry.at("name").as_string();
+         const std::string& sequence = entry.at("sequence").as_string();
+         auto& store = target[name];
+         store.reference_sequence.reserve(sequence.size());
+         for (const char c : sequence) {
+            const auto symbol = char_to_symbol(c);
+            if (!symbol.has_value()) {
+               throw std::runtime_error(std::string("illegal character in the ") + what + " reference sequence " + name);
+            }
+            store.reference_sequence.push_back(*symbol);
+         }
+      }
+   };
+   read(reference_genomes.at("nucleotideSequences"), nuc_sequences, Nucleotide::charToSymbol, "nucleotide");
+   read(reference_genomes.at("genes"), aa_sequences, AminoAcid::charToSymbol, "amino acid");
+}
+
+DatabasePartition& Database::addPartition(uint32_t sequence_count) {
+   // one silo_gpu sequence store per nucleotide segment and per gene, in std::map (name) order
+   std::vector<silo_gpu_seqstore_desc> descs;
+   std::vector<std::vector<uint8_t>> references;
+   static const std::vector<uint8_t> nuc_scan = [] {
+      std::vector<uint8_t> out;
+      for (const auto symbol : Nucleotide::VALID_MUTATION_SYMBOLS) {
+         out.push_back(static_cast<uint8_t>(symbol));
+      }
+      return out;
+   }();
+   static const std::vector<uint8_t> aa_scan = [] {
+      std::vector<uint8_t> out;
+      for (const auto symbol : AminoAcid::VALID_MUTATION_SYMBOLS) {
+         out.push_back(static_cast<uint8_t>(symbol));
+      }
+      return out;
+   }();
+   static const uint8_t nuc_extra[] = {static_cast<uint8_t>(Nucleotide::SYMBOL_MISSING)};
+   static const uint8_t aa_extra[] = {static_cast<uint8_t>(AminoAcid::SYMBOL_MISSING)};
+
+   const auto add = [&](const auto& stores, uint32_t alphabet, const std::vector<uint8_t>& scan, const uint8_t* extra) {
+      for (const auto& [name, store] : stores) {
+         auto& reference = references.emplace_back();
+         for (const auto symbol : store.reference_sequence) {
+            reference.push_back(static_cast<uint8_t>(symbol));
+         }
+         silo_gpu_seqstore_desc desc{};
+         desc.alphabet = alphabet;
+         desc.positions = static_cast<uint32_t>(reference.size());
+         desc.n_scan_symbols = static_cast<uint32_t>(scan.size());
+         desc.scan_symbols = scan.data();
+         desc.n_extra_symbols = 1;
+         desc.extra_symbols = extra;
+         descs.push_back(desc);
+      }
+   };
+   add(nuc_sequences, SILO_GPU_ALPHABET_NUCLEOTIDE, nuc_scan, nuc_extra);
+   add(aa_sequences, SILO_GPU_ALPHABET_AMINO_ACID, aa_scan, aa_extra);
+   for (size_t i = 0; i < descs.size(); ++i) {
+      descs[i].reference = references[i].data();
+   }
+   if (descs.empty()) {
+      throw std::runtime_error("Database has no sequence stores: call setReferenceGenomes first");
+   }
+   silo_gpu_store_desc desc{};
+   desc.device = device;
+   desc.sequence_count = sequence_count;
+   desc.n_seqstores = static_cast<uint32_t>(descs.size());
+   desc.seqstores = descs.data();
+
+   DatabasePartition& partition = partitions.emplace_back();
+   partition.sequence_count = sequence_count;
+   const int status = silo_gpu_store_create(&desc, &partition.store);
+   if (status != SILO_GPU_OK) {
+      partitions.pop_back();
+      checkGpu(status, "silo_gpu_store_create");
+   }
+   uint32_t seqstore_id = 0;
+   for (const auto& [name, store] : nuc_sequences) {
+      partition.nuc_sequences.emplace(
+         std::piecewise_construct, std::forward_as_tuple(name),
+         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count)
+      );
+   }
+   for (const auto& [name, store] : aa_sequences) {
+      partition.aa_sequences.emplace(
+         std::piecewise_construct, std::forward_as_tuple(name),
+         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count)
+      );
+   }
+   return partition;
+}
+
+void Database::finalize() {
+   for (auto& partition : partitions) {
+      checkGpu(silo_gpu_store_finalize(partition.store), "silo_gpu_store_finalize");
+      for (auto& [name, column] : partition.columns.pango_lineage_columns) {
+         column.finalize();
+      }
+   }
+}
+
+}  // namespace silo

@@ -1,0 +1,246 @@
+// database.h — host-side mirror of the slice of silo::Database the query path reads.
+//
+// Reference types mirrored (file:line under the reference tree):
+//   silo::Database                       include/silo/database.h:29-118 (partitions, nuc_sequences, aa_sequences,
+//                                        alias_key, database_config, executeQuery :79)
+//   silo::DatabasePartition              include/silo/storage/database_partition.h:39-112
+//   silo::SequenceStorePartition<S>      include/silo/storage/sequence_store.h:34-88
+//   silo::SequenceStore<S>               include/silo/storage/sequence_store.h:90-101
+//   storage::column::PangoLineageColumnPartition   include/silo/storage/column/pango_lineage_column.h
+//   silo::PangoLineageAliasLookup        include/silo/storage/pango_lineage_alias.h
+//
+// MI355X-first difference: the bitmaps live in HBM behind a silo_gpu_store (include/silo_gpu.h); this
+// layer holds names, reference sequences, the lineage dictionary and device handles only.
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "json.h"
+#include "silo_gpu.h"
+#include "symbols.h"
+
+namespace silo {
+
+namespace query_engine {
+struct QueryResult;
+}
+
+/// Thrown when a silo_gpu call fails; surfaces as HTTP 500 like any std::exception
+/// (src/silo_api/query_handler.cpp:46-50).
+class DeviceException : public std::runtime_error {
+  public:
+   using std::runtime_error::runtime_error;
+};
+void checkGpu(int status, const char* what);
+
+/// RAII device allocation taken from / returned to a per-database pool (no hipMalloc on the hot path).
+class DevicePool;
+class DeviceBuffer {
+  public:
+   DeviceBuffer() = default;
+   DeviceBuffer(DevicePool* pool, void* ptr, size_t bytes) : pool_(pool), ptr_(ptr), bytes_(bytes) {}
+   DeviceBuffer(DeviceBuffer&& other) noexcept { *this = std::move(other); }
+   DeviceBuffer& operator=(DeviceBuffer&& other) noexcept;
+   DeviceBuffer(const DeviceBuffer&) = delete;
+   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+   ~DeviceBuffer();
+   [[nodiscard]] void* get() const { return ptr_; }
+   template <typename T>
+   [[nodiscard]] T* as() const { return static_cast<T*>(ptr_); }
+   [[nodiscard]] size_t size() const { return bytes_; }
+   explicit operator bool() const { return ptr_ != nullptr; }
+
+  private:
+   DevicePool* pool_ = nullptr;
+   void* ptr_ = nullptr;
+   size_t bytes_ = 0;
+};
+
+class DevicePool {
+  public:
+   ~DevicePool();
+   DeviceBuffer acquire(size_t bytes);
+   void release(void* ptr, size_t bytes);
+
+  private:
+   std::mutex mutex_;
+   std::multimap<size_t, void*> free_;
+};
+
+class PangoLineageAliasLookup {
+  public:
+   PangoLineageAliasLookup() = default;
+   explicit PangoLineageAliasLookup(std::unordered_map<std::string, std::vector<std::string>> alias_key)
+       : alias_key(std::move(alias_key)) {}
+   static PangoLineageAliasLookup fromJson(const json::Value& json);
+   [[nodiscard]] std::string unaliasPangoLineage(const std::string& pango_lineage) const;
+
+  private:
+   std::unordered_map<std::string, std::vector<std::string>> alias_key;
+};
+
+std::vector<std::string> getParentLineages(const std::string& unaliased_lineage);
+
+class DatabasePartition;
+
+namespace storage::column {
+
+/// Dictionary-encoded lineage column: the value id of every row sits in HBM; a filter bitset is built on
+/// the device from a per-dictionary-entry membership table on first use and cached ("host-built bitset
+/// uploaded once").  Reference: pango_lineage_column.cpp:21-77.
+class PangoLineageColumnPartition {
+  public:
+   PangoLineageColumnPartition(const PangoLineageAliasLookup& alias_key, const DatabasePartition& partition);
+   ~PangoLineageColumnPartition();
+   PangoLineageColumnPartition(const PangoLineageColumnPartition&) = delete;
+
+   void insert(const std::string& value);
+   void insertNull() { insert(""); }
+   /// Bulk form for synthetic data: ids into `dictionary` (already unaliased lineage names).
+   void setValues(std::vector<std::string> dictionary, const uint32_t* value_ids, size_t n_rows);
+   void finalize();
+
+   [[nodiscard]] std::optional<const uint64_t*> filter(const std::string& value) const;
+   [[nodiscard]] std::optional<const uint64_t*> filterIncludingSublineages(const std::string& value) const;
+   [[nodiscard]] size_t numRows() const { return n_rows_; }
+
+  private:
+   std::optional<const uint64_t*> lookup(const std::string& value, bool sublineages) const;
+
+   const PangoLineageAliasLookup& alias_key;
+   const DatabasePartition& partition;
+   std::vector<std::string> dictionary_;  // unaliased lineage per value id
+   std::unordered_map<std::string, uint32_t> lookup_unaliased_;
+   std::vector<uint32_t> value_ids_;      // host staging until finalize()
+   uint32_t* d_value_ids_ = nullptr;
+   size_t n_rows_ = 0;
+   mutable std::mutex mutex_;
+   mutable std::map<std::pair<std::string, bool>, uint64_t*> cache_;  // device bitsets
+};
+
+}  // namespace storage::column
+
+template <typename SymbolType>
+class SequenceStore {
+  public:
+   std::vector<typename SymbolType::Symbol> reference_sequence;
+};
+
+template <typename SymbolType>
+class SequenceStorePartition {
+  public:
+   SequenceStorePartition(const std::vector<typename SymbolType::Symbol>& reference_sequence, silo_gpu_store* store, uint32_t seqstore_id, uint32_t sequence_count)
+       : reference_sequence(reference_sequence), store(store), seqstore_id(seqstore_id), sequence_count(sequence_count) {}
+
+   const std::vector<typename SymbolType::Symbol>& reference_sequence;
+   silo_gpu_store* store;
+   uint32_t seqstore_id;
+   uint32_t sequence_count;
+
+   /// Device pointer of the dense plane, nullptr when the symbol is stored sparsely
+   /// (sequence_store.cpp:92-98 returned a roaring pointer).
+   [[nodiscard]] const uint64_t* getBitmap(size_t position, typename SymbolType::Symbol symbol) const {
+      return silo_gpu_store_plane(store, seqstore_id, static_cast<uint32_t>(position), static_cast<uint32_t>(symbol));
+   }
+};
+
+class DatabasePartition {
+  public:
+   DatabasePartition() = default;
+   DatabasePartition(const DatabasePartition&) = delete;
+   ~DatabasePartition();
+
+   uint32_t sequence_count = 0;
+   silo_gpu_store* store = nullptr;
+   std::map<std::string, SequenceStorePartition<Nucleotide>> nuc_sequences;
+   std::map<std::string, SequenceStorePartition<AminoAcid>> aa_sequences;
+   struct ColumnPartitionGroup {
+      std::map<std::string, storage::column::PangoLineageColumnPartition> pango_lineage_columns;
+   } columns;
+
+   mutable DevicePool pool;
+   /// Unfiltered Mutations totals per sequence store, computed once (mutations.cpp:98-136 reads
+   /// cardinalities for full filters): key = (is_aa, seqstore_id).
+   mutable std::mutex totals_mutex;
+   mutable std::map<uint32_t, std::vector<uint32_t>> full_counts;
+
+   [[nodiscard]] uint32_t rowWords() const { return silo_gpu_store_row_words(store); }
+
+   template <typename SymbolType>
+   [[nodiscard]] const std::map<std::string, SequenceStorePartition<SymbolType>>& getSequenceStores() const;
+};
+
+/// Collective hook for multi-GPU runs (one process per GPU): sums `n` uint32 on the device across all
+/// ranks in place, on `stream`.  bench.py backs it with torch.distributed (RCCL over xGMI); a native
+/// host would call ncclAllReduce.  SURVEY.md §8(e).
+using AllReduceU32 = int (*)(void* context, uint32_t* device_values, size_t n, void* stream);
+
+class Database {
+  public:
+   Database() = default;
+   virtual ~Database() = default;
+
+   std::deque<DatabasePartition> partitions;
+   std::map<std::string, SequenceStore<Nucleotide>> nuc_sequences;
+   std::map<std::string, SequenceStore<AminoAcid>> aa_sequences;
+   struct DatabaseConfig {
+      std::string default_nucleotide_sequence = "main";
+   } database_config;
+   PangoLineageAliasLookup alias_key;
+   int device = 0;
+
+   // --- sharding ---------------------------------------------------------------
+   /// Position-range sharding: this rank scans rows [begin,end) of the position x symbol space only
+   /// and the counts are all-reduced.  world == 1 -> everything local.
+   uint32_t shard_rank = 0;
+   uint32_t shard_world = 1;
+   bool shard_by_position = false;
+   AllReduceU32 all_reduce = nullptr;
+   void* all_reduce_context = nullptr;
+
+   /// Timings of the last query on this thread, the reference's two phases (query_engine.cpp:63-65).
+   struct Timings {
+      int64_t filter_microseconds = 0;
+      int64_t action_microseconds = 0;
+   };
+   static Timings& lastTimings();
+
+   template <typename SymbolType>
+   [[nodiscard]] const std::map<std::string, SequenceStore<SymbolType>>& getSequenceStores() const;
+
+   /// database.cpp:710-714
+   [[nodiscard]] virtual query_engine::QueryResult executeQuery(const std::string& query) const;
+
+   // --- construction (replaces Preprocessor::buildDatabase, preprocessor.cpp:447-503) -----------
+   void setReferenceGenomes(const json::Value& reference_genomes);
+   DatabasePartition& addPartition(uint32_t sequence_count);
+   void finalize();
+};
+
+template <>
+inline const std::map<std::string, SequenceStorePartition<Nucleotide>>& DatabasePartition::getSequenceStores<Nucleotide>() const {
+   return nuc_sequences;
+}
+template <>
+inline const std::map<std::string, SequenceStorePartition<AminoAcid>>& DatabasePartition::getSequenceStores<AminoAcid>() const {
+   return aa_sequences;
+}
+template <>
+inline const std::map<std::string, SequenceStore<Nucleotide>>& Database::getSequenceStores<Nucleotide>() const {
+   return nuc_sequences;
+}
+template <>
+inline const std::map<std::string, SequenceStore<AminoAcid>>& Database::getSequenceStores<AminoAcid>() const {
+   return aa_sequences;
+}
+
+}  // namespace silo

@@ -1,0 +1,636 @@
+// filter_expressions.cpp — logical filter tree: JSON -> Expression -> compile() -> operators.
+// Mirrors src/silo/query_engine/filter_expressions/*.cpp of the reference (cited per function),
+// including the algebraic rewrites and the observable quirks listed in SURVEY.md §8(a).
+#include <algorithm>
+
+#include "query_engine.h"
+
+namespace silo::query_engine::filter_expressions {
+
+using operators::Operator;
+using operators::OperatorVector;
+
+namespace {
+
+RowSpace rowsOf(const DatabasePartition& partition) {
+   return {partition.sequence_count, &partition};
+}
+
+std::string join(const std::vector<std::string>& parts, const std::string& separator) {
+   std::string out;
+   for (size_t i = 0; i < parts.size(); ++i) {
+      if (i != 0) {
+         out += separator;
+      }
+      out += parts[i];
+   }
+   return out;
+}
+
+// nucleotide_symbol_equals.cpp:28-73
+using NS = Nucleotide::Symbol;
+const std::array<std::vector<NS>, Nucleotide::COUNT> AMBIGUITY_NUC_SYMBOLS{{
+   {NS::GAP},
+   {NS::A, NS::R, NS::M, NS::W, NS::D, NS::H, NS::V, NS::N},
+   {NS::C, NS::Y, NS::M, NS::S, NS::B, NS::H, NS::V, NS::N},
+   {NS::G, NS::R, NS::K, NS::S, NS::B, NS::D, NS::V, NS::N},
+   {NS::T, NS::Y, NS::K, NS::W, NS::B, NS::D, NS::H, NS::N},
+   {NS::R}, {NS::Y}, {NS::S}, {NS::W}, {NS::K}, {NS::M}, {NS::B}, {NS::D}, {NS::H}, {NS::V}, {NS::N},
+}};
+
+/// Leaf operator for "row has `symbol` at `position`".  The reference distinguishes flipped and deleted
+/// storage here (nucleotide_symbol_equals.cpp:144-188); those are storage tricks with no observable
+/// effect: the dense store holds the true membership plane of every symbol.
+template <typename SymbolType>
+std::unique_ptr<Operator> symbolPlane(
+   const SequenceStorePartition<SymbolType>& store, const DatabasePartition& partition, uint32_t position, typename SymbolType::Symbol symbol
+) {
+   const RowSpace rows = rowsOf(partition);
+   const uint64_t* plane = store.getBitmap(position, symbol);
+   if (symbol == SymbolType::SYMBOL_MISSING) {
+      // nucleotide_symbol_equals.cpp:131-143 / aa_symbol_equals.cpp:55-62
+      return std::make_unique<operators::BitmapSelection>(plane, rows, operators::BitmapSelection::CONTAINS, position);
+   }
+   if (plane == nullptr) {
+      return std::make_unique<operators::IndexScan>(store.seqstore_id, position, static_cast<uint32_t>(symbol), rows);
+   }
+   return std::make_unique<operators::IndexScan>(plane, rows);
+}
+
+}  // namespace
+
+Expression::AmbiguityMode invertMode(Expression::AmbiguityMode mode) {  // expression.cpp:38-46
+   if (mode == Expression::UPPER_BOUND) {
+      return Expression::LOWER_BOUND;
+   }
+   if (mode == Expression::LOWER_BOUND) {
+      return Expression::UPPER_BOUND;
+   }
+   return mode;
+}
+
+// ---- True / False ---------------------------------------------------------------------------------
+std::string True::toString(const Database& /*database*/) const {
+   return "True";
+}
+std::unique_ptr<Operator> True::compile(const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/) const {
+   return std::make_unique<operators::Full>(rowsOf(database_partition));
+}
+std::string False::toString(const Database& /*database*/) const {
+   return "False";
+}
+std::unique_ptr<Operator> False::compile(const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/) const {
+   return std::make_unique<operators::Empty>(rowsOf(database_partition));
+}
+
+// ---- And (and.cpp:101-227; Selection predicates are outside this path) -----------------------------
+std::string And::toString(const Database& database) const {
+   std::vector<std::string> child_strings;
+   for (const auto& child : children) {
+      child_strings.push_back(child->toString(database));
+   }
+   return "And(" + join(child_strings, " & ") + ")";
+}
+
+std::pair<OperatorVector, OperatorVector> And::compileChildren(
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+) const {
+   OperatorVector all_child_operators;
+   for (const auto& expression : children) {
+      all_child_operators.push_back(expression->compile(database, database_partition, mode));
+   }
+   OperatorVector non_negated_child_operators;
+   OperatorVector negated_child_operators;
+   for (auto& child : all_child_operators) {
+      if (child->type() == operators::FULL) {
+         continue;
+      }
+      if (child->type() == operators::EMPTY) {
+         OperatorVector empty;
+         empty.emplace_back(std::make_unique<operators::Empty>(rowsOf(database_partition)));
+         return {std::move(empty), OperatorVector()};
+      }
+      if (child->type() == operators::INTERSECTION) {
+         auto* intersection_child = dynamic_cast<operators::Intersection*>(child.get());
+         for (auto& grandchild : intersection_child->children) {
+            non_negated_child_operators.push_back(std::move(grandchild));
+         }
+         for (auto& grandchild : intersection_child->negated_children) {
+            negated_child_operators.push_back(std::move(grandchild));
+         }
+      } else if (child->type() == operators::COMPLEMENT) {
+         negated_child_operators.emplace_back(child->negate());
+      } else {
+         non_negated_child_operators.push_back(std::move(child));
+      }
+   }
+   return {std::move(non_negated_child_operators), std::move(negated_child_operators)};
+}
+
+std::unique_ptr<Operator> And::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   auto [non_negated_child_operators, negated_child_operators] = compileChildren(database, database_partition, mode);
+   const RowSpace rows = rowsOf(database_partition);
+   if (non_negated_child_operators.empty() && negated_child_operators.empty()) {
+      return std::make_unique<operators::Full>(rows);
+   }
+   if (non_negated_child_operators.size() == 1 && negated_child_operators.empty()) {
+      return std::move(non_negated_child_operators[0]);
+   }
+   if (negated_child_operators.size() == 1 && non_negated_child_operators.empty()) {
+      return std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
+   }
+   if (non_negated_child_operators.empty()) {
+      auto union_ret = std::make_unique<operators::Union>(std::move(negated_child_operators), rows);
+      return std::make_unique<operators::Complement>(std::move(union_ret), rows);
+   }
+   return std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
+}
+
+// ---- Or (or.cpp:41-94) ---------------------------------------------------------------------------
+std::string Or::toString(const Database& database) const {
+   std::vector<std::string> child_strings;
+   for (const auto& child : children) {
+      child_strings.push_back(child->toString(database));
+   }
+   return "Or(" + join(child_strings, " | ") + ")";
+}
+
+std::unique_ptr<Operator> Or::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   const RowSpace rows = rowsOf(database_partition);
+   OperatorVector all_child_operators;
+   for (const auto& expression : children) {
+      all_child_operators.push_back(expression->compile(database, database_partition, mode));
+   }
+   OperatorVector filtered_child_operators;
+   for (auto& child : all_child_operators) {
+      if (child->type() == operators::EMPTY) {
+         continue;
+      }
+      if (child->type() == operators::FULL) {
+         return std::make_unique<operators::Full>(rows);
+      }
+      if (child->type() == operators::UNION) {
+         auto* or_child = dynamic_cast<operators::Union*>(child.get());
+         for (auto& grandchild : or_child->children) {
+            filtered_child_operators.push_back(std::move(grandchild));
+         }
+      } else {
+         filtered_child_operators.push_back(std::move(child));
+      }
+   }
+   if (filtered_child_operators.empty()) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   if (filtered_child_operators.size() == 1) {
+      return std::move(filtered_child_operators[0]);
+   }
+   if (std::any_of(filtered_child_operators.begin(), filtered_child_operators.end(), [](const auto& child) {
+          return child->type() == operators::COMPLEMENT;
+       })) {
+      return operators::Complement::fromDeMorgan(std::move(filtered_child_operators), rows);
+   }
+   return std::make_unique<operators::Union>(std::move(filtered_child_operators), rows);
+}
+
+// ---- Negation / Maybe / Exact ----------------------------------------------------------------------
+std::string Negation::toString(const Database& database) const {
+   return "!(" + child->toString(database) + ")";
+}
+std::unique_ptr<Operator> Negation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   auto child_operator = child->compile(database, database_partition, invertMode(mode));  // negation.cpp:27-34
+   return child_operator->negate();
+}
+std::string Maybe::toString(const Database& database) const {
+   return "Maybe (" + child->toString(database) + ")";
+}
+std::unique_ptr<Operator> Maybe::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode /*mode*/) const {
+   return child->compile(database, database_partition, AmbiguityMode::UPPER_BOUND);  // maybe.cpp:26-32
+}
+std::string Exact::toString(const Database& database) const {
+   return "Exact ( " + child->toString(database) + ")";
+}
+std::unique_ptr<Operator> Exact::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode /*mode*/) const {
+   return child->compile(database, database_partition, AmbiguityMode::LOWER_BOUND);  // exact.cpp:26-32
+}
+
+// ---- N-Of (nof.cpp) ------------------------------------------------------------------------------
+namespace {
+
+std::unique_ptr<Operator> handleTrivialCases(  // nof.cpp:35-88
+   const int updated_number_of_matchers, OperatorVector& non_negated_child_operators, OperatorVector& negated_child_operators,
+   bool match_exactly, RowSpace rows
+) {
+   const int child_operator_count = static_cast<int>(non_negated_child_operators.size() + negated_child_operators.size());
+   if (updated_number_of_matchers > child_operator_count) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   if (updated_number_of_matchers < 0) {
+      if (match_exactly) {
+         return std::make_unique<operators::Empty>(rows);
+      }
+      return std::make_unique<operators::Full>(rows);
+   }
+   if (updated_number_of_matchers == 0) {
+      if (!match_exactly) {
+         return std::make_unique<operators::Full>(rows);
+      }
+      if (child_operator_count == 0) {
+         return std::make_unique<operators::Full>(rows);
+      }
+      if (child_operator_count == 1) {
+         if (non_negated_child_operators.empty()) {
+            return std::move(negated_child_operators[0]);
+         }
+         return std::make_unique<operators::Complement>(std::move(non_negated_child_operators[0]), rows);
+      }
+      if (negated_child_operators.empty()) {
+         auto union_ret = std::make_unique<operators::Union>(std::move(non_negated_child_operators), rows);
+         return std::make_unique<operators::Complement>(std::move(union_ret), rows);
+      }
+      return std::make_unique<operators::Intersection>(std::move(negated_child_operators), std::move(non_negated_child_operators), rows);
+   }
+   if (updated_number_of_matchers == 1 && child_operator_count == 1) {
+      if (negated_child_operators.empty()) {
+         return std::move(non_negated_child_operators[0]);
+      }
+      return std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
+   }
+   return nullptr;
+}
+
+std::unique_ptr<Operator> toOperator(  // nof.cpp:90-154
+   const int updated_number_of_matchers, OperatorVector&& non_negated_child_operators, OperatorVector&& negated_child_operators,
+   bool match_exactly, RowSpace rows
+) {
+   auto tmp = handleTrivialCases(updated_number_of_matchers, non_negated_child_operators, negated_child_operators, match_exactly, rows);
+   if (tmp) {
+      return tmp;
+   }
+   const int child_operator_count = static_cast<int>(non_negated_child_operators.size() + negated_child_operators.size());
+   if (updated_number_of_matchers == child_operator_count) {  // handleAndCase
+      if (non_negated_child_operators.empty()) {
+         auto union_ret = std::make_unique<operators::Union>(std::move(negated_child_operators), rows);
+         return std::make_unique<operators::Complement>(std::move(union_ret), rows);
+      }
+      return std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
+   }
+   if (updated_number_of_matchers == 1 && !match_exactly) {  // handleOrCase
+      if (negated_child_operators.empty()) {
+         return std::make_unique<operators::Union>(std::move(non_negated_child_operators), rows);
+      }
+      auto intersection_ret = std::make_unique<operators::Intersection>(
+         std::move(negated_child_operators), std::move(non_negated_child_operators), rows
+      );
+      return std::make_unique<operators::Complement>(std::move(intersection_ret), rows);
+   }
+   return std::make_unique<operators::Threshold>(
+      std::move(non_negated_child_operators), std::move(negated_child_operators), updated_number_of_matchers, match_exactly, rows
+   );
+}
+
+}  // namespace
+
+std::string NOf::toString(const Database& database) const {
+   std::string res = match_exactly ? "[exactly-" + std::to_string(number_of_matchers) + "-of:" : "[" + std::to_string(number_of_matchers) + "-of:";
+   for (const auto& child : children) {
+      res += child->toString(database);
+      res += ", ";
+   }
+   return res + "]";
+}
+
+std::tuple<OperatorVector, OperatorVector, int> NOf::mapChildExpressions(  // nof.cpp:185-218
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+) const {
+   OperatorVector non_negated_child_operators;
+   OperatorVector negated_child_operators;
+   int updated_number_of_matchers = number_of_matchers;
+   for (const auto& child_expression : children) {
+      auto child_operator = child_expression->compile(database, database_partition, mode);
+      if (child_operator->type() == operators::EMPTY) {
+         continue;
+      }
+      if (child_operator->type() == operators::FULL) {
+         updated_number_of_matchers--;
+      } else if (child_operator->type() == operators::COMPLEMENT) {
+         negated_child_operators.emplace_back(child_operator->negate());
+      } else {
+         non_negated_child_operators.push_back(std::move(child_operator));
+      }
+   }
+   return {std::move(non_negated_child_operators), std::move(negated_child_operators), updated_number_of_matchers};
+}
+
+std::unique_ptr<Operator> NOf::rewriteNonExact(  // nof.cpp:220-258
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+) const {
+   const RowSpace rows = rowsOf(database_partition);
+   OperatorVector at_least_k;
+   {
+      auto [non_negated, negated, updated] = mapChildExpressions(database, database_partition, mode);
+      at_least_k.emplace_back(toOperator(updated, std::move(non_negated), std::move(negated), false, rows));
+   }
+   OperatorVector at_least_k_plus_one;
+   {
+      auto [non_negated, negated, updated] = mapChildExpressions(database, database_partition, mode);
+      at_least_k_plus_one.emplace_back(toOperator(updated + 1, std::move(non_negated), std::move(negated), false, rows));
+   }
+   return toOperator(2, std::move(at_least_k), std::move(at_least_k_plus_one), false, rows);
+}
+
+std::unique_ptr<Operator> NOf::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   auto [non_negated_child_operators, negated_child_operators, updated_number_of_matchers] =
+      mapChildExpressions(database, database_partition, mode);
+   // nof.cpp:268-271
+   if (mode != NONE && match_exactly && number_of_matchers < static_cast<int>(children.size())) {
+      return rewriteNonExact(database, database_partition, mode);
+   }
+   return toOperator(
+      updated_number_of_matchers, std::move(non_negated_child_operators), std::move(negated_child_operators), match_exactly,
+      rowsOf(database_partition)
+   );
+}
+
+// ---- NucleotideSymbolEquals (nucleotide_symbol_equals.cpp:94-189) -----------------------------------
+std::string NucleotideSymbolEquals::toString(const Database& /*database*/) const {
+   const std::string prefix = nuc_sequence_name ? nuc_sequence_name.value() + ":" : "";
+   const char symbol_char = value.has_value() ? Nucleotide::symbolToChar(*value) : '.';
+   return prefix + std::to_string(position + 1) + std::to_string(symbol_char);
+}
+
+std::unique_ptr<Operator> NucleotideSymbolEquals::compile(
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+) const {
+   const std::string nuc_sequence_name_or_default = nuc_sequence_name.value_or(database.database_config.default_nucleotide_sequence);
+   CHECK_SILO_QUERY(
+      database.nuc_sequences.count(nuc_sequence_name_or_default) != 0,
+      "Database does not contain the nucleotide sequence with name: '" + nuc_sequence_name_or_default + "'"
+   )
+   const auto& seq_store_partition = database_partition.nuc_sequences.at(nuc_sequence_name_or_default);
+   if (position >= seq_store_partition.reference_sequence.size()) {
+      throw QueryParseException(
+         "NucleotideEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" +
+         std::to_string(seq_store_partition.reference_sequence.size()) + "'"
+      );
+   }
+   const Nucleotide::Symbol nucleotide_symbol = value.value_or(seq_store_partition.reference_sequence.at(position));
+   if (mode == UPPER_BOUND) {
+      const auto& symbols_to_match = AMBIGUITY_NUC_SYMBOLS.at(static_cast<uint32_t>(nucleotide_symbol));
+      ExpressionVector symbol_filters;
+      for (const auto symbol : symbols_to_match) {
+         symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
+      }
+      return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+   }
+   return symbolPlane<Nucleotide>(seq_store_partition, database_partition, position, nucleotide_symbol);
+}
+
+// ---- AASymbolEquals (aa_symbol_equals.cpp:41-92; the ambiguity mode is ignored, :44) ----------------
+std::string AASymbolEquals::toString(const Database& /*database*/) const {
+   const char symbol_char = value.has_value() ? AminoAcid::symbolToChar(*value) : '.';
+   return aa_sequence_name + ":" + std::to_string(position + 1) + std::to_string(symbol_char);
+}
+
+std::unique_ptr<Operator> AASymbolEquals::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {
+   const auto& aa_store_partition = database_partition.aa_sequences.at(aa_sequence_name);  // out_of_range -> 500, as in the reference
+   if (position >= aa_store_partition.reference_sequence.size()) {
+      throw QueryParseException(
+         "AminoAcidEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" +
+         std::to_string(aa_store_partition.reference_sequence.size()) + "'"
+      );
+   }
+   const AminoAcid::Symbol aa_symbol = value.value_or(aa_store_partition.reference_sequence.at(position));
+   // The reference's rewrite for a deleted STOP symbol recurses forever; the dense
+   // store simply returns the intended set.
+   return symbolPlane<AminoAcid>(aa_store_partition, database_partition, position, aa_symbol);
+}
+
+// ---- HasMutation (has_mutation.cpp:35-78) ----------------------------------------------------------
+std::string HasMutation::toString(const Database& /*database*/) const {
+   const std::string prefix = nuc_sequence_name ? nuc_sequence_name.value() + ":" : "";
+   return prefix + std::to_string(position);
+}
+
+std::unique_ptr<Operator> HasMutation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   const std::string nuc_sequence_name_or_default = nuc_sequence_name.value_or(database.database_config.default_nucleotide_sequence);
+   CHECK_SILO_QUERY(
+      database.nuc_sequences.count(nuc_sequence_name_or_default) != 0,
+      "Database does not contain the nucleotide sequence with name: '" + nuc_sequence_name_or_default + "'"
+   )
+   const Nucleotide::Symbol ref_symbol = database.nuc_sequences.at(nuc_sequence_name_or_default).reference_sequence.at(position);
+   if (mode == UPPER_BOUND) {
+      auto expression = std::make_unique<Negation>(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, ref_symbol));
+      return expression->compile(database, database_partition, NONE);
+   }
+   std::vector<Nucleotide::Symbol> symbols = {NS::A, NS::C, NS::G, NS::T};
+   // SILO_COMPAT_REMOVE_QUIRK: the reference calls std::remove without erase (has_mutation.cpp:58-65),
+   // so the list keeps four entries; at reference-T positions T itself stays in it.
+   (void)std::remove(symbols.begin(), symbols.end(), ref_symbol);
+   ExpressionVector symbol_filters;
+   for (const auto symbol : symbols) {
+      symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
+   }
+   return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+}
+
+// ---- HasAAMutation (has_aa_mutation.cpp:33-63) -----------------------------------------------------
+std::string HasAAMutation::toString(const Database& /*database*/) const {
+   return aa_sequence_name + ":" + std::to_string(position);
+}
+
+std::unique_ptr<Operator> HasAAMutation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
+   const AminoAcid::Symbol ref_symbol = database.aa_sequences.at(aa_sequence_name).reference_sequence.at(position);
+   if (mode == UPPER_BOUND) {
+      auto expression = std::make_unique<Negation>(std::make_unique<AASymbolEquals>(aa_sequence_name, position, ref_symbol));
+      return expression->compile(database, database_partition, NONE);
+   }
+   std::vector<AminoAcid::Symbol> symbols(AminoAcid::SYMBOLS.begin(), AminoAcid::SYMBOLS.end());
+   // SILO_COMPAT_REMOVE_QUIRK: both removes are without erase (has_aa_mutation.cpp:48-52)
+   (void)std::remove(symbols.begin(), symbols.end(), AminoAcid::Symbol::X);
+   (void)std::remove(symbols.begin(), symbols.end(), ref_symbol);
+   ExpressionVector symbol_filters;
+   for (const auto symbol : symbols) {
+      symbol_filters.push_back(std::make_unique<AASymbolEquals>(aa_sequence_name, position, symbol));
+   }
+   return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+}
+
+// ---- PangoLineageFilter (pango_lineage_filter.cpp:37-59) ---------------------------------------------
+std::string PangoLineageFilter::toString(const Database& /*database*/) const {
+   return include_sublineages ? lineage + "*" : lineage;
+}
+
+std::unique_ptr<Operator> PangoLineageFilter::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {
+   const RowSpace rows = rowsOf(database_partition);
+   const auto found = database_partition.columns.pango_lineage_columns.find(column);
+   if (found == database_partition.columns.pango_lineage_columns.end()) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   std::string lineage_all_upper = lineage;
+   std::transform(lineage_all_upper.begin(), lineage_all_upper.end(), lineage_all_upper.begin(), ::toupper);
+   const auto& pango_lineage_column = found->second;
+   const auto bitmap = include_sublineages ? pango_lineage_column.filterIncludingSublineages(lineage_all_upper)
+                                           : pango_lineage_column.filter(lineage_all_upper);
+   if (bitmap == std::nullopt) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   return std::make_unique<operators::IndexScan>(bitmap.value(), rows);
+}
+
+// ---- JSON -> Expression (the from_json functions) ------------------------------------------------------
+namespace {
+
+ExpressionVector parseChildren(const json::Value& json) {
+   ExpressionVector children;
+   for (const auto& child : json.at("children").items()) {
+      children.push_back(parseExpression(child));
+   }
+   return children;
+}
+
+}  // namespace
+
+std::unique_ptr<Expression> parseExpression(const json::Value& json) {  // expression.cpp:49-102
+   CHECK_SILO_QUERY(json.contains("type"), "The field 'type' is required in any filter expression")
+   CHECK_SILO_QUERY(
+      json["type"].is_string(), "The field 'type' in all filter expressions needs to be a string, but is: " + json["type"].dump()
+   )
+   const std::string expression_type = json["type"].as_string();
+   if (expression_type == "True") {
+      return std::make_unique<True>();
+   }
+   if (expression_type == "False") {
+      return std::make_unique<False>();
+   }
+   if (expression_type == "And") {  // and.cpp:230-239
+      CHECK_SILO_QUERY(json.contains("children"), "The field 'children' is required in an And expression")
+      CHECK_SILO_QUERY(json["children"].is_array(), "The field 'children' in an And expression needs to be an array")
+      return std::make_unique<And>(parseChildren(json));
+   }
+   if (expression_type == "Or") {  // or.cpp:97-106
+      CHECK_SILO_QUERY(json.contains("children"), "The field 'children' is required in an Or expression")
+      CHECK_SILO_QUERY(json["children"].is_array(), "The field 'children' in an Or expression needs to be an array")
+      return std::make_unique<Or>(parseChildren(json));
+   }
+   if (expression_type == "N-Of") {  // nof.cpp:283-316
+      CHECK_SILO_QUERY(json.contains("children"), "The field 'children' is required in an N-Of expression")
+      CHECK_SILO_QUERY(json["children"].is_array(), "The field 'children' in an N-Of expression needs to be an array")
+      CHECK_SILO_QUERY(json.contains("numberOfMatchers"), "The field 'numberOfMatchers' is required in an N-Of expression")
+      CHECK_SILO_QUERY(
+         json["numberOfMatchers"].is_number_unsigned(), "The field 'numberOfMatchers' in an N-Of expression needs to be an unsigned integer"
+      )
+      CHECK_SILO_QUERY(json.contains("matchExactly"), "The field 'matchExactly' is required in an N-Of expression")
+      CHECK_SILO_QUERY(json["matchExactly"].is_boolean(), "The field 'matchExactly' in an N-Of expression needs to be a boolean")
+      const uint32_t number_of_matchers = json["numberOfMatchers"].as_uint32();
+      const bool match_exactly = json["matchExactly"].as_bool();
+      return std::make_unique<NOf>(parseChildren(json), static_cast<int>(number_of_matchers), match_exactly);
+   }
+   if (expression_type == "Not") {
+      CHECK_SILO_QUERY(json.contains("child"), "The field 'child' is required in a Not expression")
+      return std::make_unique<Negation>(parseExpression(json["child"]));
+   }
+   if (expression_type == "Maybe") {
+      CHECK_SILO_QUERY(json.contains("child"), "The field 'child' is required in a Maybe expression")
+      return std::make_unique<Maybe>(parseExpression(json["child"]));
+   }
+   if (expression_type == "Exact") {
+      CHECK_SILO_QUERY(json.contains("child"), "The field 'child' is required in a Exact expression")
+      return std::make_unique<Exact>(parseExpression(json["child"]));
+   }
+   if (expression_type == "NucleotideEquals") {  // nucleotide_symbol_equals.cpp:192-227
+      CHECK_SILO_QUERY(json.is_object() && json.contains("position"), "The field 'position' is required in a NucleotideEquals expression")
+      CHECK_SILO_QUERY(
+         json["position"].is_number_unsigned() && json["position"].as_uint32() > 0,
+         "The field 'position' in a NucleotideEquals expression needs to be an unsigned integer greater than 0"
+      )
+      CHECK_SILO_QUERY(json.contains("symbol"), "The field 'symbol' is required in a NucleotideEquals expression")
+      CHECK_SILO_QUERY(json["symbol"].is_string(), "The field 'symbol' in a NucleotideEquals expression needs to be a string")
+      std::optional<std::string> nuc_sequence_name;
+      if (json.contains("sequenceName")) {
+         nuc_sequence_name = json["sequenceName"].as_string();
+      }
+      const uint32_t position = json["position"].as_uint32() - 1;
+      const std::string& nucleotide_symbol = json["symbol"].as_string();
+      CHECK_SILO_QUERY(nucleotide_symbol.size() == 1, "The string field 'symbol' must be exactly one character long")
+      const std::optional<Nucleotide::Symbol> nuc_value = Nucleotide::charToSymbol(nucleotide_symbol.at(0));
+      CHECK_SILO_QUERY(
+         nuc_value.has_value() || nucleotide_symbol.at(0) == '.',
+         "The string field 'symbol' must be either a valid nucleotide symbol or the '.' symbol."
+      )
+      return std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name, position, nuc_value);
+   }
+   if (expression_type == "AminoAcidEquals") {  // aa_symbol_equals.cpp:95-125
+      CHECK_SILO_QUERY(
+         json.contains("sequenceName") && json["sequenceName"].is_string(), "AminoAcidEquals expression requires the string field sequenceName"
+      )
+      CHECK_SILO_QUERY(json.is_object() && json.contains("position"), "The field 'position' is required in a AminoAcidEquals expression")
+      CHECK_SILO_QUERY(
+         json["position"].is_number_unsigned() && json["position"].as_uint32() > 0,
+         "The field 'position' in a AminoAcidEquals expression needs to be an unsigned integer greater than 0"
+      )
+      CHECK_SILO_QUERY(
+         json.contains("symbol") && json["symbol"].is_string(), "The string field 'symbol' is required in a AminoAcidEquals expression"
+      )
+      const std::string aa_sequence_name = json["sequenceName"].as_string();
+      const uint32_t position = json["position"].as_uint32() - 1;
+      const std::string aa_char = json["symbol"].as_string();
+      CHECK_SILO_QUERY(aa_char.size() == 1, "The string field 'symbol' must be exactly one character long")
+      const std::optional<AminoAcid::Symbol> aa_value = AminoAcid::charToSymbol(aa_char.at(0));
+      CHECK_SILO_QUERY(
+         aa_value.has_value() || aa_char.at(0) == '.', "The string field 'symbol' must be either a valid amino acid or the '.' symbol."
+      )
+      return std::make_unique<AASymbolEquals>(aa_sequence_name, position, aa_value);
+   }
+   if (expression_type == "HasNucleotideMutation") {  // has_mutation.cpp:81-96
+      CHECK_SILO_QUERY(json.contains("position"), "The field 'position' is required in a HasNucleotideMutation expression")
+      CHECK_SILO_QUERY(
+         json["position"].is_number_unsigned(), "The field 'position' in a HasNucleotideMutation expression needs to be an unsigned integer"
+      )
+      std::optional<std::string> nuc_sequence_name;
+      if (json.contains("sequenceName")) {
+         nuc_sequence_name = json["sequenceName"].as_string();
+      }
+      const uint32_t position = json["position"].as_uint32() - 1;  // position 0 wraps, then .at() throws -> 500
+      return std::make_unique<HasMutation>(nuc_sequence_name, position);
+   }
+   if (expression_type == "HasAminoAcidMutation") {  // has_aa_mutation.cpp:66-84
+      CHECK_SILO_QUERY(json.contains("position"), "The field 'position' is required in a HasAminoAcidMutation expression")
+      CHECK_SILO_QUERY(
+         json["position"].is_number_unsigned(), "The field 'position' in a HasAminoAcidMutation expression needs to be an unsigned integer"
+      )
+      CHECK_SILO_QUERY(
+         json.contains("sequenceName") && json["sequenceName"].is_string(),
+         "HasAminoAcidMutation expression requires the string field sequenceName"
+      )
+      const std::string aa_sequence_name = json["sequenceName"].as_string();
+      const uint32_t position = json["position"].as_uint32() - 1;
+      return std::make_unique<HasAAMutation>(aa_sequence_name, position);
+   }
+   if (expression_type == "PangoLineage") {  // pango_lineage_filter.cpp:62-92
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in a PangoLineage expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in a PangoLineage expression needs to be a string")
+      CHECK_SILO_QUERY(json.contains("value"), "The field 'value' is required in a PangoLineage expression")
+      CHECK_SILO_QUERY(json["value"].is_string(), "The field 'value' in a PangoLineage expression needs to be a string")
+      CHECK_SILO_QUERY(json.contains("includeSublineages"), "The field 'includeSublineages' is required in a PangoLineage expression")
+      CHECK_SILO_QUERY(
+         json["includeSublineages"].is_boolean(), "The field 'includeSublineages' in a PangoLineage expression needs to be a boolean"
+      )
+      return std::make_unique<PangoLineageFilter>(json["column"].as_string(), json["value"].as_string(), json["includeSublineages"].as_bool());
+   }
+   static const char* const metadata_filters[] = {
+      "DateBetween", "StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "InsertionContains", "AminoAcidInsertionContains",
+   };
+   for (const char* name : metadata_filters) {
+      if (expression_type == name) {
+         // host-side metadata predicates are outside the device hot path
+         throw std::runtime_error("filter type '" + expression_type + "' is not supported by the MI355X filter engine");
+      }
+   }
+   throw QueryParseException("Unknown object filter type '" + expression_type + "'");
+}
+
+}  // namespace silo::query_engine::filter_expressions

@@ -1,0 +1,464 @@
+// operators.cpp — physical operators and their lowering to the fused bit-program (K3).
+// Reference: src/silo/query_engine/operators/*.cpp, src/silo/query_engine/operator_result.cpp.
+#include <algorithm>
+#include <bit>
+#include <mutex>
+
+#include "query_engine.h"
+
+namespace silo::query_engine {
+
+// ---- OperatorResult ----------------------------------------------------------------------------
+struct OperatorResult::State {
+   RowSpace rows;
+   std::unique_ptr<operators::Operator> root;
+   std::mutex mutex;
+   DeviceBuffer bitset;
+   std::optional<uint32_t> count;
+   const uint64_t* borrowed = nullptr;  // IndexScan roots need no kernel for the bitset
+};
+
+OperatorResult::OperatorResult(RowSpace rows, std::unique_ptr<operators::Operator> root) : state(std::make_shared<State>()) {
+   state->rows = rows;
+   state->root = std::move(root);
+}
+
+const RowSpace& OperatorResult::rows() const {
+   return state->rows;
+}
+
+namespace {
+
+uint32_t readCount(const DatabasePartition& partition, const DeviceBuffer& counter) {
+   uint64_t value = 0;
+   checkGpu(silo_gpu_memcpy_d2h(&value, counter.get(), sizeof(value), nullptr), "silo_gpu_memcpy_d2h");
+   (void)partition;
+   return static_cast<uint32_t>(value);
+}
+
+}  // namespace
+
+void OperatorResult::materialize() const {
+   const std::lock_guard<std::mutex> lock(state->mutex);
+   if ((state->bitset || state->borrowed != nullptr) && state->count.has_value()) {
+      return;
+   }
+   const DatabasePartition& partition = *state->rows.partition;
+   const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
+   DeviceBuffer counter = partition.pool.acquire(sizeof(uint64_t));
+   checkGpu(silo_gpu_memset_async(counter.get(), 0, sizeof(uint64_t), nullptr), "silo_gpu_memset_async");
+   const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
+   if (scan != nullptr && !scan->sparse) {
+      state->borrowed = scan->bitmap;  // index_scan.cpp:28-30: borrow, no copy
+      checkGpu(silo_gpu_popcount(partition.store, scan->bitmap, counter.as<uint64_t>(), nullptr), "silo_gpu_popcount");
+   } else {
+      DeviceBuffer out = partition.pool.acquire(row_bytes);
+      ProgramBuilder builder(state->rows);
+      const uint32_t slot = state->root->lower(builder);
+      builder.run(slot, out.as<uint64_t>(), counter.as<uint64_t>(), nullptr);
+      state->bitset = std::move(out);
+   }
+   state->count = readCount(partition, counter);
+}
+
+uint32_t OperatorResult::cardinality() const {
+   {
+      const std::lock_guard<std::mutex> lock(state->mutex);
+      if (state->count.has_value()) {
+         return *state->count;
+      }
+      // count-only launch: no bitset is written (Aggregated never needs it)
+      const DatabasePartition& partition = *state->rows.partition;
+      if (state->root->type() == operators::EMPTY) {
+         state->count = 0;
+         return 0;
+      }
+      if (state->root->type() == operators::FULL) {
+         state->count = state->rows.row_count;
+         return *state->count;
+      }
+      DeviceBuffer counter = partition.pool.acquire(sizeof(uint64_t));
+      checkGpu(silo_gpu_memset_async(counter.get(), 0, sizeof(uint64_t), nullptr), "silo_gpu_memset_async");
+      ProgramBuilder builder(state->rows);
+      const uint32_t slot = state->root->lower(builder);
+      builder.run(slot, nullptr, counter.as<uint64_t>(), nullptr);
+      state->count = readCount(partition, counter);
+      return *state->count;
+   }
+}
+
+const uint64_t* OperatorResult::bitset() const {
+   materialize();
+   return state->borrowed != nullptr ? state->borrowed : state->bitset.as<uint64_t>();
+}
+
+bool OperatorResult::isFull() const {
+   return cardinality() == state->rows.row_count;
+}
+
+// ---- ProgramBuilder ----------------------------------------------------------------------------
+uint32_t ProgramBuilder::allocRun(uint32_t count) {
+   for (uint32_t first = 0; first + count <= SILO_GPU_MAX_SLOTS; ++first) {
+      const uint32_t mask = (count == 32 ? 0xFFFFFFFFu : ((1u << count) - 1u)) << first;
+      if ((used_slots & mask) == 0) {
+         used_slots |= mask;
+         high_water = std::max(high_water, first + count);
+         return first;
+      }
+   }
+   throw QueryCompilationException("Compilation Error: filter expression needs more than " + std::to_string(SILO_GPU_MAX_SLOTS) + " device slots");
+}
+
+uint32_t ProgramBuilder::allocSlot() {
+   return allocRun(1);
+}
+
+void ProgramBuilder::freeRun(uint32_t slot, uint32_t count) {
+   const uint32_t mask = (count == 32 ? 0xFFFFFFFFu : ((1u << count) - 1u)) << slot;
+   used_slots &= ~mask;
+}
+
+void ProgramBuilder::freeSlot(uint32_t slot) {
+   freeRun(slot, 1);
+}
+
+void ProgramBuilder::emit(uint32_t op, uint32_t dst, uint32_t a, uint32_t b, uint32_t imm) {
+   code.push_back(op | (dst << 8) | (a << 16) | (b << 24));
+   code.push_back(imm);
+}
+
+uint32_t ProgramBuilder::leaf(const uint64_t* device_bitset) {
+   const auto found = std::find(leaves.begin(), leaves.end(), device_bitset);
+   if (found != leaves.end()) {
+      return static_cast<uint32_t>(found - leaves.begin());
+   }
+   leaves.push_back(device_bitset);
+   return static_cast<uint32_t>(leaves.size() - 1);
+}
+
+uint32_t ProgramBuilder::sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol) {
+   const DatabasePartition& partition = *rows.partition;
+   DeviceBuffer buffer = partition.pool.acquire(static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t));
+   checkGpu(
+      silo_gpu_store_sparse_plane(partition.store, seqstore_id, position, symbol, buffer.as<uint64_t>(), nullptr),
+      "silo_gpu_store_sparse_plane"
+   );
+   const uint32_t index = leaf(buffer.as<uint64_t>());
+   temporaries.push_back(std::move(buffer));
+   return index;
+}
+
+uint32_t ProgramBuilder::lowerChild(const operators::Operator& child) {
+   const operators::Cost cost = child.cost();
+   const size_t instructions_after = code.size() / 2 + cost.instructions + 8;
+   const size_t leaves_after = leaves.size() + cost.leaves + 1;
+   const bool fits = instructions_after <= SILO_GPU_MAX_INSTRUCTIONS && leaves_after <= SILO_GPU_MAX_LEAVES;
+   const bool child_alone_fits = cost.instructions + 8 <= SILO_GPU_MAX_INSTRUCTIONS && cost.leaves + 1 <= SILO_GPU_MAX_LEAVES;
+   if (fits || !child_alone_fits) {
+      // too big even alone: descend — its own children are materialised one level down
+      return child.lower(*this);
+   }
+   OperatorResult result = child.evaluate();
+   const uint32_t slot = allocSlot();
+   emit(SILO_GPU_OP_LOAD, slot, 0, 0, leaf(result.bitset()));
+   materialized_children.push_back(std::move(result));
+   return slot;
+}
+
+void ProgramBuilder::run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream) {
+   if (result_slot != 0) {
+      emit(SILO_GPU_OP_MOV, 0, result_slot);
+      high_water = std::max(high_water, 1u);
+   }
+   if (code.size() / 2 > SILO_GPU_MAX_INSTRUCTIONS || leaves.size() > SILO_GPU_MAX_LEAVES) {
+      throw QueryCompilationException("Compilation Error: filter expression does not fit one device program");
+   }
+   silo_gpu_bitprog program{};
+   program.n_instructions = static_cast<uint32_t>(code.size() / 2);
+   program.code = code.data();
+   program.n_leaves = static_cast<uint32_t>(leaves.size());
+   program.leaves = leaves.data();
+   program.n_slots = std::max(high_water, 1u);
+   checkGpu(silo_gpu_filter_eval(rows.partition->store, &program, out_bitset, out_count, stream), "silo_gpu_filter_eval");
+   if (!temporaries.empty() || !materialized_children.empty()) {
+      // temporaries go back to the pool when the builder dies: make sure the kernel is done with them
+      checkGpu(silo_gpu_stream_synchronize(stream), "silo_gpu_stream_synchronize");
+   }
+}
+
+namespace operators {
+
+OperatorResult Operator::evaluate() const {
+   return OperatorResult(rows, copy());
+}
+
+namespace {
+
+OperatorVector copyAll(const OperatorVector& source) {
+   OperatorVector out;
+   out.reserve(source.size());
+   for (const auto& child : source) {
+      out.push_back(child->copy());
+   }
+   return out;
+}
+
+Cost sumCost(const OperatorVector& a, const OperatorVector* b = nullptr) {
+   Cost total;
+   for (const auto& child : a) {
+      const Cost c = child->cost();
+      total.instructions += c.instructions + 1;
+      total.leaves += c.leaves;
+   }
+   if (b != nullptr) {
+      for (const auto& child : *b) {
+         const Cost c = child->cost();
+         total.instructions += c.instructions + 2;
+         total.leaves += c.leaves;
+      }
+   }
+   return total;
+}
+
+}  // namespace
+
+// ---- Empty / Full (empty.cpp, full.cpp:24-28) ---------------------------------------------------
+std::unique_ptr<Operator> Empty::copy() const {
+   return std::make_unique<Empty>(rows);
+}
+std::unique_ptr<Operator> Empty::negate() const {
+   return std::make_unique<Full>(rows);
+}
+uint32_t Empty::lower(ProgramBuilder& builder) const {
+   const uint32_t slot = builder.allocSlot();
+   builder.emit(SILO_GPU_OP_ZERO, slot);
+   return slot;
+}
+
+std::unique_ptr<Operator> Full::copy() const {
+   return std::make_unique<Full>(rows);
+}
+std::unique_ptr<Operator> Full::negate() const {
+   return std::make_unique<Empty>(rows);
+}
+uint32_t Full::lower(ProgramBuilder& builder) const {
+   const uint32_t slot = builder.allocSlot();
+   builder.emit(SILO_GPU_OP_ONES, slot);
+   return slot;
+}
+
+// ---- IndexScan (index_scan.cpp:28-30) -----------------------------------------------------------
+std::unique_ptr<Operator> IndexScan::copy() const {
+   if (sparse) {
+      return std::make_unique<IndexScan>(seqstore_id, position, symbol, rows);
+   }
+   return std::make_unique<IndexScan>(bitmap, rows);
+}
+std::unique_ptr<Operator> IndexScan::negate() const {
+   return std::make_unique<Complement>(copy(), rows);
+}
+uint32_t IndexScan::lower(ProgramBuilder& builder) const {
+   const uint32_t slot = builder.allocSlot();
+   const uint32_t index = sparse ? builder.sparseLeaf(seqstore_id, position, symbol) : builder.leaf(bitmap);
+   builder.emit(SILO_GPU_OP_LOAD, slot, 0, 0, index);
+   return slot;
+}
+
+// ---- BitmapSelection (bitmap_selection.cpp:33-71) -----------------------------------------------
+std::unique_ptr<Operator> BitmapSelection::copy() const {
+   return std::make_unique<BitmapSelection>(missing_plane, rows, comparator, value);
+}
+std::unique_ptr<Operator> BitmapSelection::negate() const {
+   return std::make_unique<BitmapSelection>(missing_plane, rows, comparator == CONTAINS ? NOT_CONTAINS : CONTAINS, value);
+}
+uint32_t BitmapSelection::lower(ProgramBuilder& builder) const {
+   const uint32_t slot = builder.allocSlot();
+   builder.emit(SILO_GPU_OP_LOAD, slot, 0, 0, builder.leaf(missing_plane));
+   if (comparator == NOT_CONTAINS) {
+      builder.emit(SILO_GPU_OP_NOT, slot, slot);
+   }
+   return slot;
+}
+
+// ---- Complement (complement.cpp) ----------------------------------------------------------------
+std::unique_ptr<Complement> Complement::fromDeMorgan(OperatorVector disjunction, RowSpace rows) {  // complement.cpp:22-40
+   OperatorVector non_negated_child_operators;
+   OperatorVector negated_child_operators;
+   for (auto& disjunction_child : disjunction) {
+      if (disjunction_child->type() == COMPLEMENT) {
+         negated_child_operators.emplace_back(disjunction_child->negate());
+      } else {
+         non_negated_child_operators.push_back(std::move(disjunction_child));
+      }
+   }
+   auto intersection = std::make_unique<Intersection>(std::move(negated_child_operators), std::move(non_negated_child_operators), rows);
+   return std::make_unique<Complement>(std::move(intersection), rows);
+}
+std::unique_ptr<Operator> Complement::copy() const {
+   return std::make_unique<Complement>(child->copy(), rows);
+}
+std::unique_ptr<Operator> Complement::negate() const {
+   return child->copy();
+}
+uint32_t Complement::lower(ProgramBuilder& builder) const {  // flip(0,row_count): complement.cpp:50-54
+   const uint32_t slot = builder.lowerChild(*child);
+   builder.emit(SILO_GPU_OP_NOT, slot, slot);
+   return slot;
+}
+Cost Complement::cost() const {
+   Cost c = child->cost();
+   c.instructions += 1;
+   return c;
+}
+
+// ---- Intersection (intersection.cpp) ------------------------------------------------------------
+Intersection::Intersection(OperatorVector&& children_, OperatorVector&& negated_children_, RowSpace rows)
+    : Operator(rows), children(std::move(children_)), negated_children(std::move(negated_children_)) {
+   if (children.empty()) {
+      throw QueryCompilationException(
+         "Compilation bug: Intersection without non-negated children is not allowed. Should be compiled as a union."
+      );
+   }
+   if (children.size() + negated_children.size() < 2) {
+      throw QueryCompilationException("Compilation bug: Intersection needs at least two children.");
+   }
+}
+std::string Intersection::toString() const {
+   std::string res = "(" + children[0]->toString();
+   for (size_t i = 1; i < children.size(); ++i) {
+      res += " & " + children[i]->toString();
+   }
+   for (const auto& child : negated_children) {
+      res += " &! " + child->toString();
+   }
+   return res + ")";
+}
+std::unique_ptr<Operator> Intersection::copy() const {
+   return std::make_unique<Intersection>(copyAll(children), copyAll(negated_children), rows);
+}
+std::unique_ptr<Operator> Intersection::negate() const {
+   return std::make_unique<Complement>(copy(), rows);
+}
+uint32_t Intersection::lower(ProgramBuilder& builder) const {
+   // The reference orders children by cardinality to keep roaring intermediates small
+   // (intersection.cpp:94-108); a dense word-parallel AND has no such sensitivity.
+   const uint32_t acc = builder.lowerChild(*children[0]);
+   for (size_t i = 1; i < children.size(); ++i) {
+      const uint32_t tmp = builder.lowerChild(*children[i]);
+      builder.emit(SILO_GPU_OP_AND, acc, acc, tmp);
+      builder.freeSlot(tmp);
+   }
+   for (const auto& child : negated_children) {
+      const uint32_t tmp = builder.lowerChild(*child);
+      builder.emit(SILO_GPU_OP_ANDNOT, acc, acc, tmp);
+      builder.freeSlot(tmp);
+   }
+   return acc;
+}
+Cost Intersection::cost() const {
+   return sumCost(children, &negated_children);
+}
+
+// ---- Union (union.cpp) --------------------------------------------------------------------------
+std::string Union::toString() const {
+   if (children.empty()) {
+      return "()";
+   }
+   std::string res = "(" + children[0]->toString();
+   for (size_t i = 1; i < children.size(); ++i) {
+      res += " | " + children[i]->toString();
+   }
+   return res + ")";
+}
+std::unique_ptr<Operator> Union::copy() const {
+   return std::make_unique<Union>(copyAll(children), rows);
+}
+std::unique_ptr<Operator> Union::negate() const {
+   return std::make_unique<Complement>(copy(), rows);
+}
+uint32_t Union::lower(ProgramBuilder& builder) const {
+   if (children.empty()) {  // union.test.cpp:28-34: the union of nothing is empty
+      const uint32_t slot = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_ZERO, slot);
+      return slot;
+   }
+   const uint32_t acc = builder.lowerChild(*children[0]);
+   for (size_t i = 1; i < children.size(); ++i) {
+      const uint32_t tmp = builder.lowerChild(*children[i]);
+      builder.emit(SILO_GPU_OP_OR, acc, acc, tmp);
+      builder.freeSlot(tmp);
+   }
+   return acc;
+}
+Cost Union::cost() const {
+   Cost c = sumCost(children);
+   c.instructions += 1;
+   return c;
+}
+
+// ---- Threshold (threshold.cpp) ------------------------------------------------------------------
+Threshold::Threshold(OperatorVector&& non_negated_children_, OperatorVector&& negated_children_, uint32_t number_of_matchers, bool match_exactly, RowSpace rows)
+    : Operator(rows),
+      non_negated_children(std::move(non_negated_children_)),
+      negated_children(std::move(negated_children_)),
+      number_of_matchers(number_of_matchers),
+      match_exactly(match_exactly) {
+   if (number_of_matchers >= non_negated_children.size() + negated_children.size()) {  // threshold.cpp:28-33
+      throw QueryCompilationException(
+         "Compilation Error: number_of_matchers must be less than the number of children of a threshold expression"
+      );
+   }
+   if (number_of_matchers == 0) {
+      throw QueryCompilationException("Compilation Error: number_of_matchers must be greater than zero");
+   }
+}
+std::string Threshold::toString() const {
+   std::string res = match_exactly ? "=" : ">=";
+   for (const auto& child : non_negated_children) {
+      res += ", " + child->toString();
+   }
+   for (const auto& child : negated_children) {
+      res += ", ! " + child->toString();
+   }
+   return res + ")";
+}
+std::unique_ptr<Operator> Threshold::copy() const {
+   return std::make_unique<Threshold>(copyAll(non_negated_children), copyAll(negated_children), number_of_matchers, match_exactly, rows);
+}
+std::unique_ptr<Operator> Threshold::negate() const {
+   return std::make_unique<Complement>(copy(), rows);
+}
+uint32_t Threshold::lower(ProgramBuilder& builder) const {
+   // The reference keeps a DP table of n (or n+1) bitmaps, table[j] = rows matched by > j children
+   // so far (threshold.cpp:64-138).  Word-parallel restatement: a bit-sliced per-row counter of
+   // ceil(log2(k+1)) slots, one ripple-carry add per child, one comparison with n at the end.
+   const uint32_t k = static_cast<uint32_t>(non_negated_children.size() + negated_children.size());
+   const uint32_t bits = static_cast<uint32_t>(std::bit_width(k));
+   const uint32_t counter = builder.allocRun(bits);
+   for (uint32_t bit = 0; bit < bits; ++bit) {
+      builder.emit(SILO_GPU_OP_ZERO, counter + bit);
+   }
+   for (const auto& child : non_negated_children) {
+      const uint32_t tmp = builder.lowerChild(*child);
+      builder.emit(SILO_GPU_OP_CNT_ADD, counter, tmp, bits);
+      builder.freeSlot(tmp);
+   }
+   for (const auto& child : negated_children) {
+      const uint32_t tmp = builder.lowerChild(*child);
+      builder.emit(SILO_GPU_OP_NOT, tmp, tmp);
+      builder.emit(SILO_GPU_OP_CNT_ADD, counter, tmp, bits);
+      builder.freeSlot(tmp);
+   }
+   const uint32_t result = builder.allocSlot();
+   builder.emit(match_exactly ? SILO_GPU_OP_CNT_EQ : SILO_GPU_OP_CNT_GE, result, counter, bits, number_of_matchers);
+   builder.freeRun(counter, bits);
+   return result;
+}
+Cost Threshold::cost() const {
+   Cost c = sumCost(non_negated_children, &negated_children);
+   c.instructions += 8;
+   return c;
+}
+
+}  // namespace operators
+}  // namespace silo::query_engine

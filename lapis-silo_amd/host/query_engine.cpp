@@ -1,0 +1,93 @@
+// query_engine.cpp — Query, QueryEngine::executeQuery and the result JSON.
+// Reference: src/silo/query_engine/{query,query_engine,query_result}.cpp.
+#include "query_engine.h"
+
+#include <chrono>
+
+namespace silo::query_engine {
+
+Query::Query(const std::string& query_string) {  // query.cpp:13-28
+   json::Value json;
+   try {
+      json = json::parse(query_string);
+   } catch (const json::ParseError& ex) {
+      throw QueryParseException("The query was not a valid JSON: " + std::string(ex.what()));
+   }
+   if (!json.contains("filterExpression") || !json["filterExpression"].is_object() || !json.contains("action") ||
+       !json["action"].is_object()) {
+      throw QueryParseException("Query json must contain filterExpression and action.");
+   }
+   try {
+      filter = filter_expressions::parseExpression(json["filterExpression"]);
+      action = actions::parseAction(json["action"]);
+   } catch (const std::out_of_range& ex) {
+      // nlohmann raises json::exception for wrong-typed accesses, mapped to 400 (query.cpp:24-27)
+      throw QueryParseException("The query was not a valid JSON: " + std::string(ex.what()));
+   }
+}
+
+namespace {
+
+class BlockTimer {  // include/silo/common/block_timer.h:5-23
+  public:
+   explicit BlockTimer(int64_t& output) : output(output), start(std::chrono::steady_clock::now()) {}
+   ~BlockTimer() {
+      output = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - start).count();
+   }
+
+  private:
+   int64_t& output;
+   std::chrono::steady_clock::time_point start;
+};
+
+}  // namespace
+
+QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  // query_engine.cpp:30-68
+   const Query query(query_string);
+
+   std::vector<OperatorResult> partition_filters(database.partitions.size());
+   int64_t filter_time = 0;
+   {
+      const BlockTimer timer(filter_time);
+      for (size_t partition_index = 0; partition_index != database.partitions.size(); partition_index++) {
+         std::unique_ptr<operators::Operator> part_filter = query.filter->compile(
+            database, database.partitions[partition_index], filter_expressions::Expression::AmbiguityMode::NONE
+         );
+         // evaluate() is lazy: the fused kernel is launched by the action, in the mode it needs
+         // (count only for Aggregated, bitset + count for Mutations).
+         partition_filters[partition_index] = part_filter->evaluate();
+      }
+   }
+   QueryResult query_result;
+   int64_t action_time = 0;
+   {
+      const BlockTimer timer(action_time);
+      query_result = query.action->executeAndOrder(database, std::move(partition_filters));
+   }
+   Database::lastTimings() = {filter_time, action_time};
+   return query_result;
+}
+
+json::Value toJson(const QueryResult& query_result) {  // query_result.cpp:10-25
+   json::Value rows = json::Value::array();
+   for (const auto& entry : query_result.query_result) {
+      json::Value row = json::Value::object();
+      for (const auto& [field, value] : entry.fields) {
+         if (!value.has_value()) {
+            row.set(field, json::Value());
+         } else if (std::holds_alternative<std::string>(*value)) {
+            row.set(field, json::Value(std::get<std::string>(*value)));
+         } else if (std::holds_alternative<int32_t>(*value)) {
+            row.set(field, json::Value(std::get<int32_t>(*value)));
+         } else {
+            row.set(field, json::Value(std::get<double>(*value)));
+         }
+      }
+      rows.push_back(std::move(row));
+   }
+   json::Value out = json::Value::object();
+   out.set("queryResult", std::move(rows));
+   return out;
+}
+
+}  // namespace silo::query_engine

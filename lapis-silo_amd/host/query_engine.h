@@ -1,0 +1,478 @@
+// query_engine.h — host-side mirror of silo::query_engine (same type and member names, same error
+// behaviour); the arithmetic behind Operator::evaluate and Action::execute runs in HIP kernels.
+//
+// Reference interfaces mirrored (file:line under the reference tree):
+//   QueryEngine::executeQuery            include/silo/query_engine/query_engine.h:13-23, src/.../query_engine.cpp:30-68
+//   Query                                src/silo/query_engine/query.cpp:13-28
+//   QueryResult / QueryResultEntry       include/silo/query_engine/query_result.h:14-20, src/.../query_result.cpp:10-25
+//   OperatorResult                       include/silo/query_engine/operator_result.h:8-31
+//   QueryParseException / CHECK_SILO_QUERY   include/silo/query_engine/query_parse_exception.h:6-16
+//   QueryCompilationException            include/silo/query_engine/query_compilation_exception.h
+//   operators::Operator + subclasses     include/silo/query_engine/operators/*.h
+//   filter_expressions::Expression + subclasses   include/silo/query_engine/filter_expressions/*.h
+//   actions::Action, Aggregated, Mutations<S>     include/silo/query_engine/actions/{action,aggregated,mutations}.h
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include "database.h"
+#include "json.h"
+
+namespace silo {
+
+class QueryParseException : public std::runtime_error {
+  public:
+   explicit QueryParseException(const std::string& error_message) : std::runtime_error(error_message) {}
+};
+
+class QueryCompilationException : public std::runtime_error {
+  public:
+   explicit QueryCompilationException(const std::string& error_message) : std::runtime_error(error_message) {}
+};
+
+#define CHECK_SILO_QUERY(condition, message)    \
+   if (!(condition)) {                          \
+      throw silo::QueryParseException(message); \
+   }
+
+namespace query_engine {
+
+struct QueryResultEntry {
+   std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> fields;
+};
+
+struct QueryResult {
+   std::vector<QueryResultEntry> query_result;
+};
+
+json::Value toJson(const QueryResult& query_result);  // {"queryResult": [...]}
+
+/// The rows an operator ranges over: the reference passes a bare `row_count`; here it also names
+/// the device shard that holds those rows.
+struct RowSpace {
+   uint32_t row_count = 0;
+   const DatabasePartition* partition = nullptr;
+};
+
+namespace operators {
+class Operator;
+}
+
+/// Result of Operator::evaluate.  The reference holds a (borrowed or owned) roaring bitmap; here the
+/// evaluation is deferred: cardinality() runs the fused filter kernel in count-only mode, bitset()
+/// materialises the row bitset in HBM (both at most once).
+class OperatorResult {
+  public:
+   OperatorResult() = default;
+   OperatorResult(RowSpace rows, std::unique_ptr<operators::Operator> root);
+
+   [[nodiscard]] uint32_t cardinality() const;
+   [[nodiscard]] const uint64_t* bitset() const;  // device pointer, Wp words
+   [[nodiscard]] bool isFull() const;              // cardinality() == row_count
+   [[nodiscard]] const RowSpace& rows() const;
+   /// Runs the kernel now, producing both the bitset and the count in one launch.
+   void materialize() const;
+
+  private:
+   struct State;
+   std::shared_ptr<State> state;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Lowering of an operator tree to the bit-program of include/silo_gpu.h (one fused kernel launch).
+// ---------------------------------------------------------------------------------------------
+class ProgramBuilder {
+  public:
+   explicit ProgramBuilder(RowSpace rows) : rows(rows) {}
+
+   uint32_t allocSlot();
+   uint32_t allocRun(uint32_t count);
+   void freeSlot(uint32_t slot);
+   void freeRun(uint32_t slot, uint32_t count);
+   void emit(uint32_t op, uint32_t dst, uint32_t a = 0, uint32_t b = 0, uint32_t imm = 0);
+   uint32_t leaf(const uint64_t* device_bitset);
+   /// Leaf for a symbol that is stored sparsely: scattered into a pooled temporary before launch.
+   uint32_t sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol);
+   /// Lowers `child` into this program, or — when it would not fit the instruction / leaf budget —
+   /// evaluates it with its own launch and loads the result as a leaf.
+   uint32_t lowerChild(const operators::Operator& child);
+
+   /// Launches the program (result expected in `result_slot`).
+   void run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream);
+
+   const RowSpace rows;
+
+  private:
+   std::vector<uint32_t> code;
+   std::vector<const uint64_t*> leaves;
+   std::vector<DeviceBuffer> temporaries;
+   std::vector<OperatorResult> materialized_children;
+   uint32_t used_slots = 0;  // bit mask
+   uint32_t high_water = 0;
+};
+
+namespace operators {
+
+enum Type {
+   EMPTY, FULL, INDEX_SCAN, INTERSECTION, COMPLEMENT, RANGE_SELECTION, SELECTION, BITMAP_SELECTION, THRESHOLD, UNION, BITMAP_PRODUCER
+};
+
+struct Cost {
+   uint32_t instructions = 0;
+   uint32_t leaves = 0;
+};
+
+class Operator {
+  public:
+   explicit Operator(RowSpace rows) : rows(rows) {}
+   virtual ~Operator() noexcept = default;
+
+   [[nodiscard]] virtual Type type() const = 0;
+   virtual OperatorResult evaluate() const;
+   virtual std::string toString() const = 0;
+   virtual std::unique_ptr<Operator> copy() const = 0;
+   virtual std::unique_ptr<Operator> negate() const = 0;
+
+   /// Emits this subtree into `builder`; returns the slot that holds its value (caller frees it).
+   virtual uint32_t lower(ProgramBuilder& builder) const = 0;
+   [[nodiscard]] virtual Cost cost() const = 0;
+
+   const RowSpace rows;
+};
+
+using OperatorVector = std::vector<std::unique_ptr<Operator>>;
+
+class Empty : public Operator {
+  public:
+   explicit Empty(RowSpace rows) : Operator(rows) {}
+   Type type() const override { return EMPTY; }
+   std::string toString() const override { return "Empty"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override { return {1, 0}; }
+};
+
+class Full : public Operator {
+  public:
+   explicit Full(RowSpace rows) : Operator(rows) {}
+   Type type() const override { return FULL; }
+   std::string toString() const override { return "Full"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override { return {1, 0}; }
+};
+
+/// index_scan.cpp: borrows a stored bitmap; here a dense plane pointer in HBM, or a sparse symbol.
+class IndexScan : public Operator {
+  public:
+   IndexScan(const uint64_t* bitmap, RowSpace rows) : Operator(rows), bitmap(bitmap) {}
+   IndexScan(uint32_t seqstore_id, uint32_t position, uint32_t symbol, RowSpace rows)
+       : Operator(rows), sparse(true), seqstore_id(seqstore_id), position(position), symbol(symbol) {}
+   Type type() const override { return INDEX_SCAN; }
+   std::string toString() const override { return "IndexScan"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override { return {1, 1}; }
+
+   const uint64_t* bitmap = nullptr;
+   bool sparse = false;
+   uint32_t seqstore_id = 0, position = 0, symbol = 0;
+};
+
+/// bitmap_selection.cpp probes the row-wise missing-symbol bitmaps; the dense store keeps the missing
+/// symbol as a column plane, so CONTAINS is that plane and NOT_CONTAINS its complement.
+class BitmapSelection : public Operator {
+  public:
+   enum Comparator { CONTAINS, NOT_CONTAINS };
+   BitmapSelection(const uint64_t* missing_plane, RowSpace rows, Comparator comparator, uint32_t value)
+       : Operator(rows), missing_plane(missing_plane), comparator(comparator), value(value) {}
+   Type type() const override { return BITMAP_SELECTION; }
+   std::string toString() const override { return "BitmapSelection"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override { return {2, 1}; }
+
+   const uint64_t* missing_plane;
+   Comparator comparator;
+   uint32_t value;  // the position, kept for parity with the reference's constructor
+};
+
+class Complement : public Operator {
+  public:
+   Complement(std::unique_ptr<Operator> child, RowSpace rows) : Operator(rows), child(std::move(child)) {}
+   static std::unique_ptr<Complement> fromDeMorgan(OperatorVector disjunction, RowSpace rows);
+   Type type() const override { return COMPLEMENT; }
+   std::string toString() const override { return "!" + child->toString(); }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override;
+
+   std::unique_ptr<Operator> child;
+};
+
+class Intersection : public Operator {
+  public:
+   Intersection(OperatorVector&& children, OperatorVector&& negated_children, RowSpace rows);
+   Type type() const override { return INTERSECTION; }
+   std::string toString() const override;
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override;
+
+   OperatorVector children;
+   OperatorVector negated_children;
+};
+
+class Union : public Operator {
+  public:
+   Union(OperatorVector&& children, RowSpace rows) : Operator(rows), children(std::move(children)) {}
+   Type type() const override { return UNION; }
+   std::string toString() const override;
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override;
+
+   OperatorVector children;
+};
+
+class Threshold : public Operator {
+  public:
+   Threshold(OperatorVector&& non_negated_children, OperatorVector&& negated_children, uint32_t number_of_matchers, bool match_exactly, RowSpace rows);
+   Type type() const override { return THRESHOLD; }
+   std::string toString() const override;
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override;
+
+   OperatorVector non_negated_children;
+   OperatorVector negated_children;
+   uint32_t number_of_matchers;
+   bool match_exactly;
+};
+
+}  // namespace operators
+
+namespace filter_expressions {
+
+struct Expression {
+   enum AmbiguityMode { UPPER_BOUND, LOWER_BOUND, NONE };
+   virtual ~Expression() = default;
+   virtual std::string toString(const Database& database) const = 0;
+   [[nodiscard]] virtual std::unique_ptr<operators::Operator> compile(
+      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+   ) const = 0;
+};
+
+Expression::AmbiguityMode invertMode(Expression::AmbiguityMode mode);
+
+/// expression.cpp:49-102
+std::unique_ptr<Expression> parseExpression(const json::Value& json);
+
+using ExpressionVector = std::vector<std::unique_ptr<Expression>>;
+
+#define SILO_DECLARE_EXPRESSION_METHODS                                        \
+   std::string toString(const Database& database) const override;            \
+   [[nodiscard]] std::unique_ptr<operators::Operator> compile(                 \
+      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode \
+   ) const override;
+
+struct True : public Expression {
+   SILO_DECLARE_EXPRESSION_METHODS
+};
+struct False : public Expression {
+   SILO_DECLARE_EXPRESSION_METHODS
+};
+struct And : public Expression {
+   explicit And(ExpressionVector&& children) : children(std::move(children)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   ExpressionVector children;
+
+  private:
+   std::pair<operators::OperatorVector, operators::OperatorVector> compileChildren(
+      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+   ) const;
+};
+struct Or : public Expression {
+   explicit Or(ExpressionVector&& children) : children(std::move(children)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   ExpressionVector children;
+};
+struct Negation : public Expression {
+   explicit Negation(std::unique_ptr<Expression> child) : child(std::move(child)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::unique_ptr<Expression> child;
+};
+struct Maybe : public Expression {
+   explicit Maybe(std::unique_ptr<Expression> child) : child(std::move(child)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::unique_ptr<Expression> child;
+};
+struct Exact : public Expression {
+   explicit Exact(std::unique_ptr<Expression> child) : child(std::move(child)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::unique_ptr<Expression> child;
+};
+struct NOf : public Expression {
+   NOf(ExpressionVector&& children, int number_of_matchers, bool match_exactly)
+       : children(std::move(children)), number_of_matchers(number_of_matchers), match_exactly(match_exactly) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   ExpressionVector children;
+   int number_of_matchers;
+   bool match_exactly;
+
+  private:
+   std::tuple<operators::OperatorVector, operators::OperatorVector, int> mapChildExpressions(
+      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+   ) const;
+   std::unique_ptr<operators::Operator> rewriteNonExact(
+      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
+   ) const;
+};
+struct NucleotideSymbolEquals : public Expression {
+   NucleotideSymbolEquals(std::optional<std::string> nuc_sequence_name, uint32_t position, std::optional<Nucleotide::Symbol> value)
+       : nuc_sequence_name(std::move(nuc_sequence_name)), position(position), value(value) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::optional<std::string> nuc_sequence_name;
+   uint32_t position;
+   std::optional<Nucleotide::Symbol> value;
+};
+struct AASymbolEquals : public Expression {
+   AASymbolEquals(std::string aa_sequence_name, uint32_t position, std::optional<AminoAcid::Symbol> value)
+       : aa_sequence_name(std::move(aa_sequence_name)), position(position), value(value) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string aa_sequence_name;
+   uint32_t position;
+   std::optional<AminoAcid::Symbol> value;
+};
+struct HasMutation : public Expression {
+   HasMutation(std::optional<std::string> nuc_sequence_name, uint32_t position)
+       : nuc_sequence_name(std::move(nuc_sequence_name)), position(position) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::optional<std::string> nuc_sequence_name;
+   uint32_t position;
+};
+struct HasAAMutation : public Expression {
+   HasAAMutation(std::string aa_sequence_name, uint32_t position)
+       : aa_sequence_name(std::move(aa_sequence_name)), position(position) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string aa_sequence_name;
+   uint32_t position;
+};
+struct PangoLineageFilter : public Expression {
+   PangoLineageFilter(std::string column, std::string lineage, bool include_sublineages)
+       : column(std::move(column)), lineage(std::move(lineage)), include_sublineages(include_sublineages) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   std::string lineage;
+   bool include_sublineages;
+};
+
+}  // namespace filter_expressions
+
+namespace actions {
+
+struct OrderByField {
+   std::string name;
+   bool ascending;
+};
+
+class Action {
+  protected:
+   std::vector<OrderByField> order_by_fields;
+   std::optional<uint32_t> limit;
+   std::optional<uint32_t> offset;
+
+   void applySort(QueryResult& result) const;
+   void applyOffsetAndLimit(QueryResult& result) const;
+   virtual void validateOrderByFields(const Database& database) const = 0;
+   [[nodiscard]] virtual QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const = 0;
+
+  public:
+   virtual ~Action() = default;
+   void setOrdering(const std::vector<OrderByField>& order_by_fields, std::optional<uint32_t> limit, std::optional<uint32_t> offset);
+   [[nodiscard]] virtual QueryResult executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const;
+};
+
+/// action.cpp:144-187
+std::unique_ptr<Action> parseAction(const json::Value& json);
+
+class Aggregated : public Action {
+   std::vector<std::string> group_by_fields;
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   explicit Aggregated(std::vector<std::string> group_by_fields) : group_by_fields(std::move(group_by_fields)) {}
+};
+
+template <typename SymbolType>
+class Mutations : public Action {
+   std::vector<std::string> sequence_names;
+   double min_proportion;
+
+   const std::string MUTATION_FIELD_NAME = "mutation";
+   const std::string SEQUENCE_FIELD_NAME = "sequenceName";
+   const std::string PROPORTION_FIELD_NAME = "proportion";
+   const std::string COUNT_FIELD_NAME = "count";
+
+   struct PrefilteredBitmaps {
+      std::vector<std::pair<const OperatorResult&, const SequenceStorePartition<SymbolType>&>> bitmaps;
+      std::vector<std::pair<const OperatorResult&, const SequenceStorePartition<SymbolType>&>> full_bitmaps;
+   };
+
+   static std::map<std::string, PrefilteredBitmaps> preFilterBitmaps(const Database& database, std::vector<OperatorResult>& bitmap_filter);
+
+   /// counts[position][valid symbol], summed over partitions (and ranks): the K1 launches.
+   static std::vector<uint32_t> calculateMutationsPerPosition(
+      const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
+   );
+
+   void addMutationsToOutput(
+      const Database& database, const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store,
+      const PrefilteredBitmaps& bitmap_filter, std::vector<QueryResultEntry>& output
+   ) const;
+
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   Mutations(std::vector<std::string>&& sequence_names, double min_proportion)
+       : sequence_names(std::move(sequence_names)), min_proportion(min_proportion) {}
+};
+
+}  // namespace actions
+
+class Query {
+  public:
+   std::unique_ptr<filter_expressions::Expression> filter;
+   std::unique_ptr<actions::Action> action;
+   explicit Query(const std::string& query_string);
+};
+
+class QueryEngine {
+  private:
+   const Database& database;
+
+  public:
+   explicit QueryEngine(const Database& database) : database(database) {}
+   virtual ~QueryEngine() = default;
+   [[nodiscard]] virtual QueryResult executeQuery(const std::string& query) const;
+};
+
+}  // namespace query_engine
+}  // namespace silo

@@ -77,8 +77,9 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_store_create", "silo_gpu_store_destroy", "silo_gpu_store_sequence_count",
     "silo_gpu_store_row_words", "silo_gpu_store_device_bytes", "silo_gpu_store_append_sequences",
     "silo_gpu_store_finalize", "silo_gpu_store_generate_synthetic", "silo_gpu_bitset_alloc",
-    "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_free",
-    "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_stream_synchronize", "silo_gpu_store_plane",
+    "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
+    "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
+    "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_store_plane",
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",

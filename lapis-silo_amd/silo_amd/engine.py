@@ -1,0 +1,211 @@
+"""ctypes binding of include/silo_engine.h — the QueryEngine-shaped C++ host (lib/libsilo_engine.so).
+
+Python here only marshals arguments; parsing, compilation of the filter tree, kernel launches and the
+result post-processing all happen in the C++ host.  Raises if the native library is missing.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+from . import binding
+
+_LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
+
+EXPORTED_SYMBOLS = [
+    "silo_engine_create", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
+    "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
+    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_execute_query", "silo_engine_free_string",
+    "silo_engine_last_timings", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_last_error",
+]
+
+ALL_REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    binding.load_library()  # libsilo_gpu.so first (same directory, $ORIGIN rpath)
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: run __graft_entry__.build() first; there is no CPU fallback")
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp = ctypes.c_void_p
+    lib.silo_engine_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.silo_engine_destroy.argtypes = [vp]
+    lib.silo_engine_destroy.restype = None
+    lib.silo_engine_add_partition.argtypes = [vp, ctypes.c_uint32]
+    lib.silo_engine_append_sequences.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.silo_engine_generate_synthetic.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(binding.SynthDesc)]
+    lib.silo_engine_set_lineage_column.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
+    lib.silo_engine_set_lineage_column_ids.argtypes = [
+        vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, vp, ctypes.c_uint32]
+    lib.silo_engine_finalize.argtypes = [vp]
+    lib.silo_engine_set_sharding.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ALL_REDUCE_FN, vp]
+    lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
+    lib.silo_engine_free_string.argtypes = [vp]
+    lib.silo_engine_free_string.restype = None
+    lib.silo_engine_last_timings.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.silo_engine_last_timings.restype = None
+    lib.silo_engine_partition_store.argtypes = [vp, ctypes.c_int]
+    lib.silo_engine_partition_store.restype = vp
+    lib.silo_engine_seqstore_id.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    lib.silo_engine_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+class SiloEngineError(RuntimeError):
+    pass
+
+
+class QueryError(RuntimeError):
+    """Non-200 answer of execute_query: .status is 400 / 500, .document the error JSON."""
+
+    def __init__(self, status, document):
+        super().__init__(f"{status}: {document}")
+        self.status = status
+        self.document = document
+
+
+def _check(rc):
+    if rc < 0:
+        raise SiloEngineError(load_library().silo_engine_last_error().decode())
+    return rc
+
+
+class StoreView:
+    """Borrowed view of a partition's silo_gpu_store for direct kernel calls (bench roofline leg)."""
+
+    def __init__(self, handle):
+        self.lib = binding.load_library()
+        self.handle = ctypes.c_void_p(handle)
+        self.row_words = self.lib.silo_gpu_store_row_words(self.handle)
+        self.sequence_count = self.lib.silo_gpu_store_sequence_count(self.handle)
+        self.device_bytes = self.lib.silo_gpu_store_device_bytes(self.handle)
+
+
+class Engine:
+    def __init__(self, reference_genomes, alias=None, default_nucleotide_sequence=None, device=0):
+        """reference_genomes / alias: dicts (or JSON strings) in the reference's file formats."""
+        self.lib = load_library()
+        genomes_text = reference_genomes if isinstance(reference_genomes, str) else json.dumps(reference_genomes)
+        alias_text = None if alias is None else (alias if isinstance(alias, str) else json.dumps(alias))
+        handle = ctypes.c_void_p()
+        _check(self.lib.silo_engine_create(
+            genomes_text.encode(), None if alias_text is None else alias_text.encode(),
+            None if default_nucleotide_sequence is None else default_nucleotide_sequence.encode(), device, ctypes.byref(handle)))
+        self.handle = handle
+        self._callbacks = []
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.silo_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add_partition(self, sequence_count):
+        return _check(self.lib.silo_engine_add_partition(self.handle, sequence_count))
+
+    def append_sequences(self, partition, name, is_aa, first_sequence, sequences):
+        """sequences: list of str / None (missing genome)."""
+        n = len(sequences)
+        if n == 0:
+            return
+        length = next((len(s) for s in sequences if s is not None), 0)
+        chars = np.zeros((n, max(length, 1)), dtype=np.uint8)
+        is_null = np.zeros(n, dtype=np.uint8)
+        for i, seq in enumerate(sequences):
+            if seq is None:
+                is_null[i] = 1
+            else:
+                if len(seq) != length:
+                    raise ValueError("sequences of one store must have equal length")
+                chars[i, :length] = np.frombuffer(seq.encode("latin-1"), dtype=np.uint8)
+        _check(self.lib.silo_engine_append_sequences(
+            self.handle, partition, name.encode(), int(is_aa), first_sequence, n, chars.ctypes.data_as(ctypes.c_void_p),
+            is_null.ctypes.data_as(ctypes.c_void_p)))
+
+    def generate_synthetic(self, partition, name, is_aa, model):
+        arrays = [
+            np.ascontiguousarray(model.lineage_of_sequence, dtype=np.uint16), np.ascontiguousarray(model.lead_gap, dtype=np.uint32),
+            np.ascontiguousarray(model.trail_gap, dtype=np.uint32), np.ascontiguousarray(model.missing_start, dtype=np.uint32),
+            np.ascontiguousarray(model.missing_len, dtype=np.uint32), np.ascontiguousarray(model.lineage_symbol, dtype=np.uint8),
+        ]
+        desc = binding.SynthDesc(
+            model.seed, model.n_lineages, arrays[0].ctypes.data_as(binding.c_u16p), arrays[1].ctypes.data_as(binding.c_u32p),
+            arrays[2].ctypes.data_as(binding.c_u32p), arrays[3].ctypes.data_as(binding.c_u32p), arrays[4].ctypes.data_as(binding.c_u32p),
+            arrays[5].ctypes.data_as(binding.c_u8p), model.private_threshold, model.ambiguous_threshold)
+        _check(self.lib.silo_engine_generate_synthetic(self.handle, partition, name.encode(), int(is_aa), ctypes.byref(desc)))
+
+    def set_lineage_column(self, partition, column, values):
+        array = (ctypes.c_char_p * len(values))(*[None if v is None else v.encode() for v in values])
+        _check(self.lib.silo_engine_set_lineage_column(self.handle, partition, column.encode(), array, len(values)))
+
+    def set_lineage_column_ids(self, partition, column, dictionary, value_ids):
+        names = (ctypes.c_char_p * len(dictionary))(*[d.encode() for d in dictionary])
+        ids = np.ascontiguousarray(value_ids, dtype=np.uint32)
+        _check(self.lib.silo_engine_set_lineage_column_ids(
+            self.handle, partition, column.encode(), names, len(dictionary), ids.ctypes.data_as(ctypes.c_void_p), len(ids)))
+
+    def finalize(self):
+        _check(self.lib.silo_engine_finalize(self.handle))
+
+    def set_sharding(self, rank, world, shard_by_position, all_reduce=None):
+        """all_reduce(device_ptr:int, n:int, stream) -> sums n uint32 in place across ranks."""
+        if all_reduce is None:
+            callback = ALL_REDUCE_FN(0)
+        else:
+            def trampoline(_context, device_values, n, stream):
+                try:
+                    all_reduce(device_values, n, stream)
+                    return 0
+                except Exception as error:  # never let an exception cross the C boundary
+                    print("all_reduce callback failed:", error)
+                    return 1
+            callback = ALL_REDUCE_FN(trampoline)
+        self._callbacks.append(callback)
+        _check(self.lib.silo_engine_set_sharding(self.handle, rank, world, int(shard_by_position), callback, None))
+
+    def execute_raw(self, query):
+        """Returns (http_status, parsed JSON document)."""
+        text = query if isinstance(query, str) else json.dumps(query)
+        out = ctypes.c_void_p()
+        status = ctypes.c_int()
+        _check(self.lib.silo_engine_execute_query(self.handle, text.encode(), ctypes.byref(out), ctypes.byref(status)))
+        try:
+            document = json.loads(ctypes.string_at(out).decode())
+        finally:
+            self.lib.silo_engine_free_string(out)
+        return status.value, document
+
+    def execute_query(self, query):
+        status, document = self.execute_raw(query)
+        if status != 200:
+            raise QueryError(status, document)
+        return document["queryResult"]
+
+    def last_timings(self):
+        filter_us, action_us = ctypes.c_int64(), ctypes.c_int64()
+        self.lib.silo_engine_last_timings(ctypes.byref(filter_us), ctypes.byref(action_us))
+        return filter_us.value, action_us.value
+
+    def partition_store(self, partition):
+        return StoreView(self.lib.silo_engine_partition_store(self.handle, partition))
+
+    def seqstore_id(self, partition, name, is_aa):
+        return self.lib.silo_engine_seqstore_id(self.handle, partition, name.encode(), int(is_aa))

@@ -1,0 +1,153 @@
+"""End-to-end parity of the C++ QueryEngine mirror + HIP kernels: the reference's own e2e goldens on
+testBaseData/exampleDataset, and oracle-vs-device on randomised queries."""
+import json
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import silo_oracle as so  # noqa: E402
+from tests import dataset  # noqa: E402
+from tests.test_oracle_golden import build_oracle_db  # noqa: E402
+
+
+def build_engine(data, partition_sizes=None):
+    from silo_amd.engine import Engine
+
+    genomes = json.load(open(dataset.GOLDEN + "/exampleDataset/reference_genomes.json"))
+    engine = Engine(genomes, data["alias"])
+    n = len(data["keys"])
+    bounds = [0]
+    for size in partition_sizes or [n]:
+        bounds.append(bounds[-1] + size)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        part = engine.add_partition(hi - lo)
+        for name, genomes_list in data["nuc"].items():
+            engine.append_sequences(part, name, False, 0, genomes_list[lo:hi])
+        for name, genomes_list in data["aa"].items():
+            engine.append_sequences(part, name, True, 0, genomes_list[lo:hi])
+        engine.set_lineage_column(part, "pango_lineage", data["lineages"][lo:hi])
+    engine.finalize()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def example_data():
+    return dataset.load_example_dataset()
+
+
+@pytest.fixture(scope="module", params=[None, [37, 1, 62]], ids=["1-partition", "3-partitions"])
+def engines(request, built, example_data):
+    engine = build_engine(example_data, request.param)
+    oracle_db = build_oracle_db(example_data, request.param)
+    yield engine, oracle_db
+    engine.close()
+
+
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("queries"), ids=lambda c: c["file"])
+def test_reference_e2e_goldens(engines, case):
+    engine, _ = engines
+    status, document = engine.execute_raw(case["query"])
+    assert status == 200, document
+    assert document == {"queryResult": case["expectedQueryResult"]}
+
+
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("invalidQueries"), ids=lambda c: c["file"])
+def test_reference_e2e_invalid_goldens(engines, case):
+    engine, _ = engines
+    status, document = engine.execute_raw(case["query"])
+    assert status == 400
+    assert document == case["expectedError"]
+
+
+def test_inline_error_cases(engines):  # endToEndTests/test/query.test.js:64-113
+    engine, _ = engines
+    status, document = engine.execute_raw({"someJson": "but missing expected properties"})
+    assert (status, document) == (400, {"error": "Bad request", "message": "Query json must contain filterExpression and action."})
+    status, document = engine.execute_raw({"action": {"type": "invalid action"}, "filterExpression": {"type": "invalid filter type"}})
+    assert (status, document) == (400, {"error": "Bad request", "message": "Unknown object filter type 'invalid filter type'"})
+    status, document = engine.execute_raw("{ not a valid json")
+    assert status == 400 and document["error"] == "Bad request"
+    assert document["message"].startswith("The query was not a valid JSON: ")
+    # std::out_of_range from .at() is a 500 in the reference too (has_mutation.cpp:46-47)
+    status, document = engine.execute_raw({"action": {"type": "Aggregated"}, "filterExpression": {"type": "HasNucleotideMutation", "position": 0}})
+    assert status == 500 and document["error"] == "Internal Server Error"
+
+
+NUC = "ACGT-NRYKM"
+AA = "ACDEFGHIKLMNPQRSTVWY-*XBZ"
+
+
+def random_leaf(rng):
+    kind = rng.choice(["nuc", "nuc", "nuc", "aa", "hasnuc", "hasaa", "lineage", "true", "false"])
+    if kind == "nuc":
+        store = rng.choice(["main", "main", None, "testSecondSequence"])
+        if store == "testSecondSequence":
+            pos = rng.randint(1, 4)
+        else:
+            pos = rng.choice([1, 2, 241, 3037, 14408, 23403, 27542, 28881, 29903])
+        expr = {"type": "NucleotideEquals", "position": pos, "symbol": rng.choice(NUC + ".")}
+        if store is not None:
+            expr["sequenceName"] = store
+        return expr
+    if kind == "aa":
+        gene, length = rng.choice([("S", 1274), ("E", 76), ("N", 420), ("ORF1a", 4401)])
+        pos = rng.choice([1, 2, 19, 501, 614, 681, length])
+        return {"type": "AminoAcidEquals", "sequenceName": gene, "position": min(pos, length), "symbol": rng.choice(AA + ".")}
+    if kind == "hasnuc":
+        return {"type": "HasNucleotideMutation", "position": rng.choice([1, 241, 3037, 23403, 28881, 29903, 210, 4184])}
+    if kind == "hasaa":
+        gene, length = rng.choice([("S", 1274), ("E", 76), ("N", 420)])
+        return {"type": "HasAminoAcidMutation", "sequenceName": gene, "position": rng.choice([1, 19, 69, 76, length])}
+    if kind == "lineage":
+        return {"type": "PangoLineage", "column": "pango_lineage",
+                "value": rng.choice(["B.1.1.7", "b.1", "Q", "B.1.617.2", "XA.1", "AY.4", "nonsense", "B.1.1"]),
+                "includeSublineages": rng.random() < 0.6}
+    return {"type": "True"} if kind == "true" else {"type": "False"}
+
+
+def random_expression(rng, depth):
+    if depth == 0 or rng.random() < 0.25:
+        return random_leaf(rng)
+    kind = rng.choice(["And", "Or", "Not", "N-Of", "N-Of", "Maybe", "Exact"])
+    if kind in ("And", "Or"):
+        return {"type": kind, "children": [random_expression(rng, depth - 1) for _ in range(rng.randint(0, 4))]}
+    if kind == "N-Of":
+        k = rng.randint(1, 5)
+        return {"type": "N-Of", "children": [random_expression(rng, depth - 1) for _ in range(k)],
+                "numberOfMatchers": rng.randint(0, k + 1), "matchExactly": rng.random() < 0.5}
+    return {"type": kind, "child": random_expression(rng, depth - 1)}
+
+
+def test_random_filters_match_oracle(engines):
+    engine, oracle_db = engines
+    rng = random.Random(20250117)
+    for trial in range(150):
+        expression = random_expression(rng, 3)
+        query = {"action": {"type": "Aggregated"}, "filterExpression": expression}
+        want = so.execute_query(oracle_db, query)
+        got = engine.execute_query(query)
+        assert got == want, json.dumps(query)
+
+
+def test_random_mutations_match_oracle(engines):
+    engine, oracle_db = engines
+    rng = random.Random(7)
+    for trial in range(12):
+        expression = random_expression(rng, 2)
+        if rng.random() < 0.5:
+            action = {"type": "Mutations", "minProportion": rng.choice([0, 0.05, 0.5, 1]),
+                      "sequenceName": rng.choice(["main", "testSecondSequence", ["main", "testSecondSequence"]])}
+        else:
+            action = {"type": "AminoAcidMutations", "minProportion": rng.choice([0, 0.02, 0.3])}
+            if rng.random() < 0.6:
+                action["sequenceName"] = rng.choice(["S", ["E", "N"], "ORF1a"])
+        if rng.random() < 0.5:
+            action["orderByFields"] = [{"field": "count", "order": "descending"}, "mutation"]
+            action["limit"] = rng.randint(1, 50)
+            action["offset"] = rng.randint(0, 5)
+        query = {"action": action, "filterExpression": expression}
+        want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+        got = engine.execute_query(query)
+        assert got == want, json.dumps(query)
