@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py — Mutations-scan throughput of the MI355X filter engine, with roofline and CPU baseline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A *step* is one complete query through the C++ QueryEngine mirror:
+    {"action": {"type": "Mutations", "minProportion": 0.05},
+     "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": true}}
+i.e. JSON parse -> filter compile -> lineage bitset (HBM resident) -> K3 bitset+count -> K1 Mutations scan
+over every position x {-,A,C,G,T} plane -> (N > 1: all-reduce of the count table over RCCL) -> counts to
+the host -> proportion rows -> result JSON.  The planes are resident in HBM before the timed region.
+
+Workload (default): the north-star target "10 M-sequence Mutations scan" — 10 M synthetic SARS-CoV-2
+sequences x 29 903 nt (BASELINE.json configs[3], nucleotide leg, with configs[1]'s PangoLineage
+filter); 186.9 GB of algorithmic plane bytes per step.  N > 1 shards the genome by position range
+(strong scaling, same total work).  `--sequences 1000000` runs configs[1] itself; at N = 1 that
+configuration is also measured and reported under "also".
+
+metric = positions x sequences / s (whole job).  roofline: the dominant kernel k_scan_tiled, timed with
+HIP events on the stream it is launched on; algorithmic bytes = P * 5 * 8*ceil(N/64) + 8*ceil(N/64)
+(SURVEY.md §8d).  cpu_baseline: oracle/roaring_port.c (the reference's algorithm over roaring-format
+containers, OpenMP) on a bounded sample of positions of the same store, rank 0 / N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "lapis-silo_amd")]
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+QUERY_LINEAGE = "B.1"
+N_LINEAGES = 2000
+
+
+def log(*args):
+    print(*args, file=sys.stderr, flush=True)
+
+
+def load_reference_genomes():
+    path = os.path.join(ROOT, "tests", "golden", "exampleDataset", "reference_genomes.json")
+    genomes = json.load(open(path))
+    # nucleotide segment "main" only: the metric is the nucleotide Mutations scan
+    return {"nucleotideSequences": [g for g in genomes["nucleotideSequences"] if g["name"] == "main"], "genes": []}
+
+
+def build_engine(n_sequences, rank, world, all_reduce, device):
+    from silo_amd import alphabet, synth
+    from silo_amd.engine import Engine
+
+    genomes = load_reference_genomes()
+    reference = np.array([alphabet.NUCLEOTIDE.char_to_symbol[c] for c in genomes["nucleotideSequences"][0]["sequence"]], dtype=np.uint8)
+    tree = synth.make_lineage_tree(N_LINEAGES)
+    lineage = synth.assign_lineages(n_sequences, tree, synth.DEFAULT_SEED)
+    model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
+    engine = Engine(genomes, device=device)
+    if world > 1:
+        engine.set_sharding(rank, world, True, all_reduce)
+    partition = engine.add_partition(n_sequences)
+    window = engine.position_window("main", False)
+    engine.generate_synthetic(partition, "main", False, model, window)
+    engine.set_lineage_column_ids(partition, "pango_lineage", tree.names, lineage)
+    engine.finalize()
+    return engine, model, tree, lineage, window
+
+
+def make_query():
+    return json.dumps({
+        "action": {"type": "Mutations", "minProportion": 0.05},
+        "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": QUERY_LINEAGE, "includeSublineages": True},
+    })
+
+
+def time_kernel(engine, tree, window, reps):
+    """Average duration of one k_scan_tiled launch over this rank's window, HIP events on the null stream."""
+    import ctypes
+
+    from silo_amd import binding
+
+    store = engine.partition_store(0)
+    lib = binding.load_library()
+    member = tree.subtree(tree.names.index(QUERY_LINEAGE))
+    filt = ctypes.c_void_p()
+    binding._check(lib.silo_gpu_bitset_alloc(store.handle, ctypes.byref(filt)))
+    binding._check(lib.silo_gpu_bitset_from_lineages(store.handle, filt, member.ctypes.data_as(ctypes.c_void_p), len(member), None))
+    n_positions = window[1] - window[0]
+    counts = ctypes.c_void_p()
+    binding._check(lib.silo_gpu_malloc(4 * n_positions * 5, ctypes.byref(counts)))
+    binding._check(lib.silo_gpu_memset_async(counts, 0, 4 * n_positions * 5, None))
+    start, stop = binding.GpuEvent(), binding.GpuEvent()
+    for _ in range(2):
+        binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, 0, n_positions, counts, None))
+    start.record()
+    for _ in range(reps):
+        binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, 0, n_positions, counts, None))
+    stop.record()
+    ms = start.elapsed_ms(stop) / reps
+    kernel = lib.silo_gpu_last_scan_kernel().decode()
+    return ms, kernel, store, filt, counts
+
+
+def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_positions):
+    """The reference's algorithm (roaring-format containers, OpenMP over positions) on a bounded sample of
+    positions of the same synthetic store; its counts are checked against the GPU's on the same positions."""
+    import ctypes
+
+    from oracle import cpu_port, dense
+    from silo_amd import binding
+
+    threads = cpu_port.max_threads()
+    n_positions = max(threads, budget_positions // threads * threads)
+    begin = (model.positions // 2) // 64 * 64
+    t0 = time.time()
+    port = cpu_port.PortStore(n_sequences, begin, n_positions, "nuc", model=model)
+    build_s = time.time() - t0
+    member = tree.subtree(tree.names.index(QUERY_LINEAGE))
+    mask = member[lineage].astype(bool)
+    port_filter = cpu_port.Filter(dense.pack_bits(mask), n_sequences)
+    grain = n_positions // threads  # every thread owns one chunk, as in the steady state of the 300-position grain
+    best = None
+    counts = None
+    for _ in range(2):
+        counts, seconds = port.mutations_scan(port_filter, n_threads=threads, grain=grain)
+        best = seconds if best is None else min(best, seconds)
+    # parity at full size: the GPU's counts on the same positions
+    lib = binding.load_library()
+    gpu_counts_dev = ctypes.c_void_p()
+    binding._check(lib.silo_gpu_malloc(4 * n_positions * 5, ctypes.byref(gpu_counts_dev)))
+    binding._check(lib.silo_gpu_memset_async(gpu_counts_dev, 0, 4 * n_positions * 5, None))
+    binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, begin, begin + n_positions, gpu_counts_dev, None))
+    gpu_counts = np.empty(n_positions * 5, dtype=np.uint32)
+    binding._check(lib.silo_gpu_memcpy_d2h(gpu_counts.ctypes.data_as(ctypes.c_void_p), gpu_counts_dev, gpu_counts.nbytes, None))
+    lib.silo_gpu_free(gpu_counts_dev)
+    if not np.array_equal(gpu_counts.reshape(n_positions, 5), counts[:, :5]):
+        raise AssertionError("cpu_baseline: GPU counts differ from the CPU port on the sampled positions")
+    census = port.census()
+    port.close()
+    return {
+        "value": n_sequences * n_positions / best,
+        "unit": "positions*sequences/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"positions [{begin},{begin + n_positions}) of the same {n_sequences}-sequence store, filter cardinality "
+                  f"{int(mask.sum())}, {threads} OpenMP threads x {grain} positions, best of 2; build {build_s:.1f}s; "
+                  f"containers array/bitset/run = {census['arrays']}/{census['bitsets']}/{census['runs']}; "
+                  f"counts equal to the GPU's on these positions",
+        "seconds": best,
+    }
+
+
+def run_steps(engine, query, steps, warmup, sync):
+    for _ in range(warmup):
+        engine.execute_query(query)
+    sync()
+    t0 = time.perf_counter()
+    rows = None
+    for _ in range(steps):
+        rows = engine.execute_query(query)
+    sync()
+    return time.perf_counter() - t0, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sequences", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
+    ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    from silo_amd import binding
+
+    lib = binding.load_library()
+    all_reduce = None
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+        class DeviceU32:
+            """A raw device pointer exposed to torch (as int32: a wrapping int32 sum has the same bits as a uint32 sum)."""
+
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+        def all_reduce(device_ptr, n, _stream):
+            tensor = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI; ordered after the scan on the null stream
+
+        def sync():
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def sync():
+            binding._check(lib.silo_gpu_stream_synchronize(None))
+
+    t0 = time.time()
+    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank)
+    log(f"[rank {rank}] store ready in {time.time() - t0:.1f}s: {args.sequences} sequences, positions {window}, "
+        f"{engine.partition_store(0).device_bytes / 1e9:.1f} GB in HBM")
+    query = make_query()
+    positions = model.positions
+
+    elapsed, rows = run_steps(engine, query, args.steps, args.warmup, sync)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    filter_us, action_us = engine.last_timings()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.sequences * positions / (elapsed / args.steps)
+
+    # roofline of the dominant kernel, on this rank's window
+    w8 = 8 * ((args.sequences + 63) // 64)
+    n_local = window[1] - window[0]
+    kernel_ms, kernel_name, store, filt, counts_dev = time_kernel(engine, tree, window, reps=max(5, args.steps))
+    alg_bytes = n_local * 5 * w8 + w8
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "Mutations-scan positions*sequences/s",
+        "value": value,
+        "unit": "positions*sequences/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.sequences}-sequence x {positions}-nt nucleotide Mutations scan (minProportion 0.05) with a "
+                        f"PangoLineage sublineage filter ({QUERY_LINEAGE}*), through QueryEngine::executeQuery",
+            "sequences": args.sequences,
+            "positions": positions,
+            "mutation_rows": len(rows),
+            "sharding": "none" if world == 1 else f"position-range x{world}, all-reduce of counts[{positions}][5] over RCCL",
+            "reference_phases_us": {"filter": filter_us, "action": action_us},
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": kernel_name,
+            "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ~10-30 s of CPU work: one position costs ~25 ns per filtered sequence (the row-wise missing probes)
+        budget = args.cpu_positions or int(max(16, min(4800, 20.0 / max(1e-9, 25e-9 * 0.415 * args.sequences))))
+        try:
+            result["cpu_baseline"] = cpu_baseline(model, tree, lineage, args.sequences, store, filt, budget)
+        except AssertionError:
+            raise
+        except Exception as error:  # the baseline is informational; a failure to build it must not hide the GPU number
+            result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
+    lib.silo_gpu_free(filt)
+    lib.silo_gpu_free(counts_dev)
+    engine.close()
+
+    if rank == 0 and world == 1 and not args.no_also and args.sequences != 1_000_000:
+        # BASELINE.json configs[1]: 1 M sequences, same query
+        engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank)
+        elapsed1, rows1 = run_steps(engine1, query, args.steps, args.warmup, sync)
+        kernel_ms1, _, _, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
+        w81 = 8 * ((1_000_000 + 63) // 64)
+        alg1 = positions * 5 * w81 + w81
+        result["also"] = {
+            "workload": "BASELINE.json configs[1]: 1000000 sequences, same query",
+            "value": 1_000_000 * positions / (elapsed1 / args.steps),
+            "ms_per_step": elapsed1 / args.steps * 1e3,
+            "kernel_ms": kernel_ms1,
+            "roofline_frac": alg1 / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "mutation_rows": len(rows1),
+        }
+        lib.silo_gpu_free(filt1)
+        lib.silo_gpu_free(counts1)
+        engine1.close()
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -55,9 +55,10 @@ int silo_engine_set_lineage_column_ids(
 /* Call once after loading, before the first query. */
 int silo_engine_finalize(silo_engine* engine);
 
-/* Multi-GPU (one process per GPU).  shard_by_position != 0: this rank scans only its slice of the
- * position range and counts are all-reduced; otherwise the partitions of this rank are a
- * sequence-id shard and counts / cardinalities are all-reduced.  all_reduce sums n uint32 in place on
+/* Multi-GPU (one process per GPU).  Call before silo_engine_add_partition.  shard_by_position != 0:
+ * this rank holds and scans only positions [P*rank/world, P*(rank+1)/world) of every sequence store
+ * (sequences appended must be that slice) and counts are all-reduced; otherwise the partitions of
+ * this rank are a sequence-id shard and counts / cardinalities are all-reduced.  all_reduce sums n uint32 in place on
  * the device across ranks (RCCL over xGMI in production). */
 typedef int (*silo_engine_all_reduce_u32)(void* context, uint32_t* device_values, size_t n, void* stream);
 int silo_engine_set_sharding(
@@ -77,6 +78,9 @@ void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_micr
 silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int partition);
 /* silo_gpu sequence-store index of a named store inside a partition, or -1. */
 int silo_engine_seqstore_id(const silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid);
+
+/* Genome positions [*begin, *end) of a named sequence store that are resident on this rank. */
+int silo_engine_position_window(const silo_engine* engine, const char* sequence_name, int is_amino_acid, uint32_t* begin, uint32_t* end);
 
 const char* silo_engine_last_error(void);
 

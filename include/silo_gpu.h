@@ -108,6 +108,10 @@ typedef struct {
    const uint8_t* lineage_symbol;       /* [positions][n_lineages] */
    uint32_t private_threshold;          /* of 2^20: P(private substitution) per cell */
    uint32_t ambiguous_threshold;        /* of 2^24: P(sparse ambiguity code) per cell */
+   /* Position-range shards: the store holds positions [position_offset, position_offset + positions)
+    * of a genome of total_positions (0 = the store's own length); lineage_symbol covers the slice. */
+   uint32_t position_offset;
+   uint32_t total_positions;
 } silo_gpu_synth_desc;
 int silo_gpu_store_generate_synthetic(
    silo_gpu_store* store, uint32_t seqstore_id, const silo_gpu_synth_desc* synth

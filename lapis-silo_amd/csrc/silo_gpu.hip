@@ -170,28 +170,27 @@ __device__ __forceinline__ uint32_t popc128(const ulonglong2& v, const ulonglong
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ROWS_BATCH = 64;
 
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+
 template <int WPT, bool GUARDED>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiled(
+__device__ __forceinline__ void scanTile(
    const uint64_t* __restrict__ planes,
    const uint64_t* __restrict__ filter,
    uint32_t* __restrict__ counts,
    uint32_t row_words,
    uint32_t n_rows,
    uint32_t rows_per_block,
-   uint32_t n_tiles,
-   uint32_t first_tile
+   uint32_t tile,
+   uint32_t row_group,
+   uint32_t (&s_partial)[2][SCAN_WAVES][SCAN_ROWS_BATCH]
 ) {
    constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread
    constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
-   constexpr int WAVES = SCAN_THREADS / 64;
-   // per-wave partial counts of one batch of rows, double-buffered so one barrier per batch suffices
-   __shared__ uint32_t s_partial[2][WAVES][SCAN_ROWS_BATCH];
+   constexpr int WAVES = SCAN_WAVES;
 
    const uint32_t tid = threadIdx.x;
    const uint32_t wave = tid >> 6;
    const bool writer = (tid & 63u) == 63u;  // waveSumToLane63 leaves the total in lane 63
-   const uint32_t tile = first_tile + blockIdx.x % n_tiles;
-   const uint32_t row_group = blockIdx.x / n_tiles;
    const uint32_t row_begin = row_group * rows_per_block;
    const uint32_t row_end = min(n_rows, row_begin + rows_per_block);
    const uint32_t last_row = row_end - 1;
@@ -265,6 +264,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiled(
          batch_first_row += done;
          buffer ^= 1u;
       }
+   }
+}
+
+// One launch covers the whole (rows x row_words) rectangle: blockIdx.x = row_group * n_tiles + tile.
+// Only the last column tile can be ragged (row_words is a multiple of 32 words, a tile is 2048); it
+// takes the guarded instantiation through a block-uniform branch, every other block the unguarded one.
+template <int WPT>
+__global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan_tiled(
+   const uint64_t* __restrict__ planes,
+   const uint64_t* __restrict__ filter,
+   uint32_t* __restrict__ counts,
+   uint32_t row_words,
+   uint32_t n_rows,
+   uint32_t rows_per_block,
+   uint32_t n_tiles
+) {
+   // per-wave partial counts of one batch of rows, double-buffered so one barrier per batch suffices
+   __shared__ uint32_t s_partial[2][SCAN_WAVES][SCAN_ROWS_BATCH];
+   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
+   const uint32_t tile = blockIdx.x % n_tiles;
+   const uint32_t row_group = blockIdx.x / n_tiles;
+   if ((tile + 1) * TILE_WORDS <= row_words) {
+      scanTile<WPT, false>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
+   } else {
+      scanTile<WPT, true>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
    }
 }
 
@@ -489,6 +513,8 @@ struct SynthArgs {
    uint32_t ambiguous_threshold;
    uint32_t private_base, private_count;      // nuc: 1,4 (A C G T)   aa: 1,20 (A..Y)
    uint32_t ambiguous_base, ambiguous_count;  // nuc: 5,10 (R..V)     aa: 21,2 (B Z)
+   uint32_t position_offset;                  // global position of the store's position 0
+   uint32_t total_positions;                  // genome length (>= position_offset + store positions)
 };
 
 constexpr uint32_t SYNTH_POSITIONS_PER_WAVE = 128;
@@ -510,12 +536,13 @@ __global__ __launch_bounds__(256) void k_generate_synthetic(
    const uint32_t trail = args.trail_gap[i];
    const uint32_t mstart = args.missing_start[i];
    const uint32_t mlen = args.missing_len[i];
-   const uint32_t positions = store.positions;
+   const uint32_t positions = args.total_positions;
    const uint64_t seq_hash = args.seed ^ (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull);
 
    const uint32_t pos_begin = blockIdx.y * SYNTH_POSITIONS_PER_WAVE;
-   const uint32_t pos_end = min(positions, pos_begin + SYNTH_POSITIONS_PER_WAVE);
-   for (uint32_t p = pos_begin; p < pos_end; ++p) {
+   const uint32_t pos_end = min(store.positions, pos_begin + SYNTH_POSITIONS_PER_WAVE);
+   for (uint32_t local = pos_begin; local < pos_end; ++local) {
+      const uint32_t p = args.position_offset + local;  // global genome position
       uint32_t symbol;
       if (p < lead || p >= positions - trail) {
          symbol = 0;  // GAP
@@ -528,14 +555,14 @@ __global__ __launch_bounds__(256) void k_generate_synthetic(
          } else if (((h >> 32) & 0xFFFFFFu) < args.ambiguous_threshold) {
             symbol = args.ambiguous_base + static_cast<uint32_t>(h >> 56) % args.ambiguous_count;
          } else {
-            const uint8_t ls = args.lineage_symbol[static_cast<size_t>(p) * args.n_lineages + lineage];
-            symbol = ls != SILO_GPU_SYMBOL_NONE ? ls : args.reference[p];
+            const uint8_t ls = args.lineage_symbol[static_cast<size_t>(local) * args.n_lineages + lineage];
+            symbol = ls != SILO_GPU_SYMBOL_NONE ? ls : args.reference[local];
          }
       }
       if (!active) {
          symbol = SILO_GPU_SYMBOL_NONE;
       }
-      emitWord(store, p, word, symbol, /*whole_word=*/true, sparse, sparse_count, sparse_capacity);
+      emitWord(store, local, word, symbol, /*whole_word=*/true, sparse, sparse_count, sparse_capacity);
    }
 }
 
@@ -963,6 +990,12 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    args.reference = seqstore.d_reference;
    args.private_threshold = synth->private_threshold;
    args.ambiguous_threshold = synth->ambiguous_threshold;
+   args.position_offset = synth->position_offset;
+   args.total_positions = synth->total_positions != 0 ? synth->total_positions : positions;
+   if (static_cast<uint64_t>(args.position_offset) + positions > args.total_positions) {
+      release();
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "synthetic position window exceeds total_positions");
+   }
    if (seqstore.alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE) {
       args.private_base = 1;
       args.private_count = 4;
@@ -1353,21 +1386,12 @@ int silo_gpu_mutations_scan(
    if (rows_per_block <= 0) {
       rows_per_block = 256;
    }
-   const uint32_t full_tiles = row_words / TILE_WORDS;
-   const bool ragged = row_words % TILE_WORDS != 0;
+   const uint32_t n_tiles = (row_words + TILE_WORDS - 1) / TILE_WORDS;
    const uint32_t row_groups = (n_rows + rows_per_block - 1) / rows_per_block;
-   if (full_tiles > 0) {
-      k_scan_tiled<WPT, false><<<full_tiles * row_groups, SCAN_THREADS, 0, hip_stream>>>(
-         planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, full_tiles, 0
-      );
-      HIP_TRY(hipGetLastError());
-   }
-   if (ragged) {
-      k_scan_tiled<WPT, true><<<row_groups, SCAN_THREADS, 0, hip_stream>>>(
-         planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, 1, full_tiles
-      );
-      HIP_TRY(hipGetLastError());
-   }
+   k_scan_tiled<WPT><<<n_tiles * row_groups, SCAN_THREADS, 0, hip_stream>>>(
+      planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles
+   );
+   HIP_TRY(hipGetLastError());
    g_last_scan_kernel = "k_scan_tiled";
    return SILO_GPU_OK;
 }

@@ -148,26 +148,23 @@ std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
       return counts;
    }
    // position-range shard of this rank; [0, P) when not sharded by position
-   uint32_t pos_begin = 0;
-   uint32_t pos_end = sequence_length;
-   if (database.shard_by_position && database.shard_world > 1) {
-      pos_begin = static_cast<uint32_t>(static_cast<uint64_t>(sequence_length) * database.shard_rank / database.shard_world);
-      pos_end = static_cast<uint32_t>(static_cast<uint64_t>(sequence_length) * (database.shard_rank + 1) / database.shard_world);
-   }
+   const auto [pos_begin, pos_end] = database.positionWindow(sequence_length);
    const DatabasePartition& home = database.partitions.front();
    DeviceBuffer device_counts = home.pool.acquire(n_counts * sizeof(uint32_t));
    checkGpu(silo_gpu_memset_async(device_counts.get(), 0, n_counts * sizeof(uint32_t), nullptr), "silo_gpu_memset_async");
    uint32_t* window = device_counts.as<uint32_t>() + static_cast<size_t>(pos_begin) * n_symbols;
+   // the device store of a rank holds exactly its window: local positions [0, pos_end - pos_begin)
+   const uint32_t local_positions = pos_end - pos_begin;
    for (const auto& [filter, store] : bitmap_filter.bitmaps) {
       checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), pos_begin, pos_end, window, nullptr),
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), 0, local_positions, window, nullptr),
          "silo_gpu_mutations_scan"
       );
    }
    for (const auto& [filter, store] : bitmap_filter.full_bitmaps) {
       // full filter: the reference reads plain cardinalities (mutations.cpp:98-136); NULL = all rows
       checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, pos_begin, pos_end, window, nullptr), "silo_gpu_mutations_scan"
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, 0, local_positions, window, nullptr), "silo_gpu_mutations_scan"
       );
    }
    allReduce(database, device_counts.as<uint32_t>(), n_counts);

@@ -254,6 +254,30 @@ silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int parti
    return engine->database.partitions[static_cast<size_t>(partition)].store;
 }
 
+int silo_engine_position_window(const silo_engine* engine, const char* sequence_name, int is_amino_acid, uint32_t* begin, uint32_t* end) {
+   if (engine == nullptr || sequence_name == nullptr || begin == nullptr || end == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_position_window: null argument");
+   }
+   size_t length = 0;
+   if (is_amino_acid != 0) {
+      const auto found = engine->database.aa_sequences.find(sequence_name);
+      if (found == engine->database.aa_sequences.end()) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
+      }
+      length = found->second.reference_sequence.size();
+   } else {
+      const auto found = engine->database.nuc_sequences.find(sequence_name);
+      if (found == engine->database.nuc_sequences.end()) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
+      }
+      length = found->second.reference_sequence.size();
+   }
+   const auto [window_begin, window_end] = engine->database.positionWindow(length);
+   *begin = window_begin;
+   *end = window_end;
+   return 0;
+}
+
 int silo_engine_seqstore_id(const silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid) {
    if (engine == nullptr || partition < 0 || static_cast<size_t>(partition) >= engine->database.partitions.size()) {
       return -1;

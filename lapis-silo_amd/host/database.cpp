@@ -215,6 +215,15 @@ query_engine::QueryResult Database::executeQuery(const std::string& query) const
    return query_engine.executeQuery(query);
 }
 
+std::pair<uint32_t, uint32_t> Database::positionWindow(size_t length) const {
+   if (!shard_by_position || shard_world <= 1) {
+      return {0, static_cast<uint32_t>(length)};
+   }
+   return {
+      static_cast<uint32_t>(static_cast<uint64_t>(length) * shard_rank / shard_world),
+      static_cast<uint32_t>(static_cast<uint64_t>(length) * (shard_rank + 1) / shard_world)};
+}
+
 void Database::setReferenceGenomes(const json::Value& reference_genomes) {  // reference_genomes.cpp
    nuc_sequences.clear();
    aa_sequences.clear();
@@ -261,8 +270,12 @@ DatabasePartition& Database::addPartition(uint32_t sequence_count) {
    const auto add = [&](const auto& stores, uint32_t alphabet, const std::vector<uint8_t>& scan, const uint8_t* extra) {
       for (const auto& [name, store] : stores) {
          auto& reference = references.emplace_back();
-         for (const auto symbol : store.reference_sequence) {
-            reference.push_back(static_cast<uint8_t>(symbol));
+         const auto [window_begin, window_end] = positionWindow(store.reference_sequence.size());
+         if (window_begin == window_end) {
+            throw std::runtime_error("position-range shard of sequence store '" + name + "' is empty: more ranks than positions");
+         }
+         for (uint32_t position = window_begin; position < window_end; ++position) {
+            reference.push_back(static_cast<uint8_t>(store.reference_sequence[position]));
          }
          silo_gpu_seqstore_desc desc{};
          desc.alphabet = alphabet;
@@ -297,15 +310,17 @@ DatabasePartition& Database::addPartition(uint32_t sequence_count) {
    }
    uint32_t seqstore_id = 0;
    for (const auto& [name, store] : nuc_sequences) {
+      const auto [window_begin, window_end] = positionWindow(store.reference_sequence.size());
       partition.nuc_sequences.emplace(
          std::piecewise_construct, std::forward_as_tuple(name),
-         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count)
+         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count, window_begin, window_end)
       );
    }
    for (const auto& [name, store] : aa_sequences) {
+      const auto [window_begin, window_end] = positionWindow(store.reference_sequence.size());
       partition.aa_sequences.emplace(
          std::piecewise_construct, std::forward_as_tuple(name),
-         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count)
+         std::forward_as_tuple(store.reference_sequence, partition.store, seqstore_id++, sequence_count, window_begin, window_end)
       );
    }
    return partition;

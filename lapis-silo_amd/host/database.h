@@ -138,18 +138,35 @@ class SequenceStore {
 template <typename SymbolType>
 class SequenceStorePartition {
   public:
-   SequenceStorePartition(const std::vector<typename SymbolType::Symbol>& reference_sequence, silo_gpu_store* store, uint32_t seqstore_id, uint32_t sequence_count)
-       : reference_sequence(reference_sequence), store(store), seqstore_id(seqstore_id), sequence_count(sequence_count) {}
+   SequenceStorePartition(
+      const std::vector<typename SymbolType::Symbol>& reference_sequence, silo_gpu_store* store, uint32_t seqstore_id,
+      uint32_t sequence_count, uint32_t position_begin, uint32_t position_end
+   )
+       : reference_sequence(reference_sequence),
+         store(store),
+         seqstore_id(seqstore_id),
+         sequence_count(sequence_count),
+         position_begin(position_begin),
+         position_end(position_end) {}
 
    const std::vector<typename SymbolType::Symbol>& reference_sequence;
    silo_gpu_store* store;
    uint32_t seqstore_id;
    uint32_t sequence_count;
+   /// Positions [position_begin, position_end) of the genome are resident in this rank's HBM
+   /// (the whole genome unless the database is sharded by position range).
+   uint32_t position_begin;
+   uint32_t position_end;
+
+   [[nodiscard]] bool holds(size_t position) const { return position >= position_begin && position < position_end; }
 
    /// Device pointer of the dense plane, nullptr when the symbol is stored sparsely
-   /// (sequence_store.cpp:92-98 returned a roaring pointer).
+   /// (sequence_store.cpp:92-98 returned a roaring pointer).  `position` is a genome position.
    [[nodiscard]] const uint64_t* getBitmap(size_t position, typename SymbolType::Symbol symbol) const {
-      return silo_gpu_store_plane(store, seqstore_id, static_cast<uint32_t>(position), static_cast<uint32_t>(symbol));
+      if (!holds(position)) {
+         return nullptr;
+      }
+      return silo_gpu_store_plane(store, seqstore_id, static_cast<uint32_t>(position - position_begin), static_cast<uint32_t>(symbol));
    }
 };
 
@@ -199,8 +216,9 @@ class Database {
    int device = 0;
 
    // --- sharding ---------------------------------------------------------------
-   /// Position-range sharding: this rank scans rows [begin,end) of the position x symbol space only
-   /// and the counts are all-reduced.  world == 1 -> everything local.
+   /// Position-range sharding: this rank holds and scans positions [P*rank/world, P*(rank+1)/world) of
+   /// every sequence store and the counts are all-reduced (set before addPartition).  Otherwise the
+   /// partitions of this rank are a sequence-id shard.  world == 1 -> everything local.
    uint32_t shard_rank = 0;
    uint32_t shard_world = 1;
    bool shard_by_position = false;
@@ -219,6 +237,9 @@ class Database {
 
    /// database.cpp:710-714
    [[nodiscard]] virtual query_engine::QueryResult executeQuery(const std::string& query) const;
+
+   /// The position range [begin, end) of a genome of `length` positions that this rank holds.
+   [[nodiscard]] std::pair<uint32_t, uint32_t> positionWindow(size_t length) const;
 
    // --- construction (replaces Preprocessor::buildDatabase, preprocessor.cpp:447-503) -----------
    void setReferenceGenomes(const json::Value& reference_genomes);

@@ -46,13 +46,21 @@ std::unique_ptr<Operator> symbolPlane(
    const SequenceStorePartition<SymbolType>& store, const DatabasePartition& partition, uint32_t position, typename SymbolType::Symbol symbol
 ) {
    const RowSpace rows = rowsOf(partition);
+   if (!store.holds(position)) {
+      // position-range sharding keeps only a slice of the genome per rank; exchanging filter leaves
+      // between ranks is the next step, so such a leaf is an internal error for now.
+      throw std::runtime_error(
+         "position " + std::to_string(position + 1) + " is not resident on this rank (position-range shard " +
+         std::to_string(store.position_begin + 1) + ".." + std::to_string(store.position_end) + ")"
+      );
+   }
    const uint64_t* plane = store.getBitmap(position, symbol);
    if (symbol == SymbolType::SYMBOL_MISSING) {
       // nucleotide_symbol_equals.cpp:131-143 / aa_symbol_equals.cpp:55-62
       return std::make_unique<operators::BitmapSelection>(plane, rows, operators::BitmapSelection::CONTAINS, position);
    }
    if (plane == nullptr) {
-      return std::make_unique<operators::IndexScan>(store.seqstore_id, position, static_cast<uint32_t>(symbol), rows);
+      return std::make_unique<operators::IndexScan>(store.seqstore_id, position - store.position_begin, static_cast<uint32_t>(symbol), rows);
    }
    return std::make_unique<operators::IndexScan>(plane, rows);
 }

@@ -59,6 +59,8 @@ class SynthDesc(ctypes.Structure):
         ("lineage_symbol", c_u8p),
         ("private_threshold", ctypes.c_uint32),
         ("ambiguous_threshold", ctypes.c_uint32),
+        ("position_offset", ctypes.c_uint32),
+        ("total_positions", ctypes.c_uint32),
     ]
 
 
@@ -287,7 +289,7 @@ class GpuStore:
             arrays["lineage"].ctypes.data_as(c_u16p), arrays["lead"].ctypes.data_as(c_u32p),
             arrays["trail"].ctypes.data_as(c_u32p), arrays["mstart"].ctypes.data_as(c_u32p),
             arrays["mlen"].ctypes.data_as(c_u32p), arrays["table"].ctypes.data_as(c_u8p),
-            model.private_threshold, model.ambiguous_threshold,
+            model.private_threshold, model.ambiguous_threshold, 0, 0,
         )
         _check(self.lib.silo_gpu_store_generate_synthetic(self.handle, seqstore_id, ctypes.byref(desc)))
 

@@ -17,7 +17,8 @@ EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
     "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_execute_query", "silo_engine_free_string",
-    "silo_engine_last_timings", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_last_error",
+    "silo_engine_last_timings", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
+    "silo_engine_last_error",
 ]
 
 ALL_REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -53,6 +54,7 @@ def load_library():
     lib.silo_engine_partition_store.argtypes = [vp, ctypes.c_int]
     lib.silo_engine_partition_store.restype = vp
     lib.silo_engine_seqstore_id.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    lib.silo_engine_position_window.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     lib.silo_engine_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib
@@ -140,16 +142,19 @@ class Engine:
             self.handle, partition, name.encode(), int(is_aa), first_sequence, n, chars.ctypes.data_as(ctypes.c_void_p),
             is_null.ctypes.data_as(ctypes.c_void_p)))
 
-    def generate_synthetic(self, partition, name, is_aa, model):
+    def generate_synthetic(self, partition, name, is_aa, model, window=None):
+        """window = (begin, end): the position-range shard this rank's store holds (None = all)."""
+        begin, end = window if window is not None else (0, model.positions)
         arrays = [
             np.ascontiguousarray(model.lineage_of_sequence, dtype=np.uint16), np.ascontiguousarray(model.lead_gap, dtype=np.uint32),
             np.ascontiguousarray(model.trail_gap, dtype=np.uint32), np.ascontiguousarray(model.missing_start, dtype=np.uint32),
-            np.ascontiguousarray(model.missing_len, dtype=np.uint32), np.ascontiguousarray(model.lineage_symbol, dtype=np.uint8),
+            np.ascontiguousarray(model.missing_len, dtype=np.uint32),
+            np.ascontiguousarray(model.lineage_symbol[begin:end], dtype=np.uint8),
         ]
         desc = binding.SynthDesc(
             model.seed, model.n_lineages, arrays[0].ctypes.data_as(binding.c_u16p), arrays[1].ctypes.data_as(binding.c_u32p),
             arrays[2].ctypes.data_as(binding.c_u32p), arrays[3].ctypes.data_as(binding.c_u32p), arrays[4].ctypes.data_as(binding.c_u32p),
-            arrays[5].ctypes.data_as(binding.c_u8p), model.private_threshold, model.ambiguous_threshold)
+            arrays[5].ctypes.data_as(binding.c_u8p), model.private_threshold, model.ambiguous_threshold, begin, model.positions)
         _check(self.lib.silo_engine_generate_synthetic(self.handle, partition, name.encode(), int(is_aa), ctypes.byref(desc)))
 
     def set_lineage_column(self, partition, column, values):
@@ -203,6 +208,11 @@ class Engine:
         filter_us, action_us = ctypes.c_int64(), ctypes.c_int64()
         self.lib.silo_engine_last_timings(ctypes.byref(filter_us), ctypes.byref(action_us))
         return filter_us.value, action_us.value
+
+    def position_window(self, name, is_aa):
+        begin, end = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(self.lib.silo_engine_position_window(self.handle, name.encode(), int(is_aa), ctypes.byref(begin), ctypes.byref(end)))
+        return begin.value, end.value
 
     def partition_store(self, partition):
         return StoreView(self.lib.silo_engine_partition_store(self.handle, partition))
