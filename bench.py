@@ -104,6 +104,18 @@ def time_kernel(engine, tree, window, reps):
     return ms, kernel, store, filt, counts
 
 
+def cpu_share():
+    """CPU threads this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    share = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            share = min(share, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, share)
+
+
 def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_positions):
     """The reference's algorithm (roaring-format containers, OpenMP over positions) on a bounded sample of
     positions of the same synthetic store; its counts are checked against the GPU's on the same positions."""
@@ -112,7 +124,8 @@ def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_position
     from oracle import cpu_port, dense
     from silo_amd import binding
 
-    threads = cpu_port.max_threads()
+    threads = max(1, min(cpu_port.max_threads(), cpu_share()))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     n_positions = max(threads, budget_positions // threads * threads)
     begin = (model.positions // 2) // 64 * 64
     t0 = time.time()
