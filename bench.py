@@ -247,6 +247,17 @@ def main():
     kernel_ms, kernel_name, store, filt, counts_dev = time_kernel(engine, tree, window, reps=max(5, args.steps))
     alg_bytes = n_local * 5 * w8 + w8
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic of the same launch shape from the committed rocprofv3 PMC passes (tools/rocprof_summary.py):
+    # counters cannot be read in-process, so this is null unless a profile of exactly this grid is on file.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        grid = -(-store.row_words // 2048) * -(-(n_local * 5) // 256) * 256
+        entry = pmc["kernels"].get(f"k_scan_tiled<8>@{grid}")
+        if entry is not None:
+            traffic = entry["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     result = {
         "metric": "Mutations-scan positions*sequences/s",
@@ -276,7 +287,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "kernel": kernel_name,
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes,

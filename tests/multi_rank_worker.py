@@ -1,0 +1,118 @@
+"""Worker of tests/test_multi_rank.py: one rank of a gloo group (RANK / WORLD_SIZE / MASTER_* from the env).
+
+mode "cpu":  host-side sharding logic only (no GPU): the engine's position windows + oracle counts per
+             window, summed with a gloo all-reduce, must equal the unsharded oracle counts.
+mode "gpu":  the real engine on cuda:0 in every rank (a 1-GPU box), sharded by position or by
+             sequence id; the engine's all-reduce callback is backed by gloo through host memory.
+Prints one JSON line from rank 0.
+"""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "lapis-silo_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from oracle import dense  # noqa: E402
+from oracle import synth as oracle_synth  # noqa: E402
+from silo_amd import synth  # noqa: E402
+from silo_amd.engine import Engine  # noqa: E402
+
+N, P, L = 5000, 997, 60
+
+
+def genomes():
+    ref = synth.random_reference(P, "nuc", 3)
+    gene = synth.random_reference(211, "aa", 4)
+    doc = {
+        "nucleotideSequences": [{"name": "main", "sequence": "".join("-ACGT"[s] for s in ref)}],
+        "genes": [{"name": "S", "sequence": "".join("-ACDEFGHIKLMNPQRSTVWYBZ*X"[s] for s in gene)}],
+    }
+    return doc, ref, gene
+
+
+def main():
+    mode, shard = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    doc, ref, gene = genomes()
+    tree = synth.make_lineage_tree(L)
+    lineage = synth.assign_lineages(N, tree, 11)
+    models = {
+        "main": synth.make_model(N, ref, "nuc", tree, lineage, seed=5, store_index=0),
+        "S": synth.make_model(N, gene, "aa", tree, lineage, seed=5, store_index=1),
+    }
+    member = tree.subtree(1)
+    by_position = shard == "position"
+
+    if mode == "cpu":
+        engine = Engine(doc)
+        engine.set_sharding(rank, world, True)
+        out = {}
+        for name, is_aa, symbols in (("main", False, [0, 1, 2, 3, 4]), ("S", True, list(range(21)) + [23])):
+            begin, end = engine.position_window(name, is_aa)
+            windows = [None] * world
+            dist.all_gather_object(windows, (begin, end))
+            sym = oracle_synth.symbol_matrix(models[name], np.arange(N), np.arange(begin, end))
+            mask = member[lineage].astype(bool)
+            table = np.zeros((models[name].positions, len(symbols)), dtype=np.int64)
+            table[begin:end] = dense.mutation_counts(sym, mask, symbols)
+            tensor = torch.from_numpy(table)
+            dist.all_reduce(tensor)
+            if rank == 0:
+                full = oracle_synth.symbol_matrix(models[name], np.arange(N), np.arange(models[name].positions))
+                want = dense.mutation_counts(full, mask, symbols)
+                out[name] = {"windows": windows, "equal": bool(np.array_equal(tensor.numpy(), want))}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        return
+
+    # ---- gpu mode -------------------------------------------------------------------------------
+    from silo_amd import binding
+
+    lib = binding.load_library()
+
+    def all_reduce(device_ptr, n, _stream):
+        host = np.empty(n, dtype=np.int32)
+        binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, host.nbytes, None))
+        tensor = torch.from_numpy(host)
+        dist.all_reduce(tensor)
+        binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, None))
+
+    engine = Engine(doc)
+    engine.set_sharding(rank, world, by_position, all_reduce)
+    if by_position:
+        rows = slice(0, N)
+    else:
+        rows = slice(N * rank // world, N * (rank + 1) // world)
+    n_local = rows.stop - rows.start
+    part = engine.add_partition(n_local)
+    for name, is_aa in (("main", False), ("S", True)):
+        begin, end = engine.position_window(name, is_aa)
+        sym = oracle_synth.symbol_matrix(models[name], np.arange(rows.start, rows.stop), np.arange(begin, end))
+        chars = np.frombuffer(b"-ACGTRYSWKMBDHVN" if not is_aa else b"-ACDEFGHIKLMNPQRSTVWYBZ*X", dtype=np.uint8)[sym]
+        engine.append_sequences(part, name, is_aa, 0, [bytes(row).decode("latin-1") for row in chars])
+    engine.set_lineage_column_ids(part, "pango_lineage", tree.names, lineage[rows])
+    engine.finalize()
+    queries = [
+        {"action": {"type": "Mutations", "minProportion": 0.02}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": True}},
+        {"action": {"type": "AminoAcidMutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
+        {"action": {"type": "Mutations", "minProportion": 0.5}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.2.3", "includeSublineages": False}},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": True}},
+    ]
+    results = [engine.execute_raw(q) for q in queries]
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(results), flush=True)
+    engine.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""CPU-side checks: the native libraries load and export every declared symbol, the bit-program
+instruction semantics (shared header, g++ build), and the product's loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import dense
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(silo_(?:gpu|engine)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_libsilo_gpu_exports_every_declared_symbol(built):
+    from silo_amd import binding
+
+    lib = binding.load_library()
+    declared = [name for name in declared_functions("silo_gpu.h") if not name.endswith("_desc")]
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(binding.EXPORTED_SYMBOLS) == sorted(declared)
+
+
+def test_libsilo_engine_exports_every_declared_symbol(built):
+    from silo_amd import engine
+
+    lib = engine.load_library()
+    declared = [n for n in declared_functions("silo_engine.h") if n.startswith("silo_engine_") and n != "silo_engine_all_reduce_u32"]
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(engine.EXPORTED_SYMBOLS) == sorted(declared)
+
+
+def test_product_fails_loudly_without_a_gpu(built):
+    import subprocess
+    import sys
+
+    # run in a child so that a visible GPU on the test box does not change the outcome
+    code = (
+        "import sys; sys.path[:0]=[%r, %r]\n"
+        "import numpy as np\n"
+        "from silo_amd import binding\n"
+        "try:\n"
+        "    binding.GpuStore(8, [dict(name='m', alphabet='nuc', reference=np.ones(4, dtype=np.uint8))])\n"
+        "    print('CREATED')\n"
+        "except binding.SiloGpuError as e:\n"
+        "    print('ERR', e.code)\n"
+    ) % (ROOT, os.path.join(ROOT, "lapis-silo_amd"))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout
+    assert "ERR -4" in out, out  # SILO_GPU_ERR_NO_DEVICE: there is no CPU fallback
+
+
+@pytest.fixture(scope="module")
+def bitprog(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "lapis-silo_amd", "lib", "libbitprog_host.so"))
+    lib.bitprog_eval_host.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+
+    def run(code, masks, n):
+        n_words = (n + 63) // 64 + 1  # one padding word: must come out zero
+        code = np.ascontiguousarray(code, dtype=np.uint32)
+        leaves = np.zeros((max(1, len(masks)), n_words), dtype=np.uint64)
+        for k, mask in enumerate(masks):
+            words = dense.pack_bits(mask)
+            leaves[k, : len(words)] = words
+        out = np.zeros(n_words, dtype=np.uint64)
+        lib.bitprog_eval_host(code.ctypes.data, len(code) // 2, leaves.ctypes.data, len(masks), n_words, n, out.ctypes.data)
+        assert out[-1] == 0
+        return dense.unpack_bits(out, n)
+
+    return run
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 1000])
+def test_bitprog_semantics(bitprog, n):
+    from silo_amd import binding as b
+
+    rng = np.random.default_rng(n)
+    masks = [rng.random(n) < p for p in (0.5, 0.3, 0.8, 0.1, 0.6, 0.5, 0.9)]
+    full = np.ones(n, bool)
+    assert np.array_equal(bitprog(b.encode(b.OP_ONES, 0), [], n), full)
+    assert np.array_equal(bitprog(b.encode(b.OP_ZERO, 0) + b.encode(b.OP_NOT, 0, 0), [], n), full)
+    code = (b.encode(b.OP_LOAD, 1, imm=0) + b.encode(b.OP_LOAD, 2, imm=1) + b.encode(b.OP_ANDNOT, 3, 1, 2)
+            + b.encode(b.OP_LOAD, 1, imm=2) + b.encode(b.OP_OR, 3, 3, 1) + b.encode(b.OP_MOV, 0, 3))
+    assert np.array_equal(bitprog(code, masks, n), (masks[0] & ~masks[1]) | masks[2])
+    total = sum(m.astype(int) for m in masks)
+    for k in range(0, 10):
+        code = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3)
+        for leaf in range(7):
+            code += b.encode(b.OP_LOAD, 0, imm=leaf) + b.encode(b.OP_CNT_ADD, 1, 0, 3)
+        assert np.array_equal(bitprog(code + b.encode(b.OP_CNT_GE, 0, 1, 3, imm=k), masks, n), total >= k), k
+        assert np.array_equal(bitprog(code + b.encode(b.OP_CNT_EQ, 0, 1, 3, imm=k), masks, n), total == k), k
