@@ -42,6 +42,7 @@ int fail(int code, const std::string& msg) {
    do {                                                                                        \
       hipError_t err_ = (expr);                                                                \
       if (err_ != hipSuccess) {                                                                \
+         (void)hipGetLastError(); /* clear the sticky error so later launch checks start clean */ \
          return fail(                                                                          \
             err_ == hipErrorOutOfMemory ? SILO_GPU_ERR_OUT_OF_MEMORY : SILO_GPU_ERR_HIP,       \
             std::string(#expr) + ": " + hipGetErrorString(err_)                                \

@@ -122,6 +122,9 @@ def load_library():
     lib.silo_gpu_free.restype = None
     lib.silo_gpu_malloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.silo_gpu_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_upload_u32.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.silo_gpu_bitset_from_value_ids.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
     lib.silo_gpu_stream_synchronize.argtypes = [vp]
     lib.silo_gpu_store_plane.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.silo_gpu_store_plane.restype = vp
