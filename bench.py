@@ -49,7 +49,7 @@ def load_reference_genomes():
     return {"nucleotideSequences": [g for g in genomes["nucleotideSequences"] if g["name"] == "main"], "genes": []}
 
 
-def build_engine(n_sequences, rank, world, all_reduce, device):
+def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False):
     from silo_amd import alphabet, synth
     from silo_amd.engine import Engine
 
@@ -59,7 +59,7 @@ def build_engine(n_sequences, rank, world, all_reduce, device):
     lineage = synth.assign_lineages(n_sequences, tree, synth.DEFAULT_SEED)
     model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
     engine = Engine(genomes, device=device)
-    if world > 1:
+    if world > 1 or sharded:
         engine.set_sharding(rank, world, True, all_reduce)
     partition = engine.add_partition(n_sequences)
     window = engine.position_window("main", False)
@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--sequences", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
+    ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed / RCCL path even with one rank (testing)")
     ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     args = ap.parse_args()
 
@@ -195,16 +196,24 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    from silo_amd import binding
-
-    lib = binding.load_library()
     all_reduce = None
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        # torch FIRST: it bundles its own HIP runtime under the same SONAME as /opt/rocm's; whichever is
+        # loaded first serves the whole process, and torch only works with its own.
         import torch
         import torch.distributed as dist
 
+    from silo_amd import binding
+
+    lib = binding.load_library()
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -226,14 +235,14 @@ def main():
             binding._check(lib.silo_gpu_stream_synchronize(None))
 
     t0 = time.time()
-    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank)
+    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank, use_dist)
     log(f"[rank {rank}] store ready in {time.time() - t0:.1f}s: {args.sequences} sequences, positions {window}, "
         f"{engine.partition_store(0).device_bytes / 1e9:.1f} GB in HBM")
     query = make_query()
     positions = model.positions
 
     elapsed, rows = run_steps(engine, query, args.steps, args.warmup, sync)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -278,7 +287,7 @@ def main():
             "sequences": args.sequences,
             "positions": positions,
             "mutation_rows": len(rows),
-            "sharding": "none" if world == 1 else f"position-range x{world}, all-reduce of counts[{positions}][5] over RCCL",
+            "sharding": "none" if not use_dist else f"position-range x{world}, all-reduce of counts[{positions}][5] over RCCL",
             "reference_phases_us": {"filter": filter_us, "action": action_us},
         },
         "roofline": {
@@ -309,7 +318,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_also and args.sequences != 1_000_000:
         # BASELINE.json configs[1]: 1 M sequences, same query
-        engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank)
+        engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank)  # no collective
         elapsed1, rows1 = run_steps(engine1, query, args.steps, args.warmup, sync)
         kernel_ms1, _, _, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
         w81 = 8 * ((1_000_000 + 63) // 64)
@@ -326,7 +335,7 @@ def main():
         lib.silo_gpu_free(counts1)
         engine1.close()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

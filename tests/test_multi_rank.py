@@ -57,33 +57,20 @@ def test_two_ranks_match_one_rank_gpu(built, shard):
 
 
 @pytest.mark.gpu
-def test_torch_can_alias_engine_device_memory(built):
-    """bench.py's RCCL leg wraps the engine's count buffer in a torch tensor through
-    __cuda_array_interface__ (int32 view): check the aliasing and that kernels still run with torch's
-    HIP runtime loaded in the same process."""
-    import ctypes
-
-    import numpy as np
-    import torch
-
-    from silo_amd import binding
-
-    assert torch.cuda.is_available()
-    torch.zeros(1, device="cuda")  # initialise torch's runtime first
-    ref = np.ones(5, dtype=np.uint8)
-    with binding.GpuStore(1000, [dict(name="m", alphabet="nuc", reference=ref)]) as store:
-        buf = store.malloc(4 * 16)
-        store.memset(buf, 0, 64)
-
-        class View:
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-
-        tensor = torch.as_tensor(View(buf.value, 16), device="cuda")
-        tensor += torch.arange(16, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        assert np.array_equal(store.read(buf, np.uint32, 16), np.arange(16, dtype=np.uint32))
-        store.append_sequences(0, 0, ["ACGTN"] * 1000)
-        store.finalize()
-        counts = store.mutations_scan(0)
-        assert counts[:, 1:].diagonal().tolist() == [1000, 1000, 1000, 1000] and counts[4].sum() == 0
+def test_bench_rccl_path_on_one_gpu(built):
+    """bench.py --force-dist: torch.distributed (nccl = RCCL) initialised on one rank, the engine's count
+    table aliased as a torch tensor through __cuda_array_interface__ and all-reduced, with torch's HIP
+    runtime serving the kernels.  Must give the same rows as the plain single-process run."""
+    root = os.path.dirname(HERE)
+    common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--sequences", "200000", "--steps", "2", "--warmup", "1",
+              "--no-also", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run(common, capture_output=True, text=True, env=env, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = subprocess.run(common + ["--force-dist"], capture_output=True, text=True, env=env, timeout=900)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(forced.stdout.strip().splitlines()[-1])
+    assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
+    assert b["config"]["sharding"].startswith("position-range x1")
+    assert b["roofline"]["frac"] > 0.05
