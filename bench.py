@@ -166,6 +166,73 @@ def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_position
     }
 
 
+def filter_query(model, tree):
+    """BASELINE.json configs[2] / SURVEY.md §8d C3: And(Or(8 eq), N-Of(3 of 8 eq), Not(Or(8 eq)), Maybe(And(8 eq)))
+    over 32 distinct (position, symbol) leaves at the positions where most sequences carry a substitution."""
+    carried = model.lineage_symbol != 0xFF                      # [P][L]
+    weight = carried.astype(np.float64) @ tree.weights          # share of sequences substituted per position
+    positions = np.argsort(-weight, kind="stable")[:32]
+    leaves = []
+    for p in positions:
+        lineages = np.nonzero(carried[p])[0]
+        symbol = int(model.lineage_symbol[p][lineages[np.argmax(tree.weights[lineages])]])
+        leaves.append({"type": "NucleotideEquals", "position": int(p) + 1, "symbol": "-ACGT"[symbol]})
+    return json.dumps({
+        "action": {"type": "Aggregated"},
+        "filterExpression": {"type": "And", "children": [
+            {"type": "Or", "children": leaves[0:8]},
+            {"type": "N-Of", "numberOfMatchers": 3, "matchExactly": False, "children": leaves[8:16]},
+            {"type": "Not", "child": {"type": "Or", "children": leaves[16:24]}},
+            {"type": "Maybe", "child": {"type": "And", "children": leaves[24:32]}},
+        ]},
+    })
+
+
+def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
+    """Filter -> Aggregated queries per second: sequential latency and 8 client threads on one engine."""
+    import threading
+
+    query = filter_query(model, tree)
+    count = engine.execute_query(query)[0]["count"]   # also warms the lineage / sparse-plane caches
+    for _ in range(5):
+        engine.execute_query(query)
+    sync()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        engine.execute_query(query)
+        n += 1
+    sequential = (time.perf_counter() - t0) / n
+
+    done = []
+
+    def client():
+        k = 0
+        end = time.perf_counter() + seconds
+        while time.perf_counter() < end:
+            engine.execute_query(query)
+            k += 1
+        done.append(k)
+
+    threads = [threading.Thread(target=client) for _ in range(8)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    concurrent = sum(done) / (time.perf_counter() - t0)
+    w8 = 8 * ((n_sequences + 63) // 64)
+    return {
+        "workload": f"BASELINE.json configs[2]: And(Or(8), 3-of-8, Not(Or(8)), Maybe(And(8))) over 32 NucleotideEquals leaves "
+                    f"-> Aggregated, {n_sequences} sequences",
+        "count": count,
+        "latency_us": sequential * 1e6,
+        "queries_per_s_1_client": 1.0 / sequential,
+        "queries_per_s_8_clients": concurrent,
+        "algorithmic_bytes_per_query": 32 * w8,
+    }
+
+
 def run_steps(engine, query, steps, warmup, sync):
     for _ in range(warmup):
         engine.execute_query(query)
@@ -312,6 +379,8 @@ def main():
             raise
         except Exception as error:  # the baseline is informational; a failure to build it must not hide the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
+    if rank == 0 and world == 1 and not use_dist and not args.no_also:
+        result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
     lib.silo_gpu_free(filt)
     lib.silo_gpu_free(counts_dev)
     engine.close()

@@ -166,6 +166,12 @@ enum {
    SILO_GPU_OP_MOV = 10      /* dst = a */
 };
 enum { SILO_GPU_MAX_INSTRUCTIONS = 320, SILO_GPU_MAX_LEAVES = 128, SILO_GPU_MAX_SLOTS = 32 };
+/* A source operand (a, b) >= SILO_GPU_LEAF_OPERAND reads leaf (operand - SILO_GPU_LEAF_OPERAND) directly, so a
+ * leaf needs no LOAD instruction of its own; destinations are always slots. */
+enum { SILO_GPU_LEAF_OPERAND = 32 };
+/* Cardinalities are accumulated into SILO_GPU_COUNT_SHARDS consecutive uint64 counters (to keep device
+ * atomics off a single word); the total is their sum.  Buffers passed as out_count_dev have that many. */
+enum { SILO_GPU_COUNT_SHARDS = 64 };
 
 typedef struct {
    uint32_t n_instructions;
@@ -175,15 +181,15 @@ typedef struct {
    uint32_t n_slots;                /* slots used, <= SILO_GPU_MAX_SLOTS */
 } silo_gpu_bitprog;
 
-/* out_bitset_dev (Wp words) and/or out_count_dev (one uint64, ACCUMULATED into, so the caller can
- * sum partitions like aggregated.cpp:58-66) may be NULL. */
+/* out_bitset_dev (Wp words) and/or out_count_dev (SILO_GPU_COUNT_SHARDS uint64, ACCUMULATED into, so the
+ * caller can sum partitions like aggregated.cpp:58-66) may be NULL. */
 int silo_gpu_filter_eval(
    const silo_gpu_store* store, const silo_gpu_bitprog* program,
    uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream
 );
 
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
-int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* accumulated */, void* stream);
+int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* shards, accumulated */, void* stream);
 
 /* ---- K1: Mutations scan (mutations.cpp:64-164) ---------------------------------------------------
  * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & plane[p][scan_symbols[s]])

@@ -331,10 +331,21 @@ __global__ __launch_bounds__(256) void k_scan_rowwave(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: popcount of one row-sized bitset, accumulated into *out
+// Cardinalities are accumulated into SILO_GPU_COUNT_SHARDS 64-bit counters (shard = block % shards):
+// thousands of waves adding to ONE word serialise at ~12 ns per atomic (the guide's "dequeue" row);
+// spreading them over 64 words removes that tail.  The host sums the shards.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void addToCountShard(unsigned long long* shards, uint32_t wave_total_lane63) {
+   if ((threadIdx.x & 63u) == 63u && wave_total_lane63 != 0) {
+      atomicAdd(shards + (blockIdx.x % SILO_GPU_COUNT_SHARDS), static_cast<unsigned long long>(wave_total_lane63));
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: popcount of one row-sized bitset
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_popcount(
-   const uint64_t* __restrict__ bitset, uint32_t row_words, unsigned long long* __restrict__ out
+   const uint64_t* __restrict__ bitset, uint32_t row_words, unsigned long long* __restrict__ out_shards
 ) {
    const uint32_t n_chunks = row_words / 2;
    uint32_t acc = 0;
@@ -342,24 +353,27 @@ __global__ __launch_bounds__(256) void k_popcount(
       const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(bitset + 2 * chunk);
       acc += static_cast<uint32_t>(__popcll(v.x)) + static_cast<uint32_t>(__popcll(v.y));
    }
-   acc = waveSumToLane63(acc);
-   if ((threadIdx.x & 63u) == 63u && acc != 0) {
-      atomicAdd(out, static_cast<unsigned long long>(acc));
-   }
+   addToCountShard(out_shards, waveSumToLane63(acc));
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: fused filter evaluator.  One program run per bitset word; slots live in LDS as
-// [slot][thread] so every ds_read_b64 / ds_write_b64 is conflict-free; the program itself sits in
-// the kernel-argument segment and is fetched with scalar loads (uniform control flow).
+// K3: fused filter evaluator.  One wave per block, one bitset word per lane.
+//   phase 1  every leaf word of this lane is fetched from HBM into LDS, 8 independent loads in flight at
+//            a time (a plain interpreter would issue one dependent load per LOAD instruction);
+//   phase 2  the bit-program runs out of LDS: slots and leaves live as [index][lane], so every
+//            ds_read_b64 / ds_write_b64 is conflict-free; operands >= SILO_GPU_LEAF_OPERAND address a
+//            leaf directly, so no LOAD instruction is needed.  The program itself sits in the
+//            kernel-argument segment and is fetched with scalar loads (uniform control flow).
 // ------------------------------------------------------------------------------------------------
-constexpr int EVAL_THREADS = 256;
+constexpr int EVAL_THREADS = 64;
 
 struct FilterEvalArgs {
    uint32_t n_instructions;
    uint32_t sequence_count;
    uint32_t row_words;
    uint32_t n_slots;
+   uint32_t n_leaves;
+   uint32_t pad;
    uint64_t* out;
    unsigned long long* out_count;
    const uint64_t* leaves[SILO_GPU_MAX_LEAVES];
@@ -367,28 +381,47 @@ struct FilterEvalArgs {
 };
 
 __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
-   extern __shared__ uint64_t s_slots[];  // [n_slots][EVAL_THREADS]
-   const uint32_t tid = threadIdx.x;
-   uint32_t local_count = 0;
-   for (uint32_t w = blockIdx.x * EVAL_THREADS + tid; w < args.row_words; w += gridDim.x * EVAL_THREADS) {
-      const uint64_t valid = silo_gpu::valid_mask(w, args.sequence_count);
-      const uint64_t result = silo_gpu::bitprog_run_word(
+   extern __shared__ uint64_t s_mem[];  // [n_slots + n_leaves][EVAL_THREADS]
+   const uint32_t lane = threadIdx.x;
+   const uint32_t w = blockIdx.x * EVAL_THREADS + lane;
+   const bool active = w < args.row_words;
+   const uint32_t w_safe = active ? w : 0;
+   uint64_t* leaf_area = s_mem + args.n_slots * EVAL_THREADS;
+
+   constexpr uint32_t BATCH = 8;
+   for (uint32_t first = 0; first < args.n_leaves; first += BATCH) {
+      uint64_t value[BATCH];
+#pragma unroll
+      for (uint32_t k = 0; k < BATCH; ++k) {  // clamped index: no load sits under a branch
+         value[k] = args.leaves[min(first + k, args.n_leaves - 1)][w_safe];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < BATCH; ++k) {
+         if (first + k < args.n_leaves) {
+            leaf_area[(first + k) * EVAL_THREADS + lane] = value[k];
+         }
+      }
+   }
+
+   const uint64_t valid = active ? silo_gpu::valid_mask(w, args.sequence_count) : 0;
+   const uint32_t n_slots = args.n_slots;
+   const uint64_t result =
+      silo_gpu::bitprog_run_word(
          args.code,
          args.n_instructions,
          valid,
-         [&](uint32_t slot) -> uint64_t& { return s_slots[slot * EVAL_THREADS + tid]; },
-         [&](uint32_t leaf) -> uint64_t { return args.leaves[leaf][w]; }
-      ) & valid;
-      if (args.out != nullptr) {
-         args.out[w] = result;
-      }
-      local_count += static_cast<uint32_t>(__popcll(result));
+         [&](uint32_t index) -> uint64_t& {
+            const uint32_t row = index < SILO_GPU_LEAF_OPERAND ? index : n_slots + (index - SILO_GPU_LEAF_OPERAND);
+            return s_mem[row * EVAL_THREADS + lane];
+         },
+         [&](uint32_t leaf) -> uint64_t { return leaf_area[leaf * EVAL_THREADS + lane]; }
+      ) &
+      valid;
+   if (active && args.out != nullptr) {
+      args.out[w] = result;
    }
    if (args.out_count != nullptr) {
-      local_count = waveSumToLane63(local_count);
-      if ((tid & 63u) == 63u && local_count != 0) {
-         atomicAdd(args.out_count, static_cast<unsigned long long>(local_count));
-      }
+      addToCountShard(args.out_count, waveSumToLane63(static_cast<uint32_t>(__popcll(result))));
    }
 }
 
@@ -1260,6 +1293,7 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
    if (!seqstore.finalized) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "store not finalized");
    }
+   HIP_TRY(hipSetDevice(store->device));
    auto hip_stream = static_cast<hipStream_t>(stream);
    HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(store->row_words) * sizeof(uint64_t), hip_stream));
    const uint64_t key_begin = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32);
@@ -1279,6 +1313,7 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
    if (store == nullptr || program == nullptr || program->code == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
    }
+   HIP_TRY(hipSetDevice(store->device));  // a new host thread starts on device 0
    if (program->n_instructions == 0 || program->n_instructions > SILO_GPU_MAX_INSTRUCTIONS ||
        program->n_leaves > SILO_GPU_MAX_LEAVES || program->n_slots == 0 || program->n_slots > SILO_GPU_MAX_SLOTS) {
       return fail(SILO_GPU_ERR_PROGRAM_TOO_LARGE, "bit-program exceeds the instruction / leaf / slot limits");
@@ -1289,9 +1324,14 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
       const uint32_t imm = program->code[2 * pc + 1];
       const uint32_t op = w0 & 0xFFu, dst = (w0 >> 8) & 0xFFu, a = (w0 >> 16) & 0xFFu, b = (w0 >> 24) & 0xFFu;
       bool ok = true;
+      // a readable operand is a slot or, from SILO_GPU_LEAF_OPERAND up, a leaf
+      const auto readable = [&](uint32_t operand) {
+         return operand < program->n_slots ||
+                (operand >= SILO_GPU_LEAF_OPERAND && operand - SILO_GPU_LEAF_OPERAND < program->n_leaves);
+      };
       switch (op) {
          case SILO_GPU_OP_LOAD:
-            ok = dst < program->n_slots && imm < program->n_leaves && program->leaves != nullptr && program->leaves[imm] != nullptr;
+            ok = dst < program->n_slots && imm < program->n_leaves;
             break;
          case SILO_GPU_OP_ZERO:
          case SILO_GPU_OP_ONES:
@@ -1299,15 +1339,15 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
             break;
          case SILO_GPU_OP_NOT:
          case SILO_GPU_OP_MOV:
-            ok = dst < program->n_slots && a < program->n_slots;
+            ok = dst < program->n_slots && readable(a);
             break;
          case SILO_GPU_OP_AND:
          case SILO_GPU_OP_OR:
          case SILO_GPU_OP_ANDNOT:
-            ok = dst < program->n_slots && a < program->n_slots && b < program->n_slots;
+            ok = dst < program->n_slots && readable(a) && readable(b);
             break;
          case SILO_GPU_OP_CNT_ADD:
-            ok = a < program->n_slots && b >= 1 && dst + b <= program->n_slots;
+            ok = readable(a) && b >= 1 && dst + b <= program->n_slots;
             break;
          case SILO_GPU_OP_CNT_GE:
          case SILO_GPU_OP_CNT_EQ:
@@ -1320,19 +1360,35 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
          return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "bit-program instruction " + std::to_string(pc) + " has an invalid operand");
       }
    }
+   for (uint32_t k = 0; k < program->n_leaves; ++k) {
+      if (program->leaves == nullptr || program->leaves[k] == nullptr) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "bit-program leaf " + std::to_string(k) + " is null");
+      }
+   }
    FilterEvalArgs args{};
    args.n_instructions = program->n_instructions;
    args.sequence_count = store->sequence_count;
    args.row_words = store->row_words;
    args.n_slots = program->n_slots;
+   args.n_leaves = program->n_leaves;
    args.out = out_bitset_dev;
    args.out_count = reinterpret_cast<unsigned long long*>(out_count_dev);
    for (uint32_t k = 0; k < program->n_leaves; ++k) {
       args.leaves[k] = program->leaves[k];
    }
    memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
-   const uint32_t blocks = std::min<uint32_t>((store->row_words + EVAL_THREADS - 1) / EVAL_THREADS, 2048u);
-   const size_t lds_bytes = static_cast<size_t>(program->n_slots) * EVAL_THREADS * sizeof(uint64_t);
+   const uint32_t blocks = (store->row_words + EVAL_THREADS - 1) / EVAL_THREADS;
+   const size_t lds_bytes = static_cast<size_t>(program->n_slots + program->n_leaves) * EVAL_THREADS * sizeof(uint64_t);
+   if (lds_bytes > 64 * 1024) {  // up to (32 + 128) * 512 B = 80 KiB of the CU's 160 KiB
+      static std::once_flag raised;
+      hipError_t attribute_error = hipSuccess;
+      std::call_once(raised, [&] {
+         attribute_error = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(k_filter_eval), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024
+         );
+      });
+      HIP_TRY(attribute_error);
+   }
    k_filter_eval<<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
@@ -1342,6 +1398,7 @@ int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, u
    if (store == nullptr || bitset_dev == nullptr || out_count_dev == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_popcount: bad arguments");
    }
+   HIP_TRY(hipSetDevice(store->device));  // a new host thread starts on device 0
    const uint32_t chunks = store->row_words / 2;
    const uint32_t blocks = std::min<uint32_t>((chunks + 255) / 256, 1024u);
    k_popcount<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
@@ -1358,6 +1415,7 @@ int silo_gpu_mutations_scan(
    if (store == nullptr || seqstore_id >= store->seqstores.size() || counts_out_dev == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan: bad arguments");
    }
+   HIP_TRY(hipSetDevice(store->device));
    const SeqStoreDev& dev = store->seqstores[seqstore_id].dev;
    if (pos_begin > pos_end || pos_end > dev.positions) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");

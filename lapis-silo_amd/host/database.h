@@ -190,6 +190,12 @@ class DatabasePartition {
    mutable std::mutex totals_mutex;
    mutable std::map<uint32_t, std::vector<uint32_t>> full_counts;
 
+   /// Materialised bitsets of sparsely stored symbols (IUPAC ambiguity codes), keyed by
+   /// seqstore << 40 | local position << 8 | symbol; filled on first use by ProgramBuilder::sparseLeaf.
+   static constexpr size_t SPARSE_CACHE_BYTES = size_t{2} << 30;
+   mutable std::mutex sparse_cache_mutex;
+   mutable std::map<uint64_t, DeviceBuffer> sparse_cache;
+
    [[nodiscard]] uint32_t rowWords() const { return silo_gpu_store_row_words(store); }
 
    template <typename SymbolType>

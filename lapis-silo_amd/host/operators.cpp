@@ -29,11 +29,26 @@ const RowSpace& OperatorResult::rows() const {
 
 namespace {
 
-uint32_t readCount(const DatabasePartition& partition, const DeviceBuffer& counter) {
-   uint64_t value = 0;
-   checkGpu(silo_gpu_memcpy_d2h(&value, counter.get(), sizeof(value), nullptr), "silo_gpu_memcpy_d2h");
-   (void)partition;
-   return static_cast<uint32_t>(value);
+constexpr size_t COUNT_BYTES = SILO_GPU_COUNT_SHARDS * sizeof(uint64_t);
+
+DeviceBuffer zeroedCounter(const DatabasePartition& partition) {
+   DeviceBuffer counter = partition.pool.acquire(COUNT_BYTES);
+   checkGpu(silo_gpu_memset_async(counter.get(), 0, COUNT_BYTES, nullptr), "silo_gpu_memset_async");
+   return counter;
+}
+
+uint32_t readCount(const DeviceBuffer& counter) {
+   uint64_t shards[SILO_GPU_COUNT_SHARDS];
+   checkGpu(silo_gpu_memcpy_d2h(shards, counter.get(), COUNT_BYTES, nullptr), "silo_gpu_memcpy_d2h");
+   uint64_t total = 0;
+   for (const uint64_t shard : shards) {
+      total += shard;
+   }
+   return static_cast<uint32_t>(total);
+}
+
+bool isLeafOperand(uint32_t operand) {
+   return operand >= SILO_GPU_LEAF_OPERAND;
 }
 
 }  // namespace
@@ -45,8 +60,7 @@ void OperatorResult::materialize() const {
    }
    const DatabasePartition& partition = *state->rows.partition;
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
-   DeviceBuffer counter = partition.pool.acquire(sizeof(uint64_t));
-   checkGpu(silo_gpu_memset_async(counter.get(), 0, sizeof(uint64_t), nullptr), "silo_gpu_memset_async");
+   DeviceBuffer counter = zeroedCounter(partition);
    const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
    if (scan != nullptr && !scan->sparse) {
       state->borrowed = scan->bitmap;  // index_scan.cpp:28-30: borrow, no copy
@@ -58,7 +72,7 @@ void OperatorResult::materialize() const {
       builder.run(slot, out.as<uint64_t>(), counter.as<uint64_t>(), nullptr);
       state->bitset = std::move(out);
    }
-   state->count = readCount(partition, counter);
+   state->count = readCount(counter);
 }
 
 uint32_t OperatorResult::cardinality() const {
@@ -77,12 +91,11 @@ uint32_t OperatorResult::cardinality() const {
          state->count = state->rows.row_count;
          return *state->count;
       }
-      DeviceBuffer counter = partition.pool.acquire(sizeof(uint64_t));
-      checkGpu(silo_gpu_memset_async(counter.get(), 0, sizeof(uint64_t), nullptr), "silo_gpu_memset_async");
+      DeviceBuffer counter = zeroedCounter(partition);
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
       builder.run(slot, nullptr, counter.as<uint64_t>(), nullptr);
-      state->count = readCount(partition, counter);
+      state->count = readCount(counter);
       return *state->count;
    }
 }
@@ -119,7 +132,18 @@ void ProgramBuilder::freeRun(uint32_t slot, uint32_t count) {
 }
 
 void ProgramBuilder::freeSlot(uint32_t slot) {
-   freeRun(slot, 1);
+   if (!isLeafOperand(slot)) {  // leaf operands are not allocated
+      freeRun(slot, 1);
+   }
+}
+
+uint32_t ProgramBuilder::writable(uint32_t operand) {
+   if (!isLeafOperand(operand)) {
+      return operand;
+   }
+   const uint32_t slot = allocSlot();
+   emit(SILO_GPU_OP_MOV, slot, operand);
+   return slot;
 }
 
 void ProgramBuilder::emit(uint32_t op, uint32_t dst, uint32_t a, uint32_t b, uint32_t imm) {
@@ -137,13 +161,32 @@ uint32_t ProgramBuilder::leaf(const uint64_t* device_bitset) {
 }
 
 uint32_t ProgramBuilder::sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol) {
+   // Sparse planes are immutable once the store is finalised, so a materialised plane is kept for later
+   // queries (bounded: beyond the budget a plane is built into a pooled temporary for this launch only).
    const DatabasePartition& partition = *rows.partition;
-   DeviceBuffer buffer = partition.pool.acquire(static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t));
+   const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
+   const uint64_t key = (static_cast<uint64_t>(seqstore_id) << 40) | (static_cast<uint64_t>(position) << 8) | symbol;
+   {
+      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const auto found = partition.sparse_cache.find(key);
+      if (found != partition.sparse_cache.end()) {
+         return leaf(found->second.as<uint64_t>());
+      }
+   }
+   DeviceBuffer buffer = partition.pool.acquire(row_bytes);
    checkGpu(
       silo_gpu_store_sparse_plane(partition.store, seqstore_id, position, symbol, buffer.as<uint64_t>(), nullptr),
       "silo_gpu_store_sparse_plane"
    );
    const uint32_t index = leaf(buffer.as<uint64_t>());
+   {
+      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      if ((partition.sparse_cache.size() + 1) * row_bytes <= DatabasePartition::SPARSE_CACHE_BYTES &&
+          partition.sparse_cache.find(key) == partition.sparse_cache.end()) {
+         partition.sparse_cache.emplace(key, std::move(buffer));
+         return index;
+      }
+   }
    temporaries.push_back(std::move(buffer));
    return index;
 }
@@ -159,10 +202,9 @@ uint32_t ProgramBuilder::lowerChild(const operators::Operator& child) {
       return child.lower(*this);
    }
    OperatorResult result = child.evaluate();
-   const uint32_t slot = allocSlot();
-   emit(SILO_GPU_OP_LOAD, slot, 0, 0, leaf(result.bitset()));
+   const uint32_t operand = SILO_GPU_LEAF_OPERAND + leaf(result.bitset());
    materialized_children.push_back(std::move(result));
-   return slot;
+   return operand;
 }
 
 void ProgramBuilder::run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream) {
@@ -258,10 +300,9 @@ std::unique_ptr<Operator> IndexScan::negate() const {
    return std::make_unique<Complement>(copy(), rows);
 }
 uint32_t IndexScan::lower(ProgramBuilder& builder) const {
-   const uint32_t slot = builder.allocSlot();
+   // a leaf operand: the kernel stages every leaf in LDS up front, no instruction is emitted here
    const uint32_t index = sparse ? builder.sparseLeaf(seqstore_id, position, symbol) : builder.leaf(bitmap);
-   builder.emit(SILO_GPU_OP_LOAD, slot, 0, 0, index);
-   return slot;
+   return SILO_GPU_LEAF_OPERAND + index;
 }
 
 // ---- BitmapSelection (bitmap_selection.cpp:33-71) -----------------------------------------------
@@ -272,11 +313,12 @@ std::unique_ptr<Operator> BitmapSelection::negate() const {
    return std::make_unique<BitmapSelection>(missing_plane, rows, comparator == CONTAINS ? NOT_CONTAINS : CONTAINS, value);
 }
 uint32_t BitmapSelection::lower(ProgramBuilder& builder) const {
-   const uint32_t slot = builder.allocSlot();
-   builder.emit(SILO_GPU_OP_LOAD, slot, 0, 0, builder.leaf(missing_plane));
-   if (comparator == NOT_CONTAINS) {
-      builder.emit(SILO_GPU_OP_NOT, slot, slot);
+   const uint32_t operand = SILO_GPU_LEAF_OPERAND + builder.leaf(missing_plane);
+   if (comparator == CONTAINS) {
+      return operand;
    }
+   const uint32_t slot = builder.allocSlot();
+   builder.emit(SILO_GPU_OP_NOT, slot, operand);
    return slot;
 }
 
@@ -301,8 +343,9 @@ std::unique_ptr<Operator> Complement::negate() const {
    return child->copy();
 }
 uint32_t Complement::lower(ProgramBuilder& builder) const {  // flip(0,row_count): complement.cpp:50-54
-   const uint32_t slot = builder.lowerChild(*child);
-   builder.emit(SILO_GPU_OP_NOT, slot, slot);
+   const uint32_t operand = builder.lowerChild(*child);
+   const uint32_t slot = isLeafOperand(operand) ? builder.allocSlot() : operand;
+   builder.emit(SILO_GPU_OP_NOT, slot, operand);
    return slot;
 }
 Cost Complement::cost() const {
@@ -342,16 +385,21 @@ std::unique_ptr<Operator> Intersection::negate() const {
 uint32_t Intersection::lower(ProgramBuilder& builder) const {
    // The reference orders children by cardinality to keep roaring intermediates small
    // (intersection.cpp:94-108); a dense word-parallel AND has no such sensitivity.
-   const uint32_t acc = builder.lowerChild(*children[0]);
+   uint32_t acc = builder.lowerChild(*children[0]);
+   const auto combine = [&](uint32_t op, const Operator& child) {
+      const uint32_t tmp = builder.lowerChild(child);
+      const uint32_t dst = isLeafOperand(acc) ? (isLeafOperand(tmp) ? builder.allocSlot() : tmp) : acc;
+      builder.emit(op, dst, acc, tmp);
+      if (dst != tmp) {
+         builder.freeSlot(tmp);
+      }
+      acc = dst;
+   };
    for (size_t i = 1; i < children.size(); ++i) {
-      const uint32_t tmp = builder.lowerChild(*children[i]);
-      builder.emit(SILO_GPU_OP_AND, acc, acc, tmp);
-      builder.freeSlot(tmp);
+      combine(SILO_GPU_OP_AND, *children[i]);
    }
    for (const auto& child : negated_children) {
-      const uint32_t tmp = builder.lowerChild(*child);
-      builder.emit(SILO_GPU_OP_ANDNOT, acc, acc, tmp);
-      builder.freeSlot(tmp);
+      combine(SILO_GPU_OP_ANDNOT, *child);
    }
    return acc;
 }
@@ -382,11 +430,15 @@ uint32_t Union::lower(ProgramBuilder& builder) const {
       builder.emit(SILO_GPU_OP_ZERO, slot);
       return slot;
    }
-   const uint32_t acc = builder.lowerChild(*children[0]);
+   uint32_t acc = builder.lowerChild(*children[0]);
    for (size_t i = 1; i < children.size(); ++i) {
       const uint32_t tmp = builder.lowerChild(*children[i]);
-      builder.emit(SILO_GPU_OP_OR, acc, acc, tmp);
-      builder.freeSlot(tmp);
+      const uint32_t dst = isLeafOperand(acc) ? (isLeafOperand(tmp) ? builder.allocSlot() : tmp) : acc;
+      builder.emit(SILO_GPU_OP_OR, dst, acc, tmp);
+      if (dst != tmp) {
+         builder.freeSlot(tmp);
+      }
+      acc = dst;
    }
    return acc;
 }
@@ -444,8 +496,9 @@ uint32_t Threshold::lower(ProgramBuilder& builder) const {
       builder.freeSlot(tmp);
    }
    for (const auto& child : negated_children) {
-      const uint32_t tmp = builder.lowerChild(*child);
-      builder.emit(SILO_GPU_OP_NOT, tmp, tmp);
+      const uint32_t operand = builder.lowerChild(*child);
+      const uint32_t tmp = isLeafOperand(operand) ? builder.allocSlot() : operand;
+      builder.emit(SILO_GPU_OP_NOT, tmp, operand);
       builder.emit(SILO_GPU_OP_CNT_ADD, counter, tmp, bits);
       builder.freeSlot(tmp);
    }

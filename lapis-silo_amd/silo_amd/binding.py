@@ -180,6 +180,10 @@ class GpuEvent:
 OP_LOAD, OP_ZERO, OP_ONES, OP_NOT, OP_AND, OP_OR, OP_ANDNOT, OP_CNT_ADD, OP_CNT_GE, OP_CNT_EQ, OP_MOV = range(11)
 
 
+COUNT_SHARDS = 64   # SILO_GPU_COUNT_SHARDS
+LEAF_OPERAND = 32   # SILO_GPU_LEAF_OPERAND
+
+
 def encode(op, dst=0, a=0, b=0, imm=0):
     return [op | (dst << 8) | (a << 16) | (b << 24), imm]
 
@@ -367,11 +371,19 @@ class GpuStore:
         prog = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
         _check(self.lib.silo_gpu_filter_eval(self.handle, ctypes.byref(prog), out_bitset, out_count, stream))
 
+    def count_buffer(self, stream=None):
+        """Zeroed accumulator for cardinalities: COUNT_SHARDS uint64 (their sum is the count)."""
+        counter = self.malloc(8 * COUNT_SHARDS)
+        self.memset(counter, 0, 8 * COUNT_SHARDS, stream)
+        return counter
+
+    def read_count(self, counter, stream=None):
+        return int(self.read(counter, np.uint64, COUNT_SHARDS, stream).sum())
+
     def popcount(self, bitset, stream=None):
-        counter = self.malloc(8)
-        self.memset(counter, 0, 8, stream)
+        counter = self.count_buffer(stream)
         _check(self.lib.silo_gpu_popcount(self.handle, bitset, counter, stream))
-        value = int(self.read(counter, np.uint64, 1, stream)[0])
+        value = self.read_count(counter, stream)
         self.free(counter)
         return value
 

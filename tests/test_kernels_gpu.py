@@ -92,11 +92,10 @@ def _eval(store, code, leaves, n_slots):
     from silo_amd.binding import encode  # noqa: F401
 
     out = store.bitset_alloc()
-    cnt = store.malloc(8)
-    store.memset(cnt, 0, 8)
+    cnt = store.count_buffer()
     store.filter_eval(code, leaves, n_slots, out, cnt)
     words = store.bitset_download(out)
-    count = int(store.read(cnt, np.uint64, 1)[0])
+    count = store.read_count(cnt)
     store.free(out)
     store.free(cnt)
     return words, count
@@ -128,6 +127,12 @@ def test_filter_eval_ops(built, n):
                 + b.encode(b.OP_LOAD, 1, imm=2) + b.encode(b.OP_NOT, 1, 1) + b.encode(b.OP_OR, 0, 0, 1)
                 + b.encode(b.OP_LOAD, 1, imm=3) + b.encode(b.OP_ANDNOT, 0, 0, 1))
         check(code, 2, ((masks[0] & masks[1]) | ~masks[2]) & ~masks[3])
+        # leaf operands: (leaf0 & leaf1) | ~leaf2, minus leaf3 without a single LOAD
+        L = b.LEAF_OPERAND
+        code = (b.encode(b.OP_AND, 0, L + 0, L + 1) + b.encode(b.OP_NOT, 1, L + 2) + b.encode(b.OP_OR, 0, 0, 1)
+                + b.encode(b.OP_ANDNOT, 0, 0, L + 3))
+        check(code, 2, ((masks[0] & masks[1]) | ~masks[2]) & ~masks[3])
+        check(b.encode(b.OP_MOV, 0, L + 4), 1, masks[4])
         check(b.encode(b.OP_ONES, 0), 1, full)
         check(b.encode(b.OP_ZERO, 0), 1, ~full)
         check(b.encode(b.OP_ZERO, 0) + b.encode(b.OP_NOT, 0, 0), 1, full)
@@ -136,7 +141,10 @@ def test_filter_eval_ops(built, n):
         for k in range(0, 7):
             code = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3)
             for leaf in range(5):
-                code += b.encode(b.OP_LOAD, 0, imm=leaf) + b.encode(b.OP_CNT_ADD, 1, 0, 3)
+                if leaf % 2 == 0:
+                    code += b.encode(b.OP_LOAD, 0, imm=leaf) + b.encode(b.OP_CNT_ADD, 1, 0, 3)
+                else:
+                    code += b.encode(b.OP_CNT_ADD, 1, b.LEAF_OPERAND + leaf, 3)
             check(code + b.encode(b.OP_CNT_GE, 0, 1, 3, imm=k), 4, total >= k)
             check(code + b.encode(b.OP_CNT_EQ, 0, 1, 3, imm=k), 4, total == k)
 
