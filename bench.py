@@ -328,10 +328,10 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        grid = -(-store.row_words // 2048) * -(-(n_local * 5) // 256) * 256
-        entry = pmc["kernels"].get(f"k_scan_tiled<8>@{grid}")
-        if entry is not None:
-            traffic = entry["hbm_bytes"]
+        for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
+            name, _, grid = key.rpartition("@")
+            if name.startswith("k_scan_tiled") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * 5:
+                traffic = entry["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         pass
 

@@ -173,7 +173,22 @@ constexpr int SCAN_ROWS_BATCH = 64;
 
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 
-template <int WPT, bool GUARDED>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte plane load; NT marks the stream non-temporal (read once, keep it out of the way of the filter tile).
+template <bool NT>
+__device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
+   if constexpr (NT) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+      return make_ulonglong2(
+         static_cast<uint64_t>(v.x) | (static_cast<uint64_t>(v.y) << 32), static_cast<uint64_t>(v.z) | (static_cast<uint64_t>(v.w) << 32)
+      );
+   } else {
+      return *reinterpret_cast<const ulonglong2*>(ptr);
+   }
+}
+
+template <int WPT, bool GUARDED, bool NT>
 __device__ __forceinline__ void scanTile(
    const uint64_t* __restrict__ planes,
    const uint64_t* __restrict__ filter,
@@ -215,7 +230,7 @@ __device__ __forceinline__ void scanTile(
       const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
 #pragma unroll
       for (int j = 0; j < CHUNKS; ++j) {
-         dst[j] = *reinterpret_cast<const ulonglong2*>(row_ptr + word[j]);
+         dst[j] = loadPlane16<NT>(row_ptr + word[j]);
       }
    };
    auto reduce_row = [&](const ulonglong2 (&src)[CHUNKS]) {
@@ -271,8 +286,8 @@ __device__ __forceinline__ void scanTile(
 // One launch covers the whole (rows x row_words) rectangle: blockIdx.x = row_group * n_tiles + tile.
 // Only the last column tile can be ragged (row_words is a multiple of 32 words, a tile is 2048); it
 // takes the guarded instantiation through a block-uniform branch, every other block the unguarded one.
-template <int WPT>
-__global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan_tiled(
+template <int WPT, bool NT>
+__global__ __launch_bounds__(SCAN_THREADS, (WPT <= 8 ? 8 : 4)) void k_scan_tiled(
    const uint64_t* __restrict__ planes,
    const uint64_t* __restrict__ filter,
    uint32_t* __restrict__ counts,
@@ -287,9 +302,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan_tiled(
    const uint32_t tile = blockIdx.x % n_tiles;
    const uint32_t row_group = blockIdx.x / n_tiles;
    if ((tile + 1) * TILE_WORDS <= row_words) {
-      scanTile<WPT, false>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
+      scanTile<WPT, false, NT>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
    } else {
-      scanTile<WPT, true>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
+      scanTile<WPT, true, NT>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
    }
 }
 
@@ -1429,10 +1444,14 @@ int silo_gpu_mutations_scan(
    const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
    auto hip_stream = static_cast<hipStream_t>(stream);
 
-   constexpr int WPT = 8;
-   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
+   // Kernel selection (measured on MI355X, profiles/r01_scan_variants.md):
+   //   rows shorter than one 2048-word tile      -> k_scan_rowwave (one wave per row, cacheable loads)
+   //   otherwise k_scan_tiled with non-temporal plane loads; 16 words per thread when rows are long and that
+   //   tiling pads the row no worse than the 8-word one (a ragged last tile idles lanes), else 8.
+   // SILO_GPU_TUNE_SCAN_VARIANT: 0 auto, 1 force tiled, 2 force rowwave, 10 tiled 8 words, 12 tiled 16 words.
    const int variant = g_tune_scan_variant.load();
-   const bool tiled = variant == 1 || (variant == 0 && row_words >= TILE_WORDS);
+   constexpr uint32_t TILE8 = SCAN_THREADS * 8, TILE16 = SCAN_THREADS * 16;
+   const bool tiled = variant == 1 || variant >= 10 || (variant == 0 && row_words >= TILE8);
    if (!tiled) {
       const uint32_t waves = std::min<uint32_t>(n_rows, 256u * 32u);
       const uint32_t blocks = (waves + 3) / 4;
@@ -1441,15 +1460,28 @@ int silo_gpu_mutations_scan(
       HIP_TRY(hipGetLastError());
       return SILO_GPU_OK;
    }
+   const double pad8 = static_cast<double>((row_words + TILE8 - 1) / TILE8 * TILE8) / row_words;
+   const double pad16 = static_cast<double>((row_words + TILE16 - 1) / TILE16 * TILE16) / row_words;
+   bool wide = row_words >= 8192 && pad16 <= pad8 + 0.02;
+   if (variant == 10) {
+      wide = false;
+   } else if (variant == 12) {
+      wide = true;
+   }
+   const uint32_t tile_words = wide ? TILE16 : TILE8;
    int rows_per_block = g_tune_rows_per_block.load();
    if (rows_per_block <= 0) {
-      rows_per_block = 256;
+      rows_per_block = 64;
    }
-   const uint32_t n_tiles = (row_words + TILE_WORDS - 1) / TILE_WORDS;
+   rows_per_block += rows_per_block & 1;  // the row pipeline works on pairs
+   const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    const uint32_t row_groups = (n_rows + rows_per_block - 1) / rows_per_block;
-   k_scan_tiled<WPT><<<n_tiles * row_groups, SCAN_THREADS, 0, hip_stream>>>(
-      planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles
-   );
+   const dim3 grid(n_tiles * row_groups);
+   if (wide) {
+      k_scan_tiled<16, true><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles);
+   } else {
+      k_scan_tiled<8, true><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles);
+   }
    HIP_TRY(hipGetLastError());
    g_last_scan_kernel = "k_scan_tiled";
    return SILO_GPU_OK;

@@ -14,8 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sequences", type=int, default=1_000_000)
 ap.add_argument("--positions", type=int, default=29903)
 ap.add_argument("--lineages", type=int, default=2000)
-ap.add_argument("--rows", type=str, default="64,128,256,512,1024")
+ap.add_argument("--rows", type=str, default="32,64,128")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--variants", type=str, default="0,10,12")
 args = ap.parse_args()
 
 n, positions = args.sequences, args.positions
@@ -41,7 +42,9 @@ w8 = 8 * ((n + 63) // 64)
 alg_bytes = positions * 5 * w8 + w8
 counts = store.malloc(4 * positions * 5)
 start, stop = binding.GpuEvent(), binding.GpuEvent()
-for rows in [int(x) for x in args.rows.split(",")]:
+reference_counts = None
+for variant, rows in [(int(v), int(r)) for v in args.variants.split(",") for r in args.rows.split(",")]:
+    store.tune(1, variant)
     store.tune(0, rows)
     best = 1e9
     for rep in range(args.reps + 1):
@@ -52,7 +55,11 @@ for rows in [int(x) for x in args.rows.split(",")]:
         ms = start.elapsed_ms(stop)
         if rep > 0:
             best = min(best, ms)
-    print(f"rows_per_block={rows:5d}  {best:8.3f} ms  {alg_bytes / best / 1e6:8.1f} GB/s  "
+    c = store.read(counts, np.uint32, positions * 5)
+    if reference_counts is None:
+        reference_counts = c.copy()
+    assert np.array_equal(c, reference_counts), "variant changed the counts"
+    print(f"variant={variant:2d} rows_per_block={rows:5d}  {best:8.3f} ms  {alg_bytes / best / 1e6:8.1f} GB/s  "
           f"{n * positions / best / 1e9 * 1e3:.3e} pos*seq/s  kernel={store.last_scan_kernel()}", flush=True)
 c = store.read(counts, np.uint32, positions * 5).reshape(positions, 5)
 print("checksum", int(c.sum()), "total@pos1000", c[1000])
