@@ -177,13 +177,14 @@ def filter_query(model, tree):
         lineages = np.nonzero(carried[p])[0]
         symbol = int(model.lineage_symbol[p][lineages[np.argmax(tree.weights[lineages])]])
         leaves.append({"type": "NucleotideEquals", "position": int(p) + 1, "symbol": "-ACGT"[symbol]})
+    # leaves are sorted by how many sequences carry them: the most common 8 go under Maybe(And), the rarest 8 under Not(Or)
     return json.dumps({
         "action": {"type": "Aggregated"},
         "filterExpression": {"type": "And", "children": [
-            {"type": "Or", "children": leaves[0:8]},
-            {"type": "N-Of", "numberOfMatchers": 3, "matchExactly": False, "children": leaves[8:16]},
-            {"type": "Not", "child": {"type": "Or", "children": leaves[16:24]}},
-            {"type": "Maybe", "child": {"type": "And", "children": leaves[24:32]}},
+            {"type": "Or", "children": leaves[8:16]},
+            {"type": "N-Of", "numberOfMatchers": 3, "matchExactly": False, "children": leaves[16:24]},
+            {"type": "Not", "child": {"type": "Or", "children": leaves[24:32]}},
+            {"type": "Maybe", "child": {"type": "And", "children": leaves[0:8]}},
         ]},
     })
 

@@ -163,7 +163,13 @@ enum {
    SILO_GPU_OP_CNT_ADD = 7,  /* bit-sliced counter in slots dst..dst+b-1 += slot a    (Threshold) */
    SILO_GPU_OP_CNT_GE = 8,   /* dst = (counter in slots a..a+b-1) >= imm                           */
    SILO_GPU_OP_CNT_EQ = 9,   /* dst = (counter in slots a..a+b-1) == imm                           */
-   SILO_GPU_OP_MOV = 10      /* dst = a */
+   SILO_GPU_OP_MOV = 10,     /* dst = a */
+   /* n-ary forms over a run of consecutive leaves, imm = first_leaf | count << 16 (count >= 1): the leaves
+    * are fetched 8 at a time with independent loads (flat Or / And / N-Of over stored columns). */
+   SILO_GPU_OP_OR_N = 11,          /* dst = leaf[first] | ... | leaf[first+count-1]          (Union)        */
+   SILO_GPU_OP_AND_N = 12,         /* dst = leaf[first] & ... & leaf[first+count-1]          (Intersection) */
+   SILO_GPU_OP_CNT_ADD_N = 13,     /* counter dst..dst+b-1 += each leaf of the run           (Threshold)    */
+   SILO_GPU_OP_CNT_ADD_NOT_N = 14  /* counter dst..dst+b-1 += each (~leaf & valid) of the run (negated children) */
 };
 enum { SILO_GPU_MAX_INSTRUCTIONS = 320, SILO_GPU_MAX_LEAVES = 128, SILO_GPU_MAX_SLOTS = 32 };
 /* A source operand (a, b) >= SILO_GPU_LEAF_OPERAND reads leaf (operand - SILO_GPU_LEAF_OPERAND) directly, so a

@@ -1,18 +1,21 @@
-// bitprog.h — one-word interpreter of the fused filter bit-program (K3).
+// bitprog.h — interpreter of the fused filter bit-program (K3), shared by the device kernel and a g++ build.
 //
-// The device kernel (silo_gpu.hip: k_filter_eval) runs this once per 64-bit bitset word with the
-// slots in LDS; tests/host_tools/bitprog_host.cpp compiles the very same function with g++ so the
-// instruction semantics can be unit-tested on a machine without a GPU.  It is not a CPU fallback:
-// nothing in the product path calls the host build.
+// The device kernel (silo_gpu.hip: k_filter_eval) runs this once per lane with T = two 64-bit bitset
+// words and the slots in LDS; tests/host_tools/bitprog_host.cpp compiles the very same function with
+// g++ (T = one word) so the instruction semantics can be unit-tested on a machine without a GPU.  It is
+// not a CPU fallback: nothing in the product path calls the host build.
 //
 // Semantics follow the reference operators (file:line under the reference tree):
-//   NOT      operators/complement.cpp:50-54     flip(0,row_count)  ->  ~x & valid
-//   AND      operators/intersection.cpp:111-126 &=
-//   ANDNOT   operators/intersection.cpp:115,124 -=
-//   OR       operators/union.cpp:44             fastunion
-//   CNT_*    operators/threshold.cpp:64-138     the n-of-k DP table, restated as a bit-sliced
-//            vertical counter: CNT_ADD ripple-adds one child plane, CNT_GE / CNT_EQ compare the
-//            per-row count with n (exact = table[n-1] - table[n], threshold.cpp:130-135).
+//   NOT           operators/complement.cpp:50-54     flip(0,row_count)  ->  ~x & valid
+//   AND / AND_N   operators/intersection.cpp:111-126 &=
+//   ANDNOT        operators/intersection.cpp:115,124 -=
+//   OR / OR_N     operators/union.cpp:44             fastunion
+//   CNT_*         operators/threshold.cpp:64-138     the n-of-k DP table, restated as a bit-sliced
+//                 vertical counter: CNT_ADD ripple-adds one child plane, CNT_GE / CNT_EQ compare the
+//                 per-row count with n (exact = table[n-1] - table[n], threshold.cpp:130-135).
+// The *_N forms take a run of consecutive leaves (imm = first | count << 16) and fetch them 8 at a time
+// with independent loads, so a flat Or / And / N-Of over stored columns streams at memory speed instead
+// of paying one dependent load per LOAD instruction.
 #pragma once
 #include <stdint.h>
 
@@ -26,11 +29,29 @@
 
 namespace silo_gpu {
 
-// `slot(i)` returns a uint64_t& ; `leaf(i)` returns the word of leaf i.
-template <class SlotFn, class LeafFn>
-SILO_HD uint64_t bitprog_run_word(
-   const uint32_t* code, uint32_t n_instructions, uint64_t valid, SlotFn slot, LeafFn leaf
-) {
+// Two bitset words handled by one lane (one 16-byte load per leaf).
+struct Word2 {
+   uint64_t x, y;
+};
+SILO_HD Word2 operator&(Word2 a, Word2 b) { return {a.x & b.x, a.y & b.y}; }
+SILO_HD Word2 operator|(Word2 a, Word2 b) { return {a.x | b.x, a.y | b.y}; }
+SILO_HD Word2 operator^(Word2 a, Word2 b) { return {a.x ^ b.x, a.y ^ b.y}; }
+SILO_HD Word2 operator~(Word2 a) { return {~a.x, ~a.y}; }
+
+template <class T>
+SILO_HD T zeroOf();
+template <>
+SILO_HD uint64_t zeroOf<uint64_t>() { return 0; }
+template <>
+SILO_HD Word2 zeroOf<Word2>() { return {0, 0}; }
+
+constexpr uint32_t LEAF_BATCH = 8;
+
+// get(index): value of slot `index`, or of leaf (index - SILO_GPU_LEAF_OPERAND) for index >= SILO_GPU_LEAF_OPERAND
+// set(index, value): store into slot `index`        leaf(i): value of leaf i (a global load on the device)
+template <class T, class GetFn, class SetFn, class LeafFn>
+SILO_HD T bitprog_run(const uint32_t* code, uint32_t n_instructions, T valid, GetFn get, SetFn set, LeafFn leaf) {
+   const T ones = ~zeroOf<T>();
    for (uint32_t pc = 0; pc < n_instructions; ++pc) {
       const uint32_t w0 = code[2 * pc];
       const uint32_t imm = code[2 * pc + 1];
@@ -40,65 +61,112 @@ SILO_HD uint64_t bitprog_run_word(
       const uint32_t b = (w0 >> 24) & 0xFFu;
       switch (op) {
          case SILO_GPU_OP_LOAD:
-            slot(dst) = leaf(imm);
+            set(dst, leaf(imm));
             break;
          case SILO_GPU_OP_ZERO:
-            slot(dst) = 0;
+            set(dst, zeroOf<T>());
             break;
          case SILO_GPU_OP_ONES:
-            slot(dst) = valid;
+            set(dst, valid);
             break;
          case SILO_GPU_OP_NOT:
-            slot(dst) = ~slot(a) & valid;
+            set(dst, ~get(a) & valid);
             break;
          case SILO_GPU_OP_AND:
-            slot(dst) = slot(a) & slot(b);
+            set(dst, get(a) & get(b));
             break;
          case SILO_GPU_OP_OR:
-            slot(dst) = slot(a) | slot(b);
+            set(dst, get(a) | get(b));
             break;
          case SILO_GPU_OP_ANDNOT:
-            slot(dst) = slot(a) & ~slot(b);
+            set(dst, get(a) & ~get(b));
             break;
          case SILO_GPU_OP_MOV:
-            slot(dst) = slot(a);
+            set(dst, get(a));
             break;
+         case SILO_GPU_OP_OR_N:
+         case SILO_GPU_OP_AND_N: {
+            const uint32_t first = imm & 0xFFFFu;
+            const uint32_t count = imm >> 16;
+            const uint32_t last = first + count - 1;
+            T acc = op == SILO_GPU_OP_OR_N ? zeroOf<T>() : ones;
+            for (uint32_t i = 0; i < count; i += LEAF_BATCH) {
+               T value[LEAF_BATCH];
+#pragma unroll
+               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {  // clamped: the last leaf is re-read, never a branch around a load
+                  const uint32_t index = first + i + k;
+                  value[k] = leaf(index < last ? index : last);
+               }
+#pragma unroll
+               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {
+                  acc = op == SILO_GPU_OP_OR_N ? (acc | value[k]) : (acc & value[k]);
+               }
+            }
+            set(dst, acc);
+            break;
+         }
          case SILO_GPU_OP_CNT_ADD: {
-            // counter bits live in slots dst .. dst+b-1 (LSB first); add the 1-bit plane slot(a)
-            uint64_t carry = slot(a);
+            // counter bits live in slots dst .. dst+b-1 (LSB first); add the 1-bit plane get(a)
+            T carry = get(a);
             for (uint32_t bit = 0; bit < b; ++bit) {
-               const uint64_t cur = slot(dst + bit);
-               slot(dst + bit) = cur ^ carry;
-               carry &= cur;
+               const T cur = get(dst + bit);
+               set(dst + bit, cur ^ carry);
+               carry = carry & cur;
+            }
+            break;
+         }
+         case SILO_GPU_OP_CNT_ADD_N:
+         case SILO_GPU_OP_CNT_ADD_NOT_N: {
+            // add every leaf of the run (or its complement within `valid`) to the counter dst .. dst+b-1
+            const uint32_t first = imm & 0xFFFFu;
+            const uint32_t count = imm >> 16;
+            for (uint32_t i = 0; i < count; i += LEAF_BATCH) {
+               T value[LEAF_BATCH];
+#pragma unroll
+               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {
+                  const uint32_t index = first + i + k;
+                  value[k] = leaf(index < first + count ? index : first + count - 1);
+               }
+#pragma unroll
+               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {  // static index into value[]: stays in registers
+                  if (i + k < count) {
+                     T carry = op == SILO_GPU_OP_CNT_ADD_N ? value[k] : (~value[k] & valid);
+                     for (uint32_t bit = 0; bit < b; ++bit) {
+                        const T cur = get(dst + bit);
+                        set(dst + bit, cur ^ carry);
+                        carry = carry & cur;
+                     }
+                  }
+               }
             }
             break;
          }
          case SILO_GPU_OP_CNT_GE:
          case SILO_GPU_OP_CNT_EQ: {
             // compare the b-bit counter in slots a .. a+b-1 with imm, MSB first
-            uint64_t greater = 0;
-            uint64_t equal = ~0ull;
+            T greater = zeroOf<T>();
+            T equal = ones;
             if (b < 32 && (imm >> b) != 0) {
-               equal = 0;  // imm does not fit in b bits: counter < imm everywhere
+               equal = zeroOf<T>();  // imm does not fit in b bits: counter < imm everywhere
             } else {
                for (int bit = static_cast<int>(b) - 1; bit >= 0; --bit) {
-                  const uint64_t cur = slot(a + static_cast<uint32_t>(bit));
+                  const T cur = get(a + static_cast<uint32_t>(bit));
                   if ((imm >> bit) & 1u) {
-                     equal &= cur;
+                     equal = equal & cur;
                   } else {
-                     greater |= equal & cur;
-                     equal &= ~cur;
+                     greater = greater | (equal & cur);
+                     equal = equal & ~cur;
                   }
                }
             }
-            slot(dst) = (op == SILO_GPU_OP_CNT_GE ? (greater | equal) : equal) & valid;
+            set(dst, (op == SILO_GPU_OP_CNT_GE ? (greater | equal) : equal) & valid);
             break;
          }
          default:
             break;
       }
    }
-   return slot(0);
+   return get(0);
 }
 
 // valid(w): rows 64w .. 64w+63 that are < sequence_count

@@ -372,23 +372,20 @@ __global__ __launch_bounds__(256) void k_popcount(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: fused filter evaluator.  One wave per block, one bitset word per lane.
-//   phase 1  every leaf word of this lane is fetched from HBM into LDS, 8 independent loads in flight at
-//            a time (a plain interpreter would issue one dependent load per LOAD instruction);
-//   phase 2  the bit-program runs out of LDS: slots and leaves live as [index][lane], so every
-//            ds_read_b64 / ds_write_b64 is conflict-free; operands >= SILO_GPU_LEAF_OPERAND address a
-//            leaf directly, so no LOAD instruction is needed.  The program itself sits in the
-//            kernel-argument segment and is fetched with scalar loads (uniform control flow).
+// K3: fused filter evaluator.  One 64-lane wave per block; each lane owns TWO bitset words (one 16-byte
+// access per leaf).  The program sits in the kernel-argument segment and is fetched with scalar loads
+// (uniform control flow).  Slots live in LDS as [slot][lane] (16 B per lane: conflict-free b128
+// accesses), typically a handful -> full occupancy; leaves are never staged: the n-ary instructions
+// stream them from HBM 8 independent loads at a time, single leaf operands are loaded on use.
 // ------------------------------------------------------------------------------------------------
 constexpr int EVAL_THREADS = 64;
+constexpr uint32_t EVAL_WORDS_PER_BLOCK = EVAL_THREADS * 2;
 
 struct FilterEvalArgs {
    uint32_t n_instructions;
    uint32_t sequence_count;
    uint32_t row_words;
    uint32_t n_slots;
-   uint32_t n_leaves;
-   uint32_t pad;
    uint64_t* out;
    unsigned long long* out_count;
    const uint64_t* leaves[SILO_GPU_MAX_LEAVES];
@@ -396,47 +393,37 @@ struct FilterEvalArgs {
 };
 
 __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
-   extern __shared__ uint64_t s_mem[];  // [n_slots + n_leaves][EVAL_THREADS]
+   extern __shared__ ulonglong2 s_slots[];  // [n_slots][EVAL_THREADS]
+   using silo_gpu::Word2;
    const uint32_t lane = threadIdx.x;
-   const uint32_t w = blockIdx.x * EVAL_THREADS + lane;
+   const uint32_t w = (blockIdx.x * EVAL_THREADS + lane) * 2;  // row_words is even (multiple of 32)
    const bool active = w < args.row_words;
    const uint32_t w_safe = active ? w : 0;
-   uint64_t* leaf_area = s_mem + args.n_slots * EVAL_THREADS;
-
-   constexpr uint32_t BATCH = 8;
-   for (uint32_t first = 0; first < args.n_leaves; first += BATCH) {
-      uint64_t value[BATCH];
-#pragma unroll
-      for (uint32_t k = 0; k < BATCH; ++k) {  // clamped index: no load sits under a branch
-         value[k] = args.leaves[min(first + k, args.n_leaves - 1)][w_safe];
-      }
-#pragma unroll
-      for (uint32_t k = 0; k < BATCH; ++k) {
-         if (first + k < args.n_leaves) {
-            leaf_area[(first + k) * EVAL_THREADS + lane] = value[k];
-         }
-      }
+   Word2 valid{0, 0};
+   if (active) {
+      valid = {silo_gpu::valid_mask(w, args.sequence_count), silo_gpu::valid_mask(w + 1, args.sequence_count)};
    }
+   const auto leaf = [&](uint32_t index) -> Word2 {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(args.leaves[index] + w_safe);
+      return {v.x, v.y};
+   };
+   const auto get = [&](uint32_t index) -> Word2 {
+      if (index >= SILO_GPU_LEAF_OPERAND) {
+         return leaf(index - SILO_GPU_LEAF_OPERAND);
+      }
+      const ulonglong2 v = s_slots[index * EVAL_THREADS + lane];
+      return {v.x, v.y};
+   };
+   const auto set = [&](uint32_t index, Word2 value) { s_slots[index * EVAL_THREADS + lane] = make_ulonglong2(value.x, value.y); };
 
-   const uint64_t valid = active ? silo_gpu::valid_mask(w, args.sequence_count) : 0;
-   const uint32_t n_slots = args.n_slots;
-   const uint64_t result =
-      silo_gpu::bitprog_run_word(
-         args.code,
-         args.n_instructions,
-         valid,
-         [&](uint32_t index) -> uint64_t& {
-            const uint32_t row = index < SILO_GPU_LEAF_OPERAND ? index : n_slots + (index - SILO_GPU_LEAF_OPERAND);
-            return s_mem[row * EVAL_THREADS + lane];
-         },
-         [&](uint32_t leaf) -> uint64_t { return leaf_area[leaf * EVAL_THREADS + lane]; }
-      ) &
-      valid;
+   Word2 result = silo_gpu::bitprog_run<Word2>(args.code, args.n_instructions, valid, get, set, leaf);
+   result = result & valid;
    if (active && args.out != nullptr) {
-      args.out[w] = result;
+      *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
    }
    if (args.out_count != nullptr) {
-      addToCountShard(args.out_count, waveSumToLane63(static_cast<uint32_t>(__popcll(result))));
+      const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
+      addToCountShard(args.out_count, waveSumToLane63(bits));
    }
 }
 
@@ -1364,6 +1351,14 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
          case SILO_GPU_OP_CNT_ADD:
             ok = readable(a) && b >= 1 && dst + b <= program->n_slots;
             break;
+         case SILO_GPU_OP_OR_N:
+         case SILO_GPU_OP_AND_N:
+            ok = dst < program->n_slots && (imm >> 16) >= 1 && (imm & 0xFFFFu) + (imm >> 16) <= program->n_leaves;
+            break;
+         case SILO_GPU_OP_CNT_ADD_N:
+         case SILO_GPU_OP_CNT_ADD_NOT_N:
+            ok = b >= 1 && dst + b <= program->n_slots && (imm >> 16) >= 1 && (imm & 0xFFFFu) + (imm >> 16) <= program->n_leaves;
+            break;
          case SILO_GPU_OP_CNT_GE:
          case SILO_GPU_OP_CNT_EQ:
             ok = dst < program->n_slots && b >= 1 && a + b <= program->n_slots;
@@ -1385,25 +1380,14 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
    args.sequence_count = store->sequence_count;
    args.row_words = store->row_words;
    args.n_slots = program->n_slots;
-   args.n_leaves = program->n_leaves;
    args.out = out_bitset_dev;
    args.out_count = reinterpret_cast<unsigned long long*>(out_count_dev);
    for (uint32_t k = 0; k < program->n_leaves; ++k) {
       args.leaves[k] = program->leaves[k];
    }
    memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
-   const uint32_t blocks = (store->row_words + EVAL_THREADS - 1) / EVAL_THREADS;
-   const size_t lds_bytes = static_cast<size_t>(program->n_slots + program->n_leaves) * EVAL_THREADS * sizeof(uint64_t);
-   if (lds_bytes > 64 * 1024) {  // up to (32 + 128) * 512 B = 80 KiB of the CU's 160 KiB
-      static std::once_flag raised;
-      hipError_t attribute_error = hipSuccess;
-      std::call_once(raised, [&] {
-         attribute_error = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(k_filter_eval), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024
-         );
-      });
-      HIP_TRY(attribute_error);
-   }
+   const uint32_t blocks = (store->row_words + EVAL_WORDS_PER_BLOCK - 1) / EVAL_WORDS_PER_BLOCK;
+   const size_t lds_bytes = static_cast<size_t>(program->n_slots) * EVAL_THREADS * sizeof(ulonglong2);  // <= 32 KiB
    k_filter_eval<<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;

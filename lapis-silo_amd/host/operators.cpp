@@ -161,6 +161,33 @@ uint32_t ProgramBuilder::leaf(const uint64_t* device_bitset) {
 }
 
 uint32_t ProgramBuilder::sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol) {
+   return leaf(sparsePointer(seqstore_id, position, symbol));
+}
+
+uint32_t ProgramBuilder::leafRun(const std::vector<const uint64_t*>& columns) {
+   if (leaves.size() + columns.size() > SILO_GPU_MAX_LEAVES) {
+      throw QueryCompilationException(
+         "Compilation Error: filter expression reads more than " + std::to_string(SILO_GPU_MAX_LEAVES) + " stored columns in one device program"
+      );
+   }
+   const auto first = static_cast<uint32_t>(leaves.size());
+   leaves.insert(leaves.end(), columns.begin(), columns.end());  // consecutive, not de-duplicated
+   return first | (static_cast<uint32_t>(columns.size()) << 16);
+}
+
+ProgramBuilder::Split ProgramBuilder::split(const operators::OperatorVector& children) {
+   Split out;
+   for (const auto& child : children) {
+      if (const uint64_t* column = child->storedColumn(*this); column != nullptr) {
+         out.columns.push_back(column);
+      } else {
+         out.composite.push_back(child.get());
+      }
+   }
+   return out;
+}
+
+const uint64_t* ProgramBuilder::sparsePointer(uint32_t seqstore_id, uint32_t position, uint32_t symbol) {
    // Sparse planes are immutable once the store is finalised, so a materialised plane is kept for later
    // queries (bounded: beyond the budget a plane is built into a pooled temporary for this launch only).
    const DatabasePartition& partition = *rows.partition;
@@ -170,7 +197,7 @@ uint32_t ProgramBuilder::sparseLeaf(uint32_t seqstore_id, uint32_t position, uin
       const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
       const auto found = partition.sparse_cache.find(key);
       if (found != partition.sparse_cache.end()) {
-         return leaf(found->second.as<uint64_t>());
+         return found->second.as<uint64_t>();
       }
    }
    DeviceBuffer buffer = partition.pool.acquire(row_bytes);
@@ -178,17 +205,17 @@ uint32_t ProgramBuilder::sparseLeaf(uint32_t seqstore_id, uint32_t position, uin
       silo_gpu_store_sparse_plane(partition.store, seqstore_id, position, symbol, buffer.as<uint64_t>(), nullptr),
       "silo_gpu_store_sparse_plane"
    );
-   const uint32_t index = leaf(buffer.as<uint64_t>());
+   const uint64_t* pointer = buffer.as<uint64_t>();
    {
       const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
       if ((partition.sparse_cache.size() + 1) * row_bytes <= DatabasePartition::SPARSE_CACHE_BYTES &&
           partition.sparse_cache.find(key) == partition.sparse_cache.end()) {
          partition.sparse_cache.emplace(key, std::move(buffer));
-         return index;
+         return pointer;
       }
    }
    temporaries.push_back(std::move(buffer));
-   return index;
+   return pointer;
 }
 
 uint32_t ProgramBuilder::lowerChild(const operators::Operator& child) {
@@ -299,6 +326,9 @@ std::unique_ptr<Operator> IndexScan::copy() const {
 std::unique_ptr<Operator> IndexScan::negate() const {
    return std::make_unique<Complement>(copy(), rows);
 }
+const uint64_t* IndexScan::storedColumn(ProgramBuilder& builder) const {
+   return sparse ? builder.sparsePointer(seqstore_id, position, symbol) : bitmap;
+}
 uint32_t IndexScan::lower(ProgramBuilder& builder) const {
    // a leaf operand: the kernel stages every leaf in LDS up front, no instruction is emitted here
    const uint32_t index = sparse ? builder.sparseLeaf(seqstore_id, position, symbol) : builder.leaf(bitmap);
@@ -311,6 +341,9 @@ std::unique_ptr<Operator> BitmapSelection::copy() const {
 }
 std::unique_ptr<Operator> BitmapSelection::negate() const {
    return std::make_unique<BitmapSelection>(missing_plane, rows, comparator == CONTAINS ? NOT_CONTAINS : CONTAINS, value);
+}
+const uint64_t* BitmapSelection::storedColumn(ProgramBuilder& /*builder*/) const {
+   return comparator == CONTAINS ? missing_plane : nullptr;
 }
 uint32_t BitmapSelection::lower(ProgramBuilder& builder) const {
    const uint32_t operand = SILO_GPU_LEAF_OPERAND + builder.leaf(missing_plane);
@@ -384,10 +417,17 @@ std::unique_ptr<Operator> Intersection::negate() const {
 }
 uint32_t Intersection::lower(ProgramBuilder& builder) const {
    // The reference orders children by cardinality to keep roaring intermediates small
-   // (intersection.cpp:94-108); a dense word-parallel AND has no such sensitivity.
-   uint32_t acc = builder.lowerChild(*children[0]);
-   const auto combine = [&](uint32_t op, const Operator& child) {
-      const uint32_t tmp = builder.lowerChild(child);
+   // (intersection.cpp:94-108); a dense word-parallel AND has no such sensitivity.  Children that are
+   // stored columns are folded by ONE n-ary instruction (streamed 8 loads at a time).
+   const ProgramBuilder::Split positive = builder.split(children);
+   const ProgramBuilder::Split negative = builder.split(negated_children);
+   constexpr uint32_t NONE = ~0u;
+   uint32_t acc = NONE;
+   const auto combine = [&](uint32_t op, uint32_t tmp) {
+      if (acc == NONE) {
+         acc = tmp;
+         return;
+      }
       const uint32_t dst = isLeafOperand(acc) ? (isLeafOperand(tmp) ? builder.allocSlot() : tmp) : acc;
       builder.emit(op, dst, acc, tmp);
       if (dst != tmp) {
@@ -395,11 +435,25 @@ uint32_t Intersection::lower(ProgramBuilder& builder) const {
       }
       acc = dst;
    };
-   for (size_t i = 1; i < children.size(); ++i) {
-      combine(SILO_GPU_OP_AND, *children[i]);
+   if (positive.columns.size() >= 2) {
+      acc = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_AND_N, acc, 0, 0, builder.leafRun(positive.columns));
+   } else if (positive.columns.size() == 1) {
+      acc = SILO_GPU_LEAF_OPERAND + builder.leaf(positive.columns[0]);
    }
-   for (const auto& child : negated_children) {
-      combine(SILO_GPU_OP_ANDNOT, *child);
+   for (const Operator* child : positive.composite) {
+      combine(SILO_GPU_OP_AND, builder.lowerChild(*child));
+   }
+   // children is never empty (constructor), so acc is set here
+   if (negative.columns.size() >= 2) {
+      const uint32_t tmp = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_OR_N, tmp, 0, 0, builder.leafRun(negative.columns));
+      combine(SILO_GPU_OP_ANDNOT, tmp);
+   } else if (negative.columns.size() == 1) {
+      combine(SILO_GPU_OP_ANDNOT, SILO_GPU_LEAF_OPERAND + builder.leaf(negative.columns[0]));
+   }
+   for (const Operator* child : negative.composite) {
+      combine(SILO_GPU_OP_ANDNOT, builder.lowerChild(*child));
    }
    return acc;
 }
@@ -430,9 +484,21 @@ uint32_t Union::lower(ProgramBuilder& builder) const {
       builder.emit(SILO_GPU_OP_ZERO, slot);
       return slot;
    }
-   uint32_t acc = builder.lowerChild(*children[0]);
-   for (size_t i = 1; i < children.size(); ++i) {
-      const uint32_t tmp = builder.lowerChild(*children[i]);
+   const ProgramBuilder::Split parts = builder.split(children);
+   constexpr uint32_t NONE = ~0u;
+   uint32_t acc = NONE;
+   if (parts.columns.size() >= 2) {  // roaring fastunion (union.cpp:44) -> one streamed n-ary OR
+      acc = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_OR_N, acc, 0, 0, builder.leafRun(parts.columns));
+   } else if (parts.columns.size() == 1) {
+      acc = SILO_GPU_LEAF_OPERAND + builder.leaf(parts.columns[0]);
+   }
+   for (const Operator* child : parts.composite) {
+      const uint32_t tmp = builder.lowerChild(*child);
+      if (acc == NONE) {
+         acc = tmp;
+         continue;
+      }
       const uint32_t dst = isLeafOperand(acc) ? (isLeafOperand(tmp) ? builder.allocSlot() : tmp) : acc;
       builder.emit(SILO_GPU_OP_OR, dst, acc, tmp);
       if (dst != tmp) {
@@ -490,12 +556,20 @@ uint32_t Threshold::lower(ProgramBuilder& builder) const {
    for (uint32_t bit = 0; bit < bits; ++bit) {
       builder.emit(SILO_GPU_OP_ZERO, counter + bit);
    }
-   for (const auto& child : non_negated_children) {
+   const ProgramBuilder::Split positive = builder.split(non_negated_children);
+   const ProgramBuilder::Split negative = builder.split(negated_children);
+   if (!positive.columns.empty()) {
+      builder.emit(SILO_GPU_OP_CNT_ADD_N, counter, 0, bits, builder.leafRun(positive.columns));
+   }
+   if (!negative.columns.empty()) {
+      builder.emit(SILO_GPU_OP_CNT_ADD_NOT_N, counter, 0, bits, builder.leafRun(negative.columns));
+   }
+   for (const Operator* child : positive.composite) {
       const uint32_t tmp = builder.lowerChild(*child);
       builder.emit(SILO_GPU_OP_CNT_ADD, counter, tmp, bits);
       builder.freeSlot(tmp);
    }
-   for (const auto& child : negated_children) {
+   for (const Operator* child : negative.composite) {
       const uint32_t operand = builder.lowerChild(*child);
       const uint32_t tmp = isLeafOperand(operand) ? builder.allocSlot() : operand;
       builder.emit(SILO_GPU_OP_NOT, tmp, operand);

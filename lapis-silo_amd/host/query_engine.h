@@ -100,8 +100,17 @@ class ProgramBuilder {
    uint32_t writable(uint32_t operand);
    void emit(uint32_t op, uint32_t dst, uint32_t a = 0, uint32_t b = 0, uint32_t imm = 0);
    uint32_t leaf(const uint64_t* device_bitset);
-   /// Leaf for a symbol that is stored sparsely: scattered into a pooled temporary before launch.
+   /// Leaf for a symbol that is stored sparsely: scattered into a cached / pooled bitset before launch.
    uint32_t sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol);
+   const uint64_t* sparsePointer(uint32_t seqstore_id, uint32_t position, uint32_t symbol);
+   /// Appends `columns` as consecutive leaves; returns the imm of an n-ary instruction (first | count << 16).
+   uint32_t leafRun(const std::vector<const uint64_t*>& columns);
+   /// Children that are stored columns (foldable by one n-ary instruction) vs composite sub-trees.
+   struct Split {
+      std::vector<const uint64_t*> columns;
+      std::vector<const operators::Operator*> composite;
+   };
+   Split split(const std::vector<std::unique_ptr<operators::Operator>>& children);
    /// Lowers `child` into this program, or — when it would not fit the instruction / leaf budget —
    /// evaluates it with its own launch and loads the result as a leaf.
    uint32_t lowerChild(const operators::Operator& child);
@@ -142,8 +151,10 @@ class Operator {
    virtual std::unique_ptr<Operator> copy() const = 0;
    virtual std::unique_ptr<Operator> negate() const = 0;
 
-   /// Emits this subtree into `builder`; returns the slot that holds its value (caller frees it).
+   /// Emits this subtree into `builder`; returns the slot (or leaf operand) that holds its value.
    virtual uint32_t lower(ProgramBuilder& builder) const = 0;
+   /// Device pointer when this operator is just a stored column (IndexScan, BitmapSelection CONTAINS).
+   virtual const uint64_t* storedColumn(ProgramBuilder& /*builder*/) const { return nullptr; }
    [[nodiscard]] virtual Cost cost() const = 0;
 
    const RowSpace rows;
@@ -184,6 +195,7 @@ class IndexScan : public Operator {
    std::unique_ptr<Operator> copy() const override;
    std::unique_ptr<Operator> negate() const override;
    uint32_t lower(ProgramBuilder& builder) const override;
+   const uint64_t* storedColumn(ProgramBuilder& builder) const override;
    Cost cost() const override { return {1, 1}; }
 
    const uint64_t* bitmap = nullptr;
@@ -203,6 +215,7 @@ class BitmapSelection : public Operator {
    std::unique_ptr<Operator> copy() const override;
    std::unique_ptr<Operator> negate() const override;
    uint32_t lower(ProgramBuilder& builder) const override;
+   const uint64_t* storedColumn(ProgramBuilder& builder) const override;
    Cost cost() const override { return {2, 1}; }
 
    const uint64_t* missing_plane;

@@ -177,7 +177,8 @@ class GpuEvent:
 
 
 # bit-program opcodes (include/silo_gpu.h)
-OP_LOAD, OP_ZERO, OP_ONES, OP_NOT, OP_AND, OP_OR, OP_ANDNOT, OP_CNT_ADD, OP_CNT_GE, OP_CNT_EQ, OP_MOV = range(11)
+(OP_LOAD, OP_ZERO, OP_ONES, OP_NOT, OP_AND, OP_OR, OP_ANDNOT, OP_CNT_ADD, OP_CNT_GE, OP_CNT_EQ, OP_MOV,
+ OP_OR_N, OP_AND_N, OP_CNT_ADD_N, OP_CNT_ADD_NOT_N) = range(15)
 
 
 COUNT_SHARDS = 64   # SILO_GPU_COUNT_SHARDS

@@ -91,6 +91,20 @@ def test_bitprog_semantics(bitprog, n):
     code = (b.encode(b.OP_LOAD, 1, imm=0) + b.encode(b.OP_LOAD, 2, imm=1) + b.encode(b.OP_ANDNOT, 3, 1, 2)
             + b.encode(b.OP_LOAD, 1, imm=2) + b.encode(b.OP_OR, 3, 3, 1) + b.encode(b.OP_MOV, 0, 3))
     assert np.array_equal(bitprog(code, masks, n), (masks[0] & ~masks[1]) | masks[2])
+    # n-ary forms over runs of consecutive leaves (imm = first | count << 16), incl. runs longer than one batch of 8
+    many = masks + [rng.random(n) < 0.97 for _ in range(13)]
+    for first, count in [(0, 1), (0, 7), (2, 5), (0, 8), (0, 9), (3, 17), (0, 20)]:
+        run = many[first:first + count]
+        imm = first | (count << 16)
+        assert np.array_equal(bitprog(b.encode(b.OP_OR_N, 0, imm=imm), many, n), np.logical_or.reduce(run)), (first, count)
+        assert np.array_equal(bitprog(b.encode(b.OP_AND_N, 0, imm=imm), many, n), np.logical_and.reduce(run)), (first, count)
+        zero = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3) + b.encode(b.OP_ZERO, 4) + b.encode(b.OP_ZERO, 5)
+        total_run = sum(m.astype(int) for m in run)
+        for k in (0, 1, count // 2, count, count + 1):
+            code = zero + b.encode(b.OP_CNT_ADD_N, 1, 0, 5, imm=imm) + b.encode(b.OP_CNT_GE, 0, 1, 5, imm=k)
+            assert np.array_equal(bitprog(code, many, n), total_run >= k), (first, count, k)
+            code = zero + b.encode(b.OP_CNT_ADD_NOT_N, 1, 0, 5, imm=imm) + b.encode(b.OP_CNT_EQ, 0, 1, 5, imm=k)
+            assert np.array_equal(bitprog(code, many, n), (count - total_run) == k), (first, count, k)
     total = sum(m.astype(int) for m in masks)
     for k in range(0, 10):
         code = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3)

@@ -133,6 +133,13 @@ def test_filter_eval_ops(built, n):
                 + b.encode(b.OP_ANDNOT, 0, 0, L + 3))
         check(code, 2, ((masks[0] & masks[1]) | ~masks[2]) & ~masks[3])
         check(b.encode(b.OP_MOV, 0, L + 4), 1, masks[4])
+        # n-ary runs: Or / And over leaves 0..4 and 1..3, 2-of-5 and "exactly 1 of the complements"
+        check(b.encode(b.OP_OR_N, 0, imm=0 | (5 << 16)), 1, np.logical_or.reduce(masks))
+        check(b.encode(b.OP_AND_N, 0, imm=1 | (3 << 16)), 1, masks[1] & masks[2] & masks[3])
+        zero3 = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3)
+        total5 = sum(m.astype(int) for m in masks)
+        check(zero3 + b.encode(b.OP_CNT_ADD_N, 1, 0, 3, imm=0 | (5 << 16)) + b.encode(b.OP_CNT_GE, 0, 1, 3, imm=2), 4, total5 >= 2)
+        check(zero3 + b.encode(b.OP_CNT_ADD_NOT_N, 1, 0, 3, imm=0 | (5 << 16)) + b.encode(b.OP_CNT_EQ, 0, 1, 3, imm=1), 4, (5 - total5) == 1)
         check(b.encode(b.OP_ONES, 0), 1, full)
         check(b.encode(b.OP_ZERO, 0), 1, ~full)
         check(b.encode(b.OP_ZERO, 0) + b.encode(b.OP_NOT, 0, 0), 1, full)
