@@ -135,6 +135,10 @@ int silo_gpu_malloc(size_t bytes, void** out_dev);
 int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream); /* synchronises */
 int silo_gpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream); /* synchronises */
 int silo_gpu_stream_synchronize(void* stream);
+/* A non-blocking HIP stream (does not synchronise with the null stream); every `void* stream` parameter of
+ * this ABI accepts one, or NULL for the null stream. */
+int silo_gpu_stream_create(void** out_stream);
+void silo_gpu_stream_destroy(void* stream);
 
 /* Device pointer of the dense plane of (seqstore, position, symbol), or NULL when that symbol is
  * sparse / not stored.  Replaces SequenceStorePartition::getBitmap (sequence_store.cpp:92-98);

@@ -1174,6 +1174,22 @@ void silo_gpu_event_destroy(void* event) {
    (void)hipEventDestroy(static_cast<hipEvent_t>(event));
 }
 
+int silo_gpu_stream_create(void** out_stream) {
+   if (out_stream == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_stream_create: null out pointer");
+   }
+   hipStream_t stream = nullptr;
+   HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+   *out_stream = stream;
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_stream_destroy(void* stream) {
+   if (stream != nullptr) {
+      (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+   }
+}
+
 int silo_gpu_stream_synchronize(void* stream) {
    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
    return SILO_GPU_OK;

@@ -71,7 +71,7 @@ namespace {
 /// Sums `n` uint32 across ranks in place on the device (no-op for a single rank).
 void allReduce(const Database& database, uint32_t* device_values, size_t n) {
    if (database.all_reduce != nullptr) {  // also with a single rank: lets a 1-GPU box exercise the collective path
-      const int status = database.all_reduce(database.all_reduce_context, device_values, n, nullptr);
+      const int status = database.all_reduce(database.all_reduce_context, device_values, n, queryStream());
       if (status != 0) {
          throw DeviceException("all-reduce of counts failed with status " + std::to_string(status));
       }
@@ -101,9 +101,9 @@ QueryResult Aggregated::execute(const Database& database, std::vector<OperatorRe
       // sequence-id sharding: every rank holds different rows
       const DatabasePartition& partition = database.partitions.front();
       DeviceBuffer buffer = partition.pool.acquire(sizeof(uint32_t));
-      checkGpu(silo_gpu_memcpy_h2d(buffer.get(), &count, sizeof(count), nullptr), "silo_gpu_memcpy_h2d");
+      checkGpu(silo_gpu_memcpy_h2d(buffer.get(), &count, sizeof(count), queryStream()), "silo_gpu_memcpy_h2d");
       allReduce(database, buffer.as<uint32_t>(), 1);
-      checkGpu(silo_gpu_memcpy_d2h(&count, buffer.get(), sizeof(count), nullptr), "silo_gpu_memcpy_d2h");
+      checkGpu(silo_gpu_memcpy_d2h(&count, buffer.get(), sizeof(count), queryStream()), "silo_gpu_memcpy_d2h");
    }
    std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> tuple_fields;
    tuple_fields["count"] = static_cast<int32_t>(count);
@@ -151,24 +151,24 @@ std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
    const auto [pos_begin, pos_end] = database.positionWindow(sequence_length);
    const DatabasePartition& home = database.partitions.front();
    DeviceBuffer device_counts = home.pool.acquire(n_counts * sizeof(uint32_t));
-   checkGpu(silo_gpu_memset_async(device_counts.get(), 0, n_counts * sizeof(uint32_t), nullptr), "silo_gpu_memset_async");
+   checkGpu(silo_gpu_memset_async(device_counts.get(), 0, n_counts * sizeof(uint32_t), queryStream()), "silo_gpu_memset_async");
    uint32_t* window = device_counts.as<uint32_t>() + static_cast<size_t>(pos_begin) * n_symbols;
    // the device store of a rank holds exactly its window: local positions [0, pos_end - pos_begin)
    const uint32_t local_positions = pos_end - pos_begin;
    for (const auto& [filter, store] : bitmap_filter.bitmaps) {
       checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), 0, local_positions, window, nullptr),
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), 0, local_positions, window, queryStream()),
          "silo_gpu_mutations_scan"
       );
    }
    for (const auto& [filter, store] : bitmap_filter.full_bitmaps) {
       // full filter: the reference reads plain cardinalities (mutations.cpp:98-136); NULL = all rows
       checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, 0, local_positions, window, nullptr), "silo_gpu_mutations_scan"
+         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, 0, local_positions, window, queryStream()), "silo_gpu_mutations_scan"
       );
    }
    allReduce(database, device_counts.as<uint32_t>(), n_counts);
-   checkGpu(silo_gpu_memcpy_d2h(counts.data(), device_counts.get(), n_counts * sizeof(uint32_t), nullptr), "silo_gpu_memcpy_d2h");
+   checkGpu(silo_gpu_memcpy_d2h(counts.data(), device_counts.get(), n_counts * sizeof(uint32_t), queryStream()), "silo_gpu_memcpy_d2h");
    return counts;
 }
 

@@ -208,6 +208,8 @@ int silo_engine_set_sharding(
    engine->database.shard_by_position = shard_by_position != 0;
    engine->database.all_reduce = all_reduce;
    engine->database.all_reduce_context = context;
+   // the collective is ordered against the null stream by its provider (torch.distributed / RCCL)
+   silo::setQueryStreamsEnabled(all_reduce == nullptr);
    return 0;
 }
 

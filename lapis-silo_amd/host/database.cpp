@@ -1,6 +1,7 @@
 #include "database.h"
 
 #include <algorithm>
+#include <atomic>
 #include <sstream>
 
 #include "query_engine.h"
@@ -11,6 +12,36 @@ void checkGpu(int status, const char* what) {
    if (status != SILO_GPU_OK) {
       throw DeviceException(std::string(what) + ": " + silo_gpu_last_error());
    }
+}
+
+// ---- per-thread streams ---------------------------------------------------------------------------
+namespace {
+
+std::atomic<bool> g_query_streams_enabled{true};
+
+struct ThreadStream {  // never destroyed: thread exit may come after the HIP runtime has shut down
+   void* stream = nullptr;
+   bool tried = false;
+};
+
+}  // namespace
+
+void setQueryStreamsEnabled(bool enabled) {
+   g_query_streams_enabled.store(enabled);
+}
+
+void* queryStream() {
+   if (!g_query_streams_enabled.load()) {
+      return nullptr;
+   }
+   thread_local ThreadStream holder;
+   if (!holder.tried) {
+      holder.tried = true;
+      if (silo_gpu_stream_create(&holder.stream) != SILO_GPU_OK) {
+         holder.stream = nullptr;  // fall back to the null stream
+      }
+   }
+   return holder.stream;
 }
 
 // ---- device pool --------------------------------------------------------------------------------

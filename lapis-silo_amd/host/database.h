@@ -42,6 +42,14 @@ class DeviceException : public std::runtime_error {
 };
 void checkGpu(int status, const char* what);
 
+/// The HIP stream the calling thread's query work is issued on.  Every request thread gets its own
+/// non-blocking stream, so concurrent executeQuery calls (silo_api runs one thread per request,
+/// database_mutex.cpp:20-23) overlap on the device instead of serialising on the null stream.  When a
+/// collective callback is installed (multi-GPU) the null stream is used, which is what torch.distributed
+/// orders its RCCL work against.
+void* queryStream();
+void setQueryStreamsEnabled(bool enabled);
+
 /// RAII device allocation taken from / returned to a per-database pool (no hipMalloc on the hot path).
 class DevicePool;
 class DeviceBuffer {

@@ -33,13 +33,13 @@ constexpr size_t COUNT_BYTES = SILO_GPU_COUNT_SHARDS * sizeof(uint64_t);
 
 DeviceBuffer zeroedCounter(const DatabasePartition& partition) {
    DeviceBuffer counter = partition.pool.acquire(COUNT_BYTES);
-   checkGpu(silo_gpu_memset_async(counter.get(), 0, COUNT_BYTES, nullptr), "silo_gpu_memset_async");
+   checkGpu(silo_gpu_memset_async(counter.get(), 0, COUNT_BYTES, queryStream()), "silo_gpu_memset_async");
    return counter;
 }
 
 uint32_t readCount(const DeviceBuffer& counter) {
    uint64_t shards[SILO_GPU_COUNT_SHARDS];
-   checkGpu(silo_gpu_memcpy_d2h(shards, counter.get(), COUNT_BYTES, nullptr), "silo_gpu_memcpy_d2h");
+   checkGpu(silo_gpu_memcpy_d2h(shards, counter.get(), COUNT_BYTES, queryStream()), "silo_gpu_memcpy_d2h");
    uint64_t total = 0;
    for (const uint64_t shard : shards) {
       total += shard;
@@ -64,12 +64,12 @@ void OperatorResult::materialize() const {
    const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
    if (scan != nullptr && !scan->sparse) {
       state->borrowed = scan->bitmap;  // index_scan.cpp:28-30: borrow, no copy
-      checkGpu(silo_gpu_popcount(partition.store, scan->bitmap, counter.as<uint64_t>(), nullptr), "silo_gpu_popcount");
+      checkGpu(silo_gpu_popcount(partition.store, scan->bitmap, counter.as<uint64_t>(), queryStream()), "silo_gpu_popcount");
    } else {
       DeviceBuffer out = partition.pool.acquire(row_bytes);
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
-      builder.run(slot, out.as<uint64_t>(), counter.as<uint64_t>(), nullptr);
+      builder.run(slot, out.as<uint64_t>(), counter.as<uint64_t>(), queryStream());
       state->bitset = std::move(out);
    }
    state->count = readCount(counter);
@@ -94,7 +94,7 @@ uint32_t OperatorResult::cardinality() const {
       DeviceBuffer counter = zeroedCounter(partition);
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
-      builder.run(slot, nullptr, counter.as<uint64_t>(), nullptr);
+      builder.run(slot, nullptr, counter.as<uint64_t>(), queryStream());
       state->count = readCount(counter);
       return *state->count;
    }
@@ -202,10 +202,12 @@ const uint64_t* ProgramBuilder::sparsePointer(uint32_t seqstore_id, uint32_t pos
    }
    DeviceBuffer buffer = partition.pool.acquire(row_bytes);
    checkGpu(
-      silo_gpu_store_sparse_plane(partition.store, seqstore_id, position, symbol, buffer.as<uint64_t>(), nullptr),
+      silo_gpu_store_sparse_plane(partition.store, seqstore_id, position, symbol, buffer.as<uint64_t>(), queryStream()),
       "silo_gpu_store_sparse_plane"
    );
    const uint64_t* pointer = buffer.as<uint64_t>();
+   // other threads (on their own streams) may pick the plane up from the cache at once: finish it first
+   checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");
    {
       const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
       if ((partition.sparse_cache.size() + 1) * row_bytes <= DatabasePartition::SPARSE_CACHE_BYTES &&

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_store_finalize", "silo_gpu_store_generate_synthetic", "silo_gpu_bitset_alloc",
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
-    "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_store_plane",
+    "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
@@ -126,6 +126,9 @@ def load_library():
     lib.silo_gpu_upload_u32.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.silo_gpu_bitset_from_value_ids.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
     lib.silo_gpu_stream_synchronize.argtypes = [vp]
+    lib.silo_gpu_stream_create.argtypes = [ctypes.POINTER(vp)]
+    lib.silo_gpu_stream_destroy.argtypes = [vp]
+    lib.silo_gpu_stream_destroy.restype = None
     lib.silo_gpu_store_plane.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.silo_gpu_store_plane.restype = vp
     lib.silo_gpu_store_sparse_plane.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
