@@ -1138,8 +1138,30 @@ int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) 
 }
 
 int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
-   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
-   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+   // Results (count shards, the counts[P][S] table) are small: bounce them through a per-thread pinned
+   // buffer so the copy is one DMA instead of the runtime's staged pageable path.
+   constexpr size_t PINNED_BYTES = 4u << 20;
+   struct Pinned {  // never freed: thread exit may come after the HIP runtime has shut down
+      void* ptr = nullptr;
+      bool tried = false;
+   };
+   thread_local Pinned pinned;
+   if (bytes <= PINNED_BYTES && !pinned.tried) {
+      pinned.tried = true;
+      if (hipHostMalloc(&pinned.ptr, PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
+         (void)hipGetLastError();
+         pinned.ptr = nullptr;
+      }
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   if (bytes <= PINNED_BYTES && pinned.ptr != nullptr) {
+      HIP_TRY(hipMemcpyAsync(pinned.ptr, src_dev, bytes, hipMemcpyDeviceToHost, hip_stream));
+      HIP_TRY(hipStreamSynchronize(hip_stream));
+      memcpy(dst_host, pinned.ptr, bytes);
+      return SILO_GPU_OK;
+   }
+   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, hip_stream));
+   HIP_TRY(hipStreamSynchronize(hip_stream));
    return SILO_GPU_OK;
 }
 
