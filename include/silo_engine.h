@@ -74,6 +74,10 @@ void silo_engine_free_string(char* text);
 /* The reference's two per-query timings (query_engine.cpp:63-65) of the last query on this thread. */
 void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_microseconds);
 
+/* Phase marks of the last query on this thread as JSON {"phase": microseconds since the query began, ...};
+ * *out_json is malloc'ed (free with silo_engine_free_string). */
+int silo_engine_last_trace(char** out_json);
+
 /* Device store of a partition, for callers that drive the kernels directly (bench roofline leg). */
 silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int partition);
 /* silo_gpu sequence-store index of a named store inside a partition, or -1. */

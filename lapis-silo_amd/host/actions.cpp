@@ -167,8 +167,10 @@ std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
          silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, 0, local_positions, window, queryStream()), "silo_gpu_mutations_scan"
       );
    }
+   Trace::mark("scan_launched");
    allReduce(database, device_counts.as<uint32_t>(), n_counts);
    checkGpu(silo_gpu_memcpy_d2h(counts.data(), device_counts.get(), n_counts * sizeof(uint32_t), queryStream()), "silo_gpu_memcpy_d2h");
+   Trace::mark("counts_on_host");
    return counts;
 }
 
@@ -239,6 +241,7 @@ QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector
       }
    }
    std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, bitmap_filter);
+   Trace::mark("filter_materialized");
 
    std::vector<QueryResultEntry> mutation_proportions;
    for (const auto& sequence_name : sequence_names_to_evaluate) {
@@ -251,6 +254,7 @@ QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector
          addMutationsToOutput(database, sequence_name, sequence_store, PrefilteredBitmaps{}, mutation_proportions);
       }
    }
+   Trace::mark("rows_built");
    return {mutation_proportions};
 }
 

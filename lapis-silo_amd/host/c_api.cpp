@@ -249,6 +249,14 @@ void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_micr
    }
 }
 
+int silo_engine_last_trace(char** out_json) {
+   if (out_json == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_last_trace: null argument");
+   }
+   *out_json = duplicate(silo::Trace::json());
+   return *out_json != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+}
+
 silo_gpu_store* silo_engine_partition_store(const silo_engine* engine, int partition) {
    if (engine == nullptr || partition < 0 || static_cast<size_t>(partition) >= engine->database.partitions.size()) {
       return nullptr;

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <sstream>
 
 #include "query_engine.h"
@@ -42,6 +43,44 @@ void* queryStream() {
       }
    }
    return holder.stream;
+}
+
+// ---- trace --------------------------------------------------------------------------------------
+namespace {
+
+struct TraceState {
+   std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+   std::vector<std::pair<const char*, int64_t>> marks;
+};
+
+TraceState& traceState() {
+   thread_local TraceState state;
+   return state;
+}
+
+}  // namespace
+
+void Trace::reset() {
+   TraceState& state = traceState();
+   state.start = std::chrono::steady_clock::now();
+   state.marks.clear();
+}
+
+void Trace::mark(const char* name) {
+   TraceState& state = traceState();
+   state.marks.emplace_back(
+      name, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - state.start).count()
+   );
+}
+
+std::string Trace::json() {
+   std::string out = "{";
+   bool first = true;
+   for (const auto& [name, microseconds] : traceState().marks) {
+      out += std::string(first ? "" : ",") + "\"" + name + "\":" + std::to_string(microseconds);
+      first = false;
+   }
+   return out + "}";
 }
 
 // ---- device pool --------------------------------------------------------------------------------

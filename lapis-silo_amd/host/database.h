@@ -50,6 +50,14 @@ void checkGpu(int status, const char* what);
 void* queryStream();
 void setQueryStreamsEnabled(bool enabled);
 
+/// Phase marks of the calling thread's last query, microseconds since the query began — the finer
+/// grained companion of the reference's two LOG_PERFORMANCE timings (query_engine.cpp:63-65).
+struct Trace {
+   static void reset();
+   static void mark(const char* name);
+   static std::string json();  // {"phase": microseconds, ...} in mark order
+};
+
 /// RAII device allocation taken from / returned to a per-database pool (no hipMalloc on the hot path).
 class DevicePool;
 class DeviceBuffer {

@@ -43,7 +43,9 @@ class BlockTimer {  // include/silo/common/block_timer.h:5-23
 }  // namespace
 
 QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  // query_engine.cpp:30-68
+   Trace::reset();
    const Query query(query_string);
+   Trace::mark("parsed");
 
    std::vector<OperatorResult> partition_filters(database.partitions.size());
    int64_t filter_time = 0;
@@ -58,12 +60,14 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
          partition_filters[partition_index] = part_filter->evaluate();
       }
    }
+   Trace::mark("compiled");
    QueryResult query_result;
    int64_t action_time = 0;
    {
       const BlockTimer timer(action_time);
       query_result = query.action->executeAndOrder(database, std::move(partition_filters));
    }
+   Trace::mark("action_done");
    Database::lastTimings() = {filter_time, action_time};
    return query_result;
 }

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
     "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_execute_query", "silo_engine_free_string",
-    "silo_engine_last_timings", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
+    "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
 
@@ -51,6 +51,7 @@ def load_library():
     lib.silo_engine_free_string.restype = None
     lib.silo_engine_last_timings.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
     lib.silo_engine_last_timings.restype = None
+    lib.silo_engine_last_trace.argtypes = [ctypes.POINTER(vp)]
     lib.silo_engine_partition_store.argtypes = [vp, ctypes.c_int]
     lib.silo_engine_partition_store.restype = vp
     lib.silo_engine_seqstore_id.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
@@ -208,6 +209,15 @@ class Engine:
         filter_us, action_us = ctypes.c_int64(), ctypes.c_int64()
         self.lib.silo_engine_last_timings(ctypes.byref(filter_us), ctypes.byref(action_us))
         return filter_us.value, action_us.value
+
+    def last_trace(self):
+        """Phase marks (µs since the query began) of the last query on this thread."""
+        out = ctypes.c_void_p()
+        _check(self.lib.silo_engine_last_trace(ctypes.byref(out)))
+        try:
+            return json.loads(ctypes.string_at(out).decode())
+        finally:
+            self.lib.silo_engine_free_string(out)
 
     def position_window(self, name, is_aa):
         begin, end = ctypes.c_uint32(), ctypes.c_uint32()
