@@ -195,13 +195,14 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
 
     query = filter_query(model, tree)
     count = engine.execute_query(query)[0]["count"]   # also warms the lineage / sparse-plane caches
+    wire = query.encode()
     for _ in range(5):
-        engine.execute_query(query)
+        engine.execute_text(wire)
     sync()
     n = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        engine.execute_query(query)
+        engine.execute_text(wire)
         n += 1
     sequential = (time.perf_counter() - t0) / n
 
@@ -211,7 +212,7 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
         k = 0
         end = time.perf_counter() + seconds
         while time.perf_counter() < end:
-            engine.execute_query(query)
+            engine.execute_text(wire)
             k += 1
         done.append(k)
 
@@ -235,15 +236,19 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
 
 
 def run_steps(engine, query, steps, warmup, sync):
+    query = query.encode()
     for _ in range(warmup):
-        engine.execute_query(query)
+        engine.execute_text(query)
     sync()
     t0 = time.perf_counter()
-    rows = None
+    body = None
     for _ in range(steps):
-        rows = engine.execute_query(query)
+        status, body = engine.execute_text(query)   # the response body, as silo_api would send it
     sync()
-    return time.perf_counter() - t0, rows
+    elapsed = time.perf_counter() - t0
+    if status != 200:
+        raise RuntimeError(body.decode())
+    return elapsed, json.loads(body.decode())["queryResult"]
 
 
 def main():

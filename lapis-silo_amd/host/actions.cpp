@@ -212,13 +212,16 @@ void Mutations<SymbolType>::addMutationsToOutput(
             const uint32_t count = counts_at_position[s];
             if (count > threshold_count) {
                const double proportion = static_cast<double>(count) / static_cast<double>(total);
-               const std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> fields{
-                  {MUTATION_FIELD_NAME,
-                   SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(pos + 1) + SymbolType::symbolToChar(symbol)},
-                  {SEQUENCE_FIELD_NAME, sequence_name},
-                  {PROPORTION_FIELD_NAME, proportion},
-                  {COUNT_FIELD_NAME, static_cast<int32_t>(count)}};
-               output.push_back({fields});
+               // same four fields as mutations.cpp:213-224, built in place (the reference copies a temporary map)
+               QueryResultEntry& entry = output.emplace_back();
+               // keys arrive in map order: count < mutation < proportion < sequenceName
+               entry.fields.emplace_hint(entry.fields.end(), COUNT_FIELD_NAME, static_cast<int32_t>(count));
+               entry.fields.emplace_hint(
+                  entry.fields.end(), MUTATION_FIELD_NAME,
+                  SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(pos + 1) + SymbolType::symbolToChar(symbol)
+               );
+               entry.fields.emplace_hint(entry.fields.end(), PROPORTION_FIELD_NAME, proportion);
+               entry.fields.emplace_hint(entry.fields.end(), SEQUENCE_FIELD_NAME, sequence_name);
             }
          }
       }

@@ -187,17 +187,24 @@ class Engine:
         self._callbacks.append(callback)
         _check(self.lib.silo_engine_set_sharding(self.handle, rank, world, int(shard_by_position), callback, None))
 
-    def execute_raw(self, query):
-        """Returns (http_status, parsed JSON document)."""
-        text = query if isinstance(query, str) else json.dumps(query)
+    def execute_text(self, query):
+        """Returns (http_status, response body as bytes) — what silo_api would put on the wire."""
+        text = query if isinstance(query, (str, bytes)) else json.dumps(query)
+        if isinstance(text, str):
+            text = text.encode()
         out = ctypes.c_void_p()
         status = ctypes.c_int()
-        _check(self.lib.silo_engine_execute_query(self.handle, text.encode(), ctypes.byref(out), ctypes.byref(status)))
+        _check(self.lib.silo_engine_execute_query(self.handle, text, ctypes.byref(out), ctypes.byref(status)))
         try:
-            document = json.loads(ctypes.string_at(out).decode())
+            body = ctypes.string_at(out)
         finally:
             self.lib.silo_engine_free_string(out)
-        return status.value, document
+        return status.value, body
+
+    def execute_raw(self, query):
+        """Returns (http_status, parsed JSON document)."""
+        status, body = self.execute_text(query)
+        return status, json.loads(body.decode())
 
     def execute_query(self, query):
         status, document = self.execute_raw(query)
