@@ -74,3 +74,48 @@ def test_bench_rccl_path_on_one_gpu(built):
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
     assert b["config"]["sharding"].startswith("position-range x1")
     assert b["roofline"]["frac"] > 0.05
+
+
+@pytest.mark.gpu
+def test_position_window_shards_partition_the_unsharded_result(built):
+    """Each rank of a position-range sharded database generates and scans only its slice of the genome
+    (bench.py --gpus N).  Without a collective, a rank's Mutations rows are exactly the unsharded rows whose
+    position lies in its window; the windows tile the genome."""
+    import re
+
+    root = os.path.dirname(HERE)
+    sys.path[:0] = [root, os.path.join(root, "lapis-silo_amd")]
+    import bench
+
+    n = 150_000
+    query = bench.make_query()
+    engine, model, tree, lineage, window = bench.build_engine(n, 0, 1, None, 0)
+    assert window == (0, model.positions)
+    full = engine.execute_query(query)
+    count = engine.execute_query({"action": {"type": "Aggregated"}, "filterExpression": json.loads(query)["filterExpression"]})
+    engine.close()
+    assert len(full) > 100
+
+    def position(row):
+        return int(re.match(r"^[^0-9]*([0-9]+)", row["mutation"]).group(1)) - 1
+
+    world = 3
+    seen = []
+    previous_end = 0
+    for rank in range(world):
+        shard, _, _, _, shard_window = bench.build_engine(n, rank, world, None, 0, sharded=True)
+        assert shard_window[0] == previous_end
+        previous_end = shard_window[1]
+        rows = shard.execute_query(query)
+        assert rows == [row for row in full if shard_window[0] <= position(row) < shard_window[1]]
+        # single-filter cardinality needs no exchange: every rank holds all rows
+        assert shard.execute_query({"action": {"type": "Aggregated"}, "filterExpression": json.loads(query)["filterExpression"]}) == count
+        # a leaf outside the window is reported, not silently wrong
+        outside = shard_window[1] + 1 if rank < world - 1 else 1
+        status, document = shard.execute_raw({"action": {"type": "Aggregated"},
+                                              "filterExpression": {"type": "NucleotideEquals", "position": outside, "symbol": "A"}})
+        assert status == 500 and "not resident" in document["message"]
+        seen.extend(rows)
+        shard.close()
+    assert previous_end == model.positions
+    assert seen == full
