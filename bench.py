@@ -61,6 +61,8 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False):
     engine = Engine(genomes, device=device)
     if world > 1 or sharded:
         engine.set_sharding(rank, world, True, all_reduce)
+        if getattr(build_engine, "broadcast", None) is not None:
+            engine.set_broadcast(build_engine.broadcast)
     partition = engine.add_partition(n_sequences)
     window = engine.position_window("main", False)
     engine.generate_synthetic(partition, "main", False, model, window)
@@ -299,6 +301,16 @@ def main():
         def all_reduce(device_ptr, n, _stream):
             tensor = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI; ordered after the scan on the null stream
+
+        class DeviceBytes:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        def broadcast(device_ptr, nbytes, root, _stream):
+            tensor = torch.as_tensor(DeviceBytes(device_ptr, nbytes), device=torch.device("cuda", local_rank))
+            dist.broadcast(tensor, src=root)  # a filter leaf travelling from the rank that owns its position
+
+        build_engine.broadcast = broadcast
 
         def sync():
             dist.barrier()

@@ -65,6 +65,12 @@ int silo_engine_set_sharding(
    silo_engine* engine, uint32_t rank, uint32_t world, int shard_by_position, silo_engine_all_reduce_u32 all_reduce, void* context
 );
 
+/* Position-range sharding only: broadcast `bytes` device bytes in place from rank `root` to all ranks.
+ * With it installed, a filter leaf at a position another rank owns is fetched from that rank (every
+ * rank must run the same queries in the same order); without it such a leaf is a 500 "not resident". */
+typedef int (*silo_engine_broadcast_bytes)(void* context, void* device_bytes, size_t bytes, uint32_t root, void* stream);
+int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes broadcast, void* context);
+
 /* Executes one query.  *out_json is malloc'ed (free with silo_engine_free_string) and holds either the
  * result or the error document; *out_http_status is 200, 400 or 500.  Returns 0 unless the arguments
  * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */

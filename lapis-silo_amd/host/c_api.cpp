@@ -213,6 +213,18 @@ int silo_engine_set_sharding(
    return 0;
 }
 
+int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes broadcast, void* context) {
+   if (engine == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_broadcast: null engine");
+   }
+   engine->database.broadcast = broadcast;
+   engine->database.broadcast_context = context;
+   if (broadcast != nullptr) {
+      silo::setQueryStreamsEnabled(false);  // collectives are ordered against the null stream
+   }
+   return 0;
+}
+
 int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status) {
    if (engine == nullptr || query_json == nullptr || out_json == nullptr || out_http_status == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_execute_query: null argument");

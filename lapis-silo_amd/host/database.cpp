@@ -294,6 +294,16 @@ std::pair<uint32_t, uint32_t> Database::positionWindow(size_t length) const {
       static_cast<uint32_t>(static_cast<uint64_t>(length) * (shard_rank + 1) / shard_world)};
 }
 
+uint32_t Database::ownerOfPosition(size_t position, size_t length) const {
+   for (uint32_t rank = 0; rank < shard_world; ++rank) {
+      const auto end = static_cast<uint64_t>(length) * (rank + 1) / shard_world;
+      if (position < end) {
+         return rank;
+      }
+   }
+   return shard_world - 1;
+}
+
 void Database::setReferenceGenomes(const json::Value& reference_genomes) {  // reference_genomes.cpp
    nuc_sequences.clear();
    aa_sequences.clear();

@@ -222,6 +222,10 @@ class DatabasePartition {
 /// ranks in place, on `stream`.  bench.py backs it with torch.distributed (RCCL over xGMI); a native
 /// host would call ncclAllReduce.  SURVEY.md §8(e).
 using AllReduceU32 = int (*)(void* context, uint32_t* device_values, size_t n, void* stream);
+/// Broadcast of `bytes` device bytes from rank `root` to every rank (in place).  Used under position-range
+/// sharding to hand a filter leaf (one 1.25 MB plane at 10 M sequences) from the rank that owns its
+/// position to the others; every rank runs the same queries in the same order (SPMD).
+using BroadcastBytes = int (*)(void* context, void* device_bytes, size_t bytes, uint32_t root, void* stream);
 
 class Database {
   public:
@@ -246,6 +250,11 @@ class Database {
    bool shard_by_position = false;
    AllReduceU32 all_reduce = nullptr;
    void* all_reduce_context = nullptr;
+   BroadcastBytes broadcast = nullptr;
+   void* broadcast_context = nullptr;
+
+   /// Rank whose position window contains `position` of a genome of `length` positions.
+   [[nodiscard]] uint32_t ownerOfPosition(size_t position, size_t length) const;
 
    /// Timings of the last query on this thread, the reference's two phases (query_engine.cpp:63-65).
    struct Timings {

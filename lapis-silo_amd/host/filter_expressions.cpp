@@ -43,15 +43,50 @@ const std::array<std::vector<NS>, Nucleotide::COUNT> AMBIGUITY_NUC_SYMBOLS{{
 /// effect: the dense store holds the true membership plane of every symbol.
 template <typename SymbolType>
 std::unique_ptr<Operator> symbolPlane(
-   const SequenceStorePartition<SymbolType>& store, const DatabasePartition& partition, uint32_t position, typename SymbolType::Symbol symbol
+   const Database& database, const SequenceStorePartition<SymbolType>& store, const DatabasePartition& partition, uint32_t position,
+   typename SymbolType::Symbol symbol
 ) {
    const RowSpace rows = rowsOf(partition);
+   const bool exchange = database.shard_by_position && database.shard_world > 1 && database.broadcast != nullptr;
+   if (exchange) {
+      // Position-range sharding keeps only a slice of the genome per rank, but a filter leaf may sit at any
+      // position: the rank that owns it broadcasts the plane (Wp words), every rank runs this same code in
+      // the same order (SPMD), so the collectives line up.
+      const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
+      const uint32_t owner = database.ownerOfPosition(position, store.reference_sequence.size());
+      auto buffer = std::make_shared<DeviceBuffer>();
+      void* payload = nullptr;
+      if (owner == database.shard_rank) {
+         const uint64_t* plane = store.getBitmap(position, symbol);
+         if (plane == nullptr) {  // sparsely stored symbol: materialise it first
+            *buffer = partition.pool.acquire(row_bytes);
+            checkGpu(
+               silo_gpu_store_sparse_plane(
+                  store.store, store.seqstore_id, position - store.position_begin, static_cast<uint32_t>(symbol), buffer->as<uint64_t>(),
+                  queryStream()
+               ),
+               "silo_gpu_store_sparse_plane"
+            );
+            plane = buffer->as<uint64_t>();
+         }
+         payload = const_cast<uint64_t*>(plane);  // the root only sends
+      } else {
+         *buffer = partition.pool.acquire(row_bytes);
+         payload = buffer->get();
+      }
+      const int status = database.broadcast(database.broadcast_context, payload, row_bytes, owner, queryStream());
+      if (status != 0) {
+         throw DeviceException("broadcast of a filter leaf failed with status " + std::to_string(status));
+      }
+      auto scan = std::make_unique<operators::IndexScan>(static_cast<const uint64_t*>(payload), rows);
+      scan->received = std::move(buffer);
+      return scan;
+   }
    if (!store.holds(position)) {
-      // position-range sharding keeps only a slice of the genome per rank; exchanging filter leaves
-      // between ranks is the next step, so such a leaf is an internal error for now.
       throw std::runtime_error(
          "position " + std::to_string(position + 1) + " is not resident on this rank (position-range shard " +
-         std::to_string(store.position_begin + 1) + ".." + std::to_string(store.position_end) + ")"
+         std::to_string(store.position_begin + 1) + ".." + std::to_string(store.position_end) +
+         ") and no broadcast callback is installed"
       );
    }
    const uint64_t* plane = store.getBitmap(position, symbol);
@@ -390,7 +425,7 @@ std::unique_ptr<Operator> NucleotideSymbolEquals::compile(
       }
       return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
    }
-   return symbolPlane<Nucleotide>(seq_store_partition, database_partition, position, nucleotide_symbol);
+   return symbolPlane<Nucleotide>(database, seq_store_partition, database_partition, position, nucleotide_symbol);
 }
 
 // ---- AASymbolEquals (aa_symbol_equals.cpp:41-92; the ambiguity mode is ignored, :44) ----------------
@@ -400,7 +435,7 @@ std::string AASymbolEquals::toString(const Database& /*database*/) const {
 }
 
 std::unique_ptr<Operator> AASymbolEquals::compile(
-   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
 ) const {
    const auto& aa_store_partition = database_partition.aa_sequences.at(aa_sequence_name);  // out_of_range -> 500, as in the reference
    if (position >= aa_store_partition.reference_sequence.size()) {
@@ -412,7 +447,7 @@ std::unique_ptr<Operator> AASymbolEquals::compile(
    const AminoAcid::Symbol aa_symbol = value.value_or(aa_store_partition.reference_sequence.at(position));
    // The reference's rewrite for a deleted STOP symbol recurses forever; the dense
    // store simply returns the intended set.
-   return symbolPlane<AminoAcid>(aa_store_partition, database_partition, position, aa_symbol);
+   return symbolPlane<AminoAcid>(database, aa_store_partition, database_partition, position, aa_symbol);
 }
 
 // ---- HasMutation (has_mutation.cpp:35-78) ----------------------------------------------------------

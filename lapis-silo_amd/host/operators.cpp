@@ -323,7 +323,9 @@ std::unique_ptr<Operator> IndexScan::copy() const {
    if (sparse) {
       return std::make_unique<IndexScan>(seqstore_id, position, symbol, rows);
    }
-   return std::make_unique<IndexScan>(bitmap, rows);
+   auto copied = std::make_unique<IndexScan>(bitmap, rows);
+   copied->received = received;
+   return copied;
 }
 std::unique_ptr<Operator> IndexScan::negate() const {
    return std::make_unique<Complement>(copy(), rows);

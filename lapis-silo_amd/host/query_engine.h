@@ -201,6 +201,8 @@ class IndexScan : public Operator {
    const uint64_t* bitmap = nullptr;
    bool sparse = false;
    uint32_t seqstore_id = 0, position = 0, symbol = 0;
+   /// Owner of `bitmap` when it is a plane received from another rank (position-range sharding).
+   std::shared_ptr<DeviceBuffer> received;
 };
 
 /// bitmap_selection.cpp probes the row-wise missing-symbol bitmaps; the dense store keeps the missing

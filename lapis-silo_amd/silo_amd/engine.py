@@ -16,12 +16,13 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_execute_query", "silo_engine_free_string",
+    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_execute_query", "silo_engine_free_string",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
 
 ALL_REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+BROADCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p)
 
 _lib = None
 
@@ -46,6 +47,7 @@ def load_library():
         vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, vp, ctypes.c_uint32]
     lib.silo_engine_finalize.argtypes = [vp]
     lib.silo_engine_set_sharding.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ALL_REDUCE_FN, vp]
+    lib.silo_engine_set_broadcast.argtypes = [vp, BROADCAST_FN, vp]
     lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_free_string.argtypes = [vp]
     lib.silo_engine_free_string.restype = None
@@ -186,6 +188,19 @@ class Engine:
             callback = ALL_REDUCE_FN(trampoline)
         self._callbacks.append(callback)
         _check(self.lib.silo_engine_set_sharding(self.handle, rank, world, int(shard_by_position), callback, None))
+
+    def set_broadcast(self, broadcast):
+        """broadcast(device_ptr:int, nbytes:int, root:int, stream): in-place broadcast from rank `root`."""
+        def trampoline(_context, device_bytes, nbytes, root, stream):
+            try:
+                broadcast(device_bytes, nbytes, root, stream)
+                return 0
+            except Exception as error:  # never let an exception cross the C boundary
+                print("broadcast callback failed:", error)
+                return 1
+        callback = BROADCAST_FN(trampoline)
+        self._callbacks.append(callback)
+        _check(self.lib.silo_engine_set_broadcast(self.handle, callback, None))
 
     def execute_text(self, query):
         """Returns (http_status, response body as bytes) — what silo_api would put on the wire."""

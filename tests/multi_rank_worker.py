@@ -48,6 +48,8 @@ def main():
         "main": synth.make_model(N, ref, "nuc", tree, lineage, seed=5, store_index=0),
         "S": synth.make_model(N, gene, "aa", tree, lineage, seed=5, store_index=1),
     }
+    for model in models.values():
+        model.ambiguous_threshold = 1 << 13  # enough IUPAC codes for the sparse-leaf path
     member = tree.subtree(1)
     by_position = shard == "position"
 
@@ -86,8 +88,19 @@ def main():
         dist.all_reduce(tensor)
         binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, None))
 
+    def broadcast(device_ptr, nbytes, root, _stream):
+        host = np.empty(nbytes, dtype=np.uint8)
+        if rank == root:
+            binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, nbytes, None))
+        tensor = torch.from_numpy(host)
+        dist.broadcast(tensor, src=root)
+        if rank != root:
+            binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, None))
+
     engine = Engine(doc)
     engine.set_sharding(rank, world, by_position, all_reduce)
+    if by_position:
+        engine.set_broadcast(broadcast)
     if by_position:
         rows = slice(0, N)
     else:
@@ -106,6 +119,16 @@ def main():
         {"action": {"type": "AminoAcidMutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
         {"action": {"type": "Mutations", "minProportion": 0.5}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.2.3", "includeSublineages": False}},
         {"action": {"type": "Aggregated"}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": True}},
+        # filter leaves spread over the genome: under position sharding they are fetched from their owner rank
+        {"action": {"type": "Mutations", "minProportion": 0.3}, "filterExpression": {"type": "And", "children": [
+            {"type": "Not", "child": {"type": "NucleotideEquals", "position": 10, "symbol": "-"}},
+            {"type": "N-Of", "numberOfMatchers": 1, "matchExactly": False, "children": [
+                {"type": "HasNucleotideMutation", "position": 900}, {"type": "NucleotideEquals", "position": 500, "symbol": "N"},
+                {"type": "Maybe", "child": {"type": "NucleotideEquals", "position": 333, "symbol": "."}}]},
+            {"type": "Not", "child": {"type": "AminoAcidEquals", "sequenceName": "S", "position": 200, "symbol": "X"}}]}},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "Or", "children": [
+            {"type": "NucleotideEquals", "position": 997, "symbol": "R"}, {"type": "NucleotideEquals", "position": 1, "symbol": "Y"},
+            {"type": "HasAminoAcidMutation", "sequenceName": "S", "position": 100}]}},
     ]
     results = [engine.execute_raw(q) for q in queries]
     dist.barrier()
