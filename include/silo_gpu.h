@@ -205,7 +205,9 @@ int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, u
  * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & plane[p][scan_symbols[s]])
  * for p in [pos_begin, pos_end).  The buffer is ACCUMULATED into (the reference sums partitions into
  * one table, mutations.cpp:71,108); zero it with silo_gpu_memset_async before the first partition.
- * filter_dev == NULL means the full filter (mutations.cpp:98-136). */
+ * filter_dev == NULL means the full filter: like the reference, which then reads stored cardinalities
+ * instead of intersecting (mutations.cpp:98-136), the totals of the unfiltered store are computed by one
+ * scan on first use, kept on the device and added from then on (invalidated by append / generate). */
 int silo_gpu_mutations_scan(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev,
    uint32_t pos_begin, uint32_t pos_end, uint32_t* counts_out_dev, void* stream

@@ -120,6 +120,10 @@ struct SeqStoreHost {
    uint32_t* d_sparse_count = nullptr;  // device counter
    std::vector<uint64_t> sparse_sorted;  // host copy after finalize
    bool finalized = false;
+   // counts of the unfiltered store, [positions][n_scan]: what the reference reads from stored
+   // cardinalities for a full filter (mutations.cpp:98-136); computed by one scan on first use
+   uint32_t* d_totals = nullptr;
+   bool totals_ready = false;
 };
 
 }  // namespace
@@ -640,6 +644,13 @@ __global__ __launch_bounds__(256) void k_bitset_from_value_ids(
    }
 }
 
+__global__ void k_add_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n) {
+   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) {
+      dst[i] += src[i];
+   }
+}
+
 __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence_count) {
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
    if (w < row_words) {
@@ -841,6 +852,7 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_reference);
       (void)hipFree(seqstore.d_sparse);
       (void)hipFree(seqstore.d_sparse_count);
+      (void)hipFree(seqstore.d_totals);
    }
    (void)hipFree(store->d_ones);
    (void)hipFree(store->d_lineage);
@@ -875,6 +887,7 @@ int silo_gpu_store_append_sequences(
    HIP_TRY(hipSetDevice(store->device));
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
    seqstore.finalized = false;
+   seqstore.totals_ready = false;
    const uint32_t positions = seqstore.dev.positions;
    const uint32_t pitch = (positions + 15u) / 16u * 16u;
 
@@ -975,6 +988,7 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    HIP_TRY(hipSetDevice(store->device));
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
    seqstore.finalized = false;
+   seqstore.totals_ready = false;
    const uint32_t n = store->sequence_count;
    const uint32_t positions = seqstore.dev.positions;
 
@@ -1460,7 +1474,36 @@ int silo_gpu_mutations_scan(
    if (pos_begin == pos_end || dev.n_scan == 0) {
       return SILO_GPU_OK;
    }
-   const uint64_t* filter = filter_dev != nullptr ? filter_dev : store->d_ones;
+   auto hip_stream_early = static_cast<hipStream_t>(stream);
+   if (filter_dev == nullptr) {
+      // Full filter: add the cached totals of the unfiltered store instead of streaming the planes again.
+      auto* mutable_store = const_cast<silo_gpu_store*>(store);  // the cache is logically const
+      SeqStoreHost& seqstore = mutable_store->seqstores[seqstore_id];
+      const size_t n_totals = static_cast<size_t>(dev.positions) * dev.n_scan;
+      {
+         const std::lock_guard<std::mutex> lock(mutable_store->mutex);
+         if (!seqstore.totals_ready) {
+            if (seqstore.d_totals == nullptr) {
+               HIP_TRY(hipMalloc(&seqstore.d_totals, n_totals * sizeof(uint32_t)));
+            }
+            HIP_TRY(hipMemsetAsync(seqstore.d_totals, 0, n_totals * sizeof(uint32_t), hip_stream_early));
+            const int rc = silo_gpu_mutations_scan(store, seqstore_id, store->d_ones, 0, dev.positions, seqstore.d_totals, stream);
+            if (rc != SILO_GPU_OK) {
+               return rc;
+            }
+            HIP_TRY(hipStreamSynchronize(hip_stream_early));  // other streams may read it from now on
+            seqstore.totals_ready = true;
+         }
+      }
+      const uint32_t n = (pos_end - pos_begin) * dev.n_scan;
+      k_add_u32<<<(n + 255) / 256, 256, 0, hip_stream_early>>>(
+         counts_out_dev, seqstore.d_totals + static_cast<size_t>(pos_begin) * dev.n_scan, n
+      );
+      HIP_TRY(hipGetLastError());
+      g_last_scan_kernel = "k_add_u32 (cached totals)";
+      return SILO_GPU_OK;
+   }
+   const uint64_t* filter = filter_dev;
    const uint32_t row_words = dev.row_words;
    const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
    const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;

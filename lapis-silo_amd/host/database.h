@@ -201,10 +201,6 @@ class DatabasePartition {
    } columns;
 
    mutable DevicePool pool;
-   /// Unfiltered Mutations totals per sequence store, computed once (mutations.cpp:98-136 reads
-   /// cardinalities for full filters): key = (is_aa, seqstore_id).
-   mutable std::mutex totals_mutex;
-   mutable std::map<uint32_t, std::vector<uint32_t>> full_counts;
 
    /// Materialised bitsets of sparsely stored symbols (IUPAC ambiguity codes), keyed by
    /// seqstore << 40 | local position << 8 | symbol; filled on first use by ProgramBuilder::sparseLeaf.

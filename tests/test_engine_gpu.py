@@ -151,3 +151,53 @@ def test_random_mutations_match_oracle(engines):
         want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
         got = engine.execute_query(query)
         assert got == want, json.dumps(query)
+
+
+def test_concurrent_clients_get_sequential_results(engines):
+    """executeQuery is re-entrant on a shared engine (the reference serves one thread per request under a
+    shared lock, database_mutex.cpp:20-23); here every thread also has its own HIP stream."""
+    import threading
+
+    engine, _ = engines
+    rng = random.Random(99)
+    queries = []
+    for _ in range(24):
+        expression = random_expression(rng, 3)
+        action = rng.choice([
+            {"type": "Aggregated"},
+            {"type": "Mutations", "minProportion": 0.05},
+            {"type": "AminoAcidMutations", "minProportion": 0.1, "sequenceName": "S"},
+        ])
+        queries.append({"action": action, "filterExpression": expression})
+    expected = [engine.execute_raw(q) for q in queries]
+    results = {}
+
+    def client(index):
+        mine = []
+        for round_ in range(3):
+            for k in range(index, len(queries), 4):
+                mine.append((k, engine.execute_raw(queries[k])))
+        results[index] = mine
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(results) == 4
+    for mine in results.values():
+        for k, got in mine:
+            assert got == expected[k], json.dumps(queries[k])
+
+
+def test_full_filter_uses_cached_totals_and_matches_scan(engines):
+    engine, oracle_db = engines
+    query = {"action": {"type": "Mutations", "minProportion": 0.0, "sequenceName": "main"}, "filterExpression": {"type": "True"}}
+    first = engine.execute_query(query)   # computes the totals
+    second = engine.execute_query(query)  # adds the cached totals
+    want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+    assert first == want and second == want
+    # a filter that happens to select every row takes the same path
+    everything = {"action": query["action"], "filterExpression": {"type": "Or", "children": [
+        {"type": "NucleotideEquals", "position": 5, "symbol": "A"}, {"type": "Not", "child": {"type": "NucleotideEquals", "position": 5, "symbol": "A"}}]}}
+    assert engine.execute_query(everything) == want
