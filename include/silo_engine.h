@@ -31,6 +31,13 @@ int silo_engine_create(
 );
 void silo_engine_destroy(silo_engine* engine);
 
+/* Loads a data set directory in the reference's INPUT formats (preprocessing_config.yaml, database_config.yaml,
+ * reference_genomes.json, pangolineage_alias.json, metadata TSV + FASTA[.zst|.xz] or ndjson[.zst|.xz]) into one
+ * partition, rows in file order, and finalises it: the load side of Preprocessor::preprocess
+ * (preprocessor.cpp:36-85) for this path, without DuckDB.  *out_summary_json (optional, malloc'ed) reports
+ * {"sequenceCount":..,"nucleotideStores":..,"aminoAcidStores":..,"lineageColumns":..,"nullSequences":..}. */
+int silo_engine_create_from_directory(const char* directory, int device, silo_engine** out, char** out_summary_json);
+
 /* Adds a DatabasePartition of `sequence_count` rows; returns its index (>= 0) or a negative status. */
 int silo_engine_add_partition(silo_engine* engine, uint32_t sequence_count);
 

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <new>
 
+#include "dataset_loader.h"
 #include "query_engine.h"
 #include "silo_engine.h"
 
@@ -96,6 +97,29 @@ int silo_engine_create(
 
 void silo_engine_destroy(silo_engine* engine) {
    delete engine;
+}
+
+int silo_engine_create_from_directory(const char* directory, int device, silo_engine** out, char** out_summary_json) {
+   if (directory == nullptr || out == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_create_from_directory: null argument");
+   }
+   *out = nullptr;
+   return guarded([&] {
+      auto engine = std::make_unique<silo_engine>();
+      engine->database.device = device;
+      const auto summary = silo::preprocessing::loadDataset(engine->database, directory);
+      if (out_summary_json != nullptr) {
+         silo::json::Value doc = silo::json::Value::object();
+         doc.set("sequenceCount", silo::json::Value(static_cast<uint64_t>(summary.sequence_count)));
+         doc.set("nucleotideStores", silo::json::Value(static_cast<uint64_t>(summary.nucleotide_stores)));
+         doc.set("aminoAcidStores", silo::json::Value(static_cast<uint64_t>(summary.amino_acid_stores)));
+         doc.set("lineageColumns", silo::json::Value(static_cast<uint64_t>(summary.lineage_columns)));
+         doc.set("nullSequences", silo::json::Value(static_cast<uint64_t>(summary.null_sequences)));
+         *out_summary_json = duplicate(doc.dump());
+      }
+      *out = engine.release();
+      return 0;
+   });
 }
 
 int silo_engine_add_partition(silo_engine* engine, uint32_t sequence_count) {

@@ -1,0 +1,575 @@
+#include "dataset_loader.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <memory>
+#include <optional>
+#include <unordered_map>
+
+#include "query_engine.h"
+
+namespace silo::preprocessing {
+
+namespace {
+
+namespace fs = std::filesystem;
+
+// ---- byte sources: plain / zstd / xz, the codecs resolved at run time (no link-time dependency) ---------
+class ByteSource {
+  public:
+   virtual ~ByteSource() = default;
+   virtual size_t read(char* destination, size_t capacity) = 0;  // 0 = end of stream
+};
+
+class PlainSource : public ByteSource {
+  public:
+   explicit PlainSource(const std::string& path) : file(std::fopen(path.c_str(), "rb")) {
+      if (file == nullptr) {
+         throw PreprocessingException("cannot open " + path);
+      }
+   }
+   ~PlainSource() override { std::fclose(file); }
+   size_t read(char* destination, size_t capacity) override { return std::fread(destination, 1, capacity, file); }
+
+  private:
+   std::FILE* file;
+};
+
+void* openLibrary(const char* const* names, const char* what) {
+   for (const char* const* name = names; *name != nullptr; ++name) {
+      if (void* handle = dlopen(*name, RTLD_NOW | RTLD_LOCAL); handle != nullptr) {
+         return handle;
+      }
+   }
+   throw PreprocessingException(std::string("cannot load the ") + what + " library needed to read a compressed input file");
+}
+
+template <typename Function>
+Function resolve(void* library, const char* symbol) {
+   void* address = dlsym(library, symbol);
+   if (address == nullptr) {
+      throw PreprocessingException(std::string("missing symbol ") + symbol);
+   }
+   return reinterpret_cast<Function>(address);
+}
+
+class ZstdSource : public ByteSource {  // zstd streaming API (stable since 1.0): zstd.h ZSTD_decompressStream
+   struct InBuffer {
+      const void* src;
+      size_t size;
+      size_t pos;
+   };
+   struct OutBuffer {
+      void* dst;
+      size_t size;
+      size_t pos;
+   };
+   using CreateFn = void* (*)();
+   using FreeFn = size_t (*)(void*);
+   using InitFn = size_t (*)(void*);
+   using DecompressFn = size_t (*)(void*, OutBuffer*, InBuffer*);
+   using IsErrorFn = unsigned (*)(size_t);
+
+  public:
+   explicit ZstdSource(const std::string& path) : input(path), compressed(1 << 17) {
+      static const char* const names[] = {"libzstd.so.1", "libzstd.so", "/opt/conda/lib/libzstd.so", nullptr};
+      void* library = openLibrary(names, "zstd");
+      release = resolve<FreeFn>(library, "ZSTD_freeDStream");
+      decompress = resolve<DecompressFn>(library, "ZSTD_decompressStream");
+      is_error = resolve<IsErrorFn>(library, "ZSTD_isError");
+      stream = resolve<CreateFn>(library, "ZSTD_createDStream")();
+      if (stream == nullptr || is_error(resolve<InitFn>(library, "ZSTD_initDStream")(stream)) != 0) {
+         throw PreprocessingException("cannot initialise the zstd decoder");
+      }
+   }
+   ~ZstdSource() override { release(stream); }
+
+   size_t read(char* destination, size_t capacity) override {
+      OutBuffer out{destination, capacity, 0};
+      while (out.pos == 0) {
+         if (in.pos == in.size) {
+            const size_t got = input.read(compressed.data(), compressed.size());
+            if (got == 0) {
+               return 0;
+            }
+            in = {compressed.data(), got, 0};
+         }
+         if (is_error(decompress(stream, &out, &in)) != 0) {
+            throw PreprocessingException("corrupt zstd stream");
+         }
+      }
+      return out.pos;
+   }
+
+  private:
+   PlainSource input;
+   std::vector<char> compressed;
+   InBuffer in{nullptr, 0, 0};
+   void* stream = nullptr;
+   FreeFn release = nullptr;
+   DecompressFn decompress = nullptr;
+   IsErrorFn is_error = nullptr;
+};
+
+class XzSource : public ByteSource {  // liblzma 5.x: lzma_stream_decoder / lzma_code (lzma/base.h layout)
+   struct Stream {
+      const uint8_t* next_in;
+      size_t avail_in;
+      uint64_t total_in;
+      uint8_t* next_out;
+      size_t avail_out;
+      uint64_t total_out;
+      const void* allocator;
+      void* internal;
+      void* reserved_ptr1;
+      void* reserved_ptr2;
+      void* reserved_ptr3;
+      void* reserved_ptr4;
+      uint64_t reserved_int1;
+      uint64_t reserved_int2;
+      size_t reserved_int3;
+      size_t reserved_int4;
+      int reserved_enum1;
+      int reserved_enum2;
+   };
+   using DecoderFn = int (*)(Stream*, uint64_t, uint32_t);
+   using CodeFn = int (*)(Stream*, int);
+   using EndFn = void (*)(Stream*);
+
+  public:
+   explicit XzSource(const std::string& path) : input(path), compressed(1 << 17) {
+      static const char* const names[] = {"liblzma.so.5", "liblzma.so", "/opt/conda/lib/liblzma.so", nullptr};
+      void* library = openLibrary(names, "lzma");
+      code = resolve<CodeFn>(library, "lzma_code");
+      end = resolve<EndFn>(library, "lzma_end");
+      memset(&stream, 0, sizeof(stream));
+      if (resolve<DecoderFn>(library, "lzma_stream_decoder")(&stream, UINT64_MAX, /*LZMA_CONCATENATED*/ 0x08) != 0) {
+         throw PreprocessingException("cannot initialise the xz decoder");
+      }
+   }
+   ~XzSource() override { end(&stream); }
+
+   size_t read(char* destination, size_t capacity) override {
+      if (finished) {
+         return 0;
+      }
+      stream.next_out = reinterpret_cast<uint8_t*>(destination);
+      stream.avail_out = capacity;
+      while (stream.avail_out == capacity) {
+         if (stream.avail_in == 0 && !input_done) {
+            const size_t got = input.read(compressed.data(), compressed.size());
+            input_done = got == 0;
+            stream.next_in = reinterpret_cast<const uint8_t*>(compressed.data());
+            stream.avail_in = got;
+         }
+         const int status = code(&stream, input_done ? /*LZMA_FINISH*/ 3 : /*LZMA_RUN*/ 0);
+         if (status == /*LZMA_STREAM_END*/ 1) {
+            finished = true;
+            break;
+         }
+         if (status != /*LZMA_OK*/ 0) {
+            throw PreprocessingException("corrupt xz stream");
+         }
+      }
+      return capacity - stream.avail_out;
+   }
+
+  private:
+   PlainSource input;
+   std::vector<char> compressed;
+   Stream stream{};
+   CodeFn code = nullptr;
+   EndFn end = nullptr;
+   bool input_done = false;
+   bool finished = false;
+};
+
+bool endsWith(const std::string& text, const std::string& suffix) {
+   return text.size() >= suffix.size() && text.compare(text.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+std::unique_ptr<ByteSource> openSource(const std::string& path) {
+   if (endsWith(path, ".zst")) {
+      return std::make_unique<ZstdSource>(path);
+   }
+   if (endsWith(path, ".xz")) {
+      return std::make_unique<XzSource>(path);
+   }
+   return std::make_unique<PlainSource>(path);
+}
+
+class LineReader {
+  public:
+   explicit LineReader(const std::string& path) : source(openSource(path)), buffer(1 << 20) {}
+
+   bool next(std::string& line) {
+      line.clear();
+      while (true) {
+         if (begin == end) {
+            end = source->read(buffer.data(), buffer.size());
+            begin = 0;
+            if (end == 0) {
+               return !line.empty();
+            }
+         }
+         const char* start = buffer.data() + begin;
+         const void* newline = memchr(start, '\n', end - begin);
+         if (newline != nullptr) {
+            const size_t length = static_cast<const char*>(newline) - start;
+            line.append(start, length);
+            begin += length + 1;
+            if (!line.empty() && line.back() == '\r') {
+               line.pop_back();
+            }
+            return true;
+         }
+         line.append(start, end - begin);
+         begin = end;
+      }
+   }
+
+  private:
+   std::unique_ptr<ByteSource> source;
+   std::vector<char> buffer;
+   size_t begin = 0;
+   size_t end = 0;
+};
+
+std::string readWholeFile(const std::string& path) {
+   std::ifstream stream(path, std::ios::binary);
+   if (!stream) {
+      throw PreprocessingException("cannot open " + path);
+   }
+   return {std::istreambuf_iterator<char>(stream), std::istreambuf_iterator<char>()};
+}
+
+/// `<name>`, `<name>.zst` or `<name>.xz`, whichever exists.
+std::optional<std::string> findWithCompression(const fs::path& base) {
+   for (const char* suffix : {"", ".zst", ".xz"}) {
+      const fs::path candidate = base.string() + suffix;
+      if (fs::exists(candidate)) {
+         return candidate.string();
+      }
+   }
+   return std::nullopt;
+}
+
+// ---- the two YAML files: a flat key/value file and the schema (only the keys the path needs) -------------
+std::string unquote(std::string value) {
+   const auto first = value.find_first_not_of(" \t");
+   const auto last = value.find_last_not_of(" \t\r");
+   if (first == std::string::npos) {
+      return "";
+   }
+   value = value.substr(first, last - first + 1);
+   if (value.size() >= 2 && ((value.front() == '"' && value.back() == '"') || (value.front() == '\'' && value.back() == '\''))) {
+      value = value.substr(1, value.size() - 2);
+   }
+   return value;
+}
+
+std::unordered_map<std::string, std::string> readFlatYaml(const std::string& path) {
+   std::unordered_map<std::string, std::string> out;
+   std::ifstream stream(path);
+   std::string line;
+   while (std::getline(stream, line)) {
+      const auto colon = line.find(':');
+      if (colon == std::string::npos || line.find_first_not_of(" \t") == std::string::npos || line[line.find_first_not_of(" \t")] == '#') {
+         continue;
+      }
+      out[unquote(line.substr(0, colon))] = unquote(line.substr(colon + 1));
+   }
+   return out;
+}
+
+struct DatabaseSchema {
+   std::string primary_key;
+   std::optional<std::string> default_nucleotide_sequence;
+   std::vector<std::string> pango_lineage_columns;
+};
+
+DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config.cpp:47-90
+   DatabaseSchema schema;
+   std::ifstream stream(path);
+   if (!stream) {
+      throw PreprocessingException("cannot open " + path);
+   }
+   std::string line;
+   std::string current_name;
+   while (std::getline(stream, line)) {
+      const auto colon = line.find(':');
+      if (colon == std::string::npos) {
+         continue;
+      }
+      std::string key = unquote(line.substr(0, colon));
+      const std::string value = unquote(line.substr(colon + 1));
+      if (!key.empty() && key.front() == '-') {
+         key = unquote(key.substr(1));
+      }
+      if (key == "primaryKey") {
+         schema.primary_key = value;
+      } else if (key == "defaultNucleotideSequence") {
+         schema.default_nucleotide_sequence = value;
+      } else if (key == "name") {
+         current_name = value;
+      } else if (key == "type" && value == "pango_lineage" && !current_name.empty()) {
+         schema.pango_lineage_columns.push_back(current_name);
+      }
+   }
+   return schema;
+}
+
+// ---- staging of one sequence store: batches of equal-length rows appended to the device ---------------------
+class StoreWriter {
+  public:
+   StoreWriter(silo_gpu_store* store, uint32_t seqstore_id, size_t length, std::string name)
+       : store(store), seqstore_id(seqstore_id), length(length), name(std::move(name)) {}
+
+   void add(const std::string* sequence, DatasetSummary& summary) {
+      if (sequence == nullptr) {
+         is_null.push_back(1);
+         chars.resize(chars.size() + length, 'N');
+         ++summary.null_sequences;
+      } else {
+         if (sequence->size() != length) {
+            throw PreprocessingException(
+               "sequence " + std::to_string(next_row + is_null.size()) + " of '" + name + "' has length " +
+               std::to_string(sequence->size()) + ", the reference has " + std::to_string(length)
+            );
+         }
+         is_null.push_back(0);
+         chars.insert(chars.end(), sequence->begin(), sequence->end());
+      }
+      if (is_null.size() >= BATCH) {
+         flush();
+      }
+   }
+
+   void flush() {
+      if (is_null.empty()) {
+         return;
+      }
+      checkGpu(
+         silo_gpu_store_append_sequences(
+            store, seqstore_id, next_row, static_cast<uint32_t>(is_null.size()), chars.data(), is_null.data()
+         ),
+         "silo_gpu_store_append_sequences"
+      );
+      next_row += static_cast<uint32_t>(is_null.size());
+      is_null.clear();
+      chars.clear();
+   }
+
+  private:
+   static constexpr size_t BATCH = 4096;  // the reference buffers 1024 genomes (sequence_store.cpp:34)
+   silo_gpu_store* store;
+   uint32_t seqstore_id;
+   size_t length;
+   std::string name;
+   uint32_t next_row = 0;
+   std::vector<char> chars;
+   std::vector<uint8_t> is_null;
+};
+
+std::vector<std::string> splitTabs(const std::string& line) {
+   std::vector<std::string> out;
+   size_t begin = 0;
+   while (true) {
+      const auto tab = line.find('\t', begin);
+      out.push_back(line.substr(begin, tab == std::string::npos ? std::string::npos : tab - begin));
+      if (tab == std::string::npos) {
+         return out;
+      }
+      begin = tab + 1;
+   }
+}
+
+std::unordered_map<std::string, std::string> readFasta(const std::string& path) {  // common/fasta_reader.cpp
+   std::unordered_map<std::string, std::string> out;
+   LineReader reader(path);
+   std::string line;
+   std::string* current = nullptr;
+   while (reader.next(line)) {
+      if (line.empty()) {
+         continue;
+      }
+      if (line.front() == '>') {
+         current = &out[line.substr(1)];
+         current->clear();
+      } else if (current != nullptr) {
+         current->append(line);
+      } else {
+         throw PreprocessingException("Fasta file " + path + " does not start with '>'");
+      }
+   }
+   return out;
+}
+
+}  // namespace
+
+DatasetSummary loadDataset(Database& database, const std::string& directory) {
+   if (!database.partitions.empty()) {
+      throw PreprocessingException("loadDataset needs an empty database");
+   }
+   const fs::path root(directory);
+   std::unordered_map<std::string, std::string> config;
+   if (fs::exists(root / "preprocessing_config.yaml")) {
+      config = readFlatYaml((root / "preprocessing_config.yaml").string());
+   }
+   const auto setting = [&](const char* key, const char* fallback) {
+      const auto found = config.find(key);
+      return found != config.end() && !found->second.empty() ? found->second : std::string(fallback);
+   };
+   if (config.count("ndjsonInputFilename") != 0 && config.count("metadataFilename") != 0) {  // preprocessing_config_reader.cpp:54-60
+      throw PreprocessingException(
+         "Cannot specify both a ndjsonInputFilename ('" + config["ndjsonInputFilename"] + "') and metadataFilename('" +
+         config["metadataFilename"] + "')."
+      );
+   }
+   const DatabaseSchema schema = readDatabaseConfig((root / "database_config.yaml").string());
+   if (schema.default_nucleotide_sequence.has_value()) {
+      database.database_config.default_nucleotide_sequence = *schema.default_nucleotide_sequence;
+   }
+   database.setReferenceGenomes(json::parse(readWholeFile((root / setting("referenceGenomeFilename", "reference_genomes.json")).string())));
+   const fs::path alias_path = root / setting("pangoLineageDefinitionFilename", "pangolineage_alias.json");
+   if (fs::exists(alias_path)) {
+      database.alias_key = PangoLineageAliasLookup::fromJson(json::parse(readWholeFile(alias_path.string())));
+   }
+
+   DatasetSummary summary;
+   summary.nucleotide_stores = database.nuc_sequences.size();
+   summary.amino_acid_stores = database.aa_sequences.size();
+   summary.lineage_columns = schema.pango_lineage_columns.size();
+
+   const bool from_ndjson = config.count("ndjsonInputFilename") != 0;
+   const std::string input_path = (root / (from_ndjson ? config["ndjsonInputFilename"] : setting("metadataFilename", "metadata.tsv"))).string();
+
+   // pass 1: the row count (a device store is allocated for a known number of rows)
+   size_t rows = 0;
+   {
+      LineReader reader(input_path);
+      std::string line;
+      while (reader.next(line)) {
+         rows += line.find_first_not_of(" \t") != std::string::npos ? 1 : 0;
+      }
+      if (!from_ndjson && rows > 0) {
+         --rows;  // TSV header
+      }
+   }
+   summary.sequence_count = rows;
+   if (rows > UINT32_MAX) {
+      throw PreprocessingException("more than 2^32 rows in one partition");
+   }
+   DatabasePartition& partition = database.addPartition(static_cast<uint32_t>(rows));
+   std::vector<storage::column::PangoLineageColumnPartition*> lineage_columns;
+   for (const std::string& column : schema.pango_lineage_columns) {
+      lineage_columns.push_back(&partition.columns.pango_lineage_columns
+                                    .emplace(std::piecewise_construct, std::forward_as_tuple(column), std::forward_as_tuple(database.alias_key, partition))
+                                    .first->second);
+   }
+   std::vector<std::pair<std::string, StoreWriter>> nuc_writers;
+   std::vector<std::pair<std::string, StoreWriter>> aa_writers;
+   for (const auto& [name, store] : partition.nuc_sequences) {
+      nuc_writers.emplace_back(name, StoreWriter(partition.store, store.seqstore_id, store.reference_sequence.size(), name));
+   }
+   for (const auto& [name, store] : partition.aa_sequences) {
+      aa_writers.emplace_back(name, StoreWriter(partition.store, store.seqstore_id, store.reference_sequence.size(), name));
+   }
+
+   if (from_ndjson) {  // preprocessor.cpp:87-131: one JSON object per line
+      LineReader reader(input_path);
+      std::string line;
+      while (reader.next(line)) {
+         if (line.find_first_not_of(" \t") == std::string::npos) {
+            continue;
+         }
+         const json::Value record = json::parse(line);
+         const json::Value& metadata = record.at("metadata");
+         for (size_t k = 0; k < lineage_columns.size(); ++k) {
+            const std::string& column = schema.pango_lineage_columns[k];
+            if (metadata.contains(column) && metadata[column].is_string()) {
+               lineage_columns[k]->insert(metadata[column].as_string());
+            } else {
+               lineage_columns[k]->insertNull();
+            }
+         }
+         const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const char* section) {
+            static const json::Value missing_section;
+            const json::Value& sequences = record.contains(section) ? record[section] : missing_section;
+            for (auto& [name, writer] : writers) {
+               if (sequences.contains(name) && sequences[name].is_string()) {
+                  writer.add(&sequences[name].as_string(), summary);
+               } else {
+                  writer.add(nullptr, summary);  // null genome: missing at every position (sequence_store.cpp:166-169)
+               }
+            }
+         };
+         feed(nuc_writers, "alignedNucleotideSequences");
+         feed(aa_writers, "alignedAminoAcidSequences");
+      }
+   } else {  // preprocessor.cpp:255-334: metadata TSV, sequences joined by primary key from FASTA files
+      std::vector<std::string> keys;
+      {
+         LineReader reader(input_path);
+         std::string line;
+         if (!reader.next(line)) {
+            throw PreprocessingException("metadata file " + input_path + " is empty");
+         }
+         const std::vector<std::string> header = splitTabs(line);
+         const auto column_of = [&](const std::string& name) -> size_t {
+            const auto found = std::find(header.begin(), header.end(), name);
+            if (found == header.end()) {
+               throw PreprocessingException("metadata file " + input_path + " has no column '" + name + "'");
+            }
+            return static_cast<size_t>(found - header.begin());
+         };
+         const size_t key_column = column_of(schema.primary_key);
+         std::vector<size_t> lineage_column_index;
+         for (const std::string& column : schema.pango_lineage_columns) {
+            lineage_column_index.push_back(column_of(column));
+         }
+         while (reader.next(line)) {
+            if (line.find_first_not_of(" \t") == std::string::npos) {
+               continue;
+            }
+            const std::vector<std::string> fields = splitTabs(line);
+            keys.push_back(key_column < fields.size() ? fields[key_column] : "");
+            for (size_t k = 0; k < lineage_columns.size(); ++k) {
+               const size_t index = lineage_column_index[k];
+               lineage_columns[k]->insert(index < fields.size() ? fields[index] : "");
+            }
+         }
+      }
+      const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const std::string& prefix) {
+         for (auto& [name, writer] : writers) {
+            const auto path = findWithCompression(root / (prefix + name + ".fasta"));
+            if (!path.has_value()) {
+               throw PreprocessingException("no sequence file " + prefix + name + ".fasta[.zst|.xz] in " + directory);
+            }
+            const auto records = readFasta(*path);
+            for (const std::string& key : keys) {
+               const auto found = records.find(key);
+               writer.add(found == records.end() ? nullptr : &found->second, summary);
+            }
+            writer.flush();
+         }
+      };
+      feed(nuc_writers, setting("nucleotideSequencePrefix", "nuc_"));
+      feed(aa_writers, setting("genePrefix", "gene_"));
+   }
+   for (auto& [name, writer] : nuc_writers) {
+      writer.flush();
+   }
+   for (auto& [name, writer] : aa_writers) {
+      writer.flush();
+   }
+   database.finalize();
+   return summary;
+}
+
+}  // namespace silo::preprocessing

@@ -1,0 +1,41 @@
+// dataset_loader.h — reads the reference's *input* files straight into the device store.
+//
+// Replaces, for this path only, the DuckDB-driven Preprocessor (reference src/silo/preprocessing/
+// preprocessor.cpp:36-85, :87-131 ndjson, :255-334 metadata + FASTA; config readers
+// preprocessing_config_reader.cpp:18-37, database_config.cpp:47-90; reference_genomes.cpp): no SQL, no
+// partitioning — one DatabasePartition with rows in input-file order (the reference orders rows by
+// partitionBy / dateToSortBy / primaryKey through DuckDB; counts, Mutations tables and every result of this
+// path are independent of row order).
+//
+// Files understood, all relative to the data set directory:
+//   preprocessing_config.yaml   optional; metadataFilename | ndjsonInputFilename, pangoLineageDefinitionFilename,
+//                               referenceGenomeFilename, nucleotideSequencePrefix ("nuc_"), genePrefix ("gene_")
+//   database_config.yaml        schema.primaryKey, schema.metadata[] (name / type; `pango_lineage` columns are
+//                               loaded, the rest are outside the path), defaultNucleotideSequence
+//   reference_genomes.json, pangolineage_alias.json
+//   <metadata>.tsv + <prefix><name>.fasta[.zst|.xz]      or      <input>.ndjson[.zst|.xz]
+#pragma once
+
+#include <string>
+
+#include "database.h"
+
+namespace silo::preprocessing {
+
+class PreprocessingException : public std::runtime_error {
+  public:
+   using std::runtime_error::runtime_error;
+};
+
+struct DatasetSummary {
+   size_t sequence_count = 0;
+   size_t nucleotide_stores = 0;
+   size_t amino_acid_stores = 0;
+   size_t lineage_columns = 0;
+   size_t null_sequences = 0;
+};
+
+/// Fills `database` (must be empty) from the files in `directory` and finalises it.
+DatasetSummary loadDataset(Database& database, const std::string& directory);
+
+}  // namespace silo::preprocessing

@@ -2,7 +2,8 @@
 
   lib/libsilo_gpu.so     HIP kernels + C ABI (include/silo_gpu.h), hipcc --offload-arch=gfx950
   lib/libsilo_engine.so  C++ host mirror of silo::query_engine (include/silo_engine.h), links libsilo_gpu
-  lib/bitprog_host       g++ build of the bit-program interpreter for host-logic unit tests
+  lib/silo_query         CLI: load a data set directory (reference input formats), answer /query bodies from stdin
+  lib/libbitprog_host.so g++ build of the bit-program interpreter for host-logic unit tests
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container and the resulting
 .so files travel to the GPU box with the repo snapshot.
@@ -71,7 +72,20 @@ def build_engine(force=False):
     if force or _newer(target, deps):
         _run([
             "g++", "-O2", "-g", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE, "-I", HOST,
-            *sources, "-o", target, "-L", LIB, "-lsilo_gpu", "-Wl,-rpath,$ORIGIN", "-pthread",
+            *sources, "-o", target, "-L", LIB, "-lsilo_gpu", "-Wl,-rpath,$ORIGIN", "-pthread", "-ldl",
+        ])
+    return target
+
+
+def build_cli(force=False):
+    """lib/silo_query: load a data set directory, answer /query bodies from stdin."""
+    src = os.path.join(PKG, "tools", "silo_query.cpp")
+    target = os.path.join(LIB, "silo_query")
+    deps = [src, os.path.join(LIB, "libsilo_engine.so"), os.path.join(INCLUDE, "silo_engine.h")]
+    if force or _newer(target, deps):
+        _run([
+            "g++", "-O2", "-std=c++20", "-Wall", "-Wextra", "-I", INCLUDE, src, "-o", target, "-L", LIB, "-lsilo_engine",
+            "-lsilo_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB, "-pthread",
         ])
     return target
 
@@ -88,7 +102,7 @@ def build_host_tools(force=False):
 
 
 def build_all(force=False):
-    return [build_gpu(force), build_engine(force), build_host_tools(force)]
+    return [build_gpu(force), build_engine(force), build_cli(force), build_host_tools(force)]
 
 
 if __name__ == "__main__":

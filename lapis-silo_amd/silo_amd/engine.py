@@ -14,7 +14,7 @@ from . import binding
 _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 
 EXPORTED_SYMBOLS = [
-    "silo_engine_create", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
+    "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
     "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_execute_query", "silo_engine_free_string",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
@@ -37,6 +37,7 @@ def load_library():
     lib = ctypes.CDLL(_LIB_PATH)
     vp = ctypes.c_void_p
     lib.silo_engine_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.silo_engine_create_from_directory.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     lib.silo_engine_destroy.argtypes = [vp]
     lib.silo_engine_destroy.restype = None
     lib.silo_engine_add_partition.argtypes = [vp, ctypes.c_uint32]
@@ -105,6 +106,22 @@ class Engine:
             None if default_nucleotide_sequence is None else default_nucleotide_sequence.encode(), device, ctypes.byref(handle)))
         self.handle = handle
         self._callbacks = []
+
+    @classmethod
+    def from_directory(cls, directory, device=0):
+        """Loads a data set directory in the reference's input formats (see include/silo_engine.h)."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self._callbacks = []
+        handle = ctypes.c_void_p()
+        summary = ctypes.c_void_p()
+        _check(self.lib.silo_engine_create_from_directory(str(directory).encode(), device, ctypes.byref(handle), ctypes.byref(summary)))
+        self.handle = handle
+        try:
+            self.summary = json.loads(ctypes.string_at(summary).decode())
+        finally:
+            self.lib.silo_engine_free_string(summary)
+        return self
 
     def close(self):
         if getattr(self, "handle", None):

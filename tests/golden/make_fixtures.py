@@ -60,7 +60,8 @@ def main():
     src = os.path.join(REF, "testBaseData", "exampleDataset")
     dst = os.path.join(HERE, "exampleDataset")
     os.makedirs(dst, exist_ok=True)
-    for name in ["reference_genomes.json", "pangolineage_alias.json", "small_metadata_set.tsv", "database_config.yaml"]:
+    for name in ["reference_genomes.json", "pangolineage_alias.json", "small_metadata_set.tsv", "database_config.yaml",
+                 "preprocessing_config.yaml"]:
         shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
     for name in sorted(os.listdir(src)):
         path = os.path.join(src, name)

@@ -1,0 +1,128 @@
+"""The C++ reader of the reference's input formats (lapis-silo_amd/host/dataset_loader.cpp): the e2e goldens
+again, this time with the engine built by silo_engine_create_from_directory from the files the reference's own
+preprocessing reads (metadata TSV + FASTA.xz, and an ndjson.zst export of the same rows)."""
+import ctypes
+import json
+import lzma
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from tests import dataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(dataset.GOLDEN, "exampleDataset")
+
+
+def zstd_compress(data: bytes) -> bytes:
+    lib = ctypes.CDLL("libzstd.so.1")
+    lib.ZSTD_compressBound.restype = ctypes.c_size_t
+    lib.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    lib.ZSTD_compress.restype = ctypes.c_size_t
+    lib.ZSTD_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    bound = lib.ZSTD_compressBound(len(data))
+    out = ctypes.create_string_buffer(bound)
+    n = lib.ZSTD_compress(out, bound, data, len(data), 3)
+    return out.raw[:n]
+
+
+def write_ndjson_dataset(directory, compression):
+    """The example data set as the reference's ndjson input (preprocessor.cpp:87-131), two rows with null genomes."""
+    data = dataset.load_example_dataset()
+    os.makedirs(directory, exist_ok=True)
+    for name in ("reference_genomes.json", "pangolineage_alias.json", "database_config.yaml"):
+        shutil.copyfile(os.path.join(EXAMPLE, name), os.path.join(directory, name))
+    lines = []
+    for i, row in enumerate(data["rows"]):
+        record = {
+            "metadata": {k: (v if v != "" else None) for k, v in row.items()},
+            "alignedNucleotideSequences": {name: seqs[i] for name, seqs in data["nuc"].items()},
+            "alignedAminoAcidSequences": {name: seqs[i] for name, seqs in data["aa"].items()},
+            "unalignedNucleotideSequences": {name: None for name in data["nuc"]},
+            "nucleotideInsertions": {name: [] for name in data["nuc"]},
+            "aminoAcidInsertions": {name: [] for name in data["aa"]},
+        }
+        lines.append(json.dumps(record))
+    text = ("\n".join(lines) + "\n").encode()
+    if compression == "zst":
+        name = "input.ndjson.zst"
+        payload = zstd_compress(text)
+    elif compression == "xz":
+        name = "input.ndjson.xz"
+        payload = lzma.compress(text)
+    else:
+        name = "input.ndjson"
+        payload = text
+    open(os.path.join(directory, name), "wb").write(payload)
+    open(os.path.join(directory, "preprocessing_config.yaml"), "w").write(
+        f'ndjsonInputFilename: "{name}"\npangoLineageDefinitionFilename: "pangolineage_alias.json"\nreferenceGenomeFilename: "reference_genomes.json"\n')
+
+
+def run_goldens(engine):
+    for case in dataset.load_query_fixtures("queries"):
+        status, document = engine.execute_raw(case["query"])
+        assert status == 200, (case["file"], document)
+        assert document == {"queryResult": case["expectedQueryResult"]}, case["file"]
+    for case in dataset.load_query_fixtures("invalidQueries"):
+        status, document = engine.execute_raw(case["query"])
+        assert (status, document) == (400, case["expectedError"]), case["file"]
+
+
+@pytest.mark.gpu
+def test_tsv_and_fasta_directory(built):
+    from silo_amd.engine import Engine
+
+    with Engine.from_directory(EXAMPLE) as engine:
+        assert engine.summary == {"sequenceCount": 100, "nucleotideStores": 2, "aminoAcidStores": 12, "lineageColumns": 1, "nullSequences": 0}
+        run_goldens(engine)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["zst", "xz", "none"])
+def test_ndjson_directory(built, tmp_path, compression):
+    from silo_amd.engine import Engine
+
+    write_ndjson_dataset(str(tmp_path), compression)
+    with Engine.from_directory(str(tmp_path)) as engine:
+        assert engine.summary["sequenceCount"] == 100
+        run_goldens(engine)
+
+
+@pytest.mark.gpu
+def test_cli_answers_queries(built):
+    cases = dataset.load_query_fixtures("queries")[:6] + dataset.load_query_fixtures("invalidQueries")[:2]
+    stdin = "".join(json.dumps(case["query"]) + "\n" for case in cases)
+    proc = subprocess.run([os.path.join(ROOT, "lapis-silo_amd", "lib", "silo_query"), EXAMPLE], input=stdin, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = proc.stdout.strip().splitlines()
+    assert len(lines) == len(cases)
+    for case, line in zip(cases, lines):
+        status, _, body = line.partition("\t")
+        if "expectedQueryResult" in case:
+            assert status == "200" and json.loads(body) == {"queryResult": case["expectedQueryResult"]}
+        else:
+            assert status == "400" and json.loads(body) == case["expectedError"]
+    assert "Execution (action)" in proc.stderr
+
+
+def test_loader_reports_problems_not_crashes(built, tmp_path):
+    """CPU: the loader's host-side parsing and error reporting (no device is reached before the store is created)."""
+    from silo_amd import engine
+
+    lib = engine.load_library()
+
+    def load(directory):
+        handle, summary = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = lib.silo_engine_create_from_directory(str(directory).encode(), 0, ctypes.byref(handle), ctypes.byref(summary))
+        return rc, lib.silo_engine_last_error().decode()
+
+    rc, message = load(tmp_path / "does-not-exist")
+    assert rc != 0 and "cannot open" in message
+    both = tmp_path / "both"
+    both.mkdir()
+    shutil.copyfile(os.path.join(EXAMPLE, "database_config.yaml"), both / "database_config.yaml")
+    (both / "preprocessing_config.yaml").write_text('ndjsonInputFilename: "a.ndjson"\nmetadataFilename: "b.tsv"\n')
+    rc, message = load(both)
+    assert rc != 0 and message == "Cannot specify both a ndjsonInputFilename ('a.ndjson') and metadataFilename('b.tsv')."
