@@ -138,6 +138,12 @@ struct silo_gpu_store {
    uint16_t* d_lineage = nullptr;    // synthetic stores only
    uint32_t n_lineages = 0;
    uint32_t* d_error_flag = nullptr;
+   // staging of append_sequences, grown on demand and reused across batches
+   uint8_t* d_stage = nullptr;
+   size_t stage_capacity = 0;
+   uint8_t* d_stage_null = nullptr;
+   size_t stage_null_capacity = 0;
+   uint8_t* d_char_table[2] = {nullptr, nullptr};  // per alphabet, uploaded on first use
    std::mutex mutex;
 };
 
@@ -511,8 +517,13 @@ __global__ __launch_bounds__(256) void k_transpose_sequences(
    const uint8_t* row = chars + static_cast<size_t>(local) * pitch;
    for (uint32_t p4 = pos_begin; p4 < pos_end; p4 += 4) {
       uint32_t packed = 0;
-      if (active && !null_genome) {
-         packed = *reinterpret_cast<const uint32_t*>(row + p4);  // pitch is a multiple of 16, p4 of 4
+      if (active && !null_genome) {  // rows are contiguous (pitch = positions, any alignment): byte loads, served from L1
+#pragma unroll
+         for (uint32_t k = 0; k < 4; ++k) {
+            if (p4 + k < pos_end) {
+               packed |= static_cast<uint32_t>(row[p4 + k]) << (8 * k);
+            }
+         }
       }
       for (uint32_t k = 0; k < 4 && p4 + k < pos_end; ++k) {
          uint32_t symbol = SILO_GPU_SYMBOL_NONE;
@@ -857,6 +868,10 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
    (void)hipFree(store->d_ones);
    (void)hipFree(store->d_lineage);
    (void)hipFree(store->d_error_flag);
+   (void)hipFree(store->d_stage);
+   (void)hipFree(store->d_stage_null);
+   (void)hipFree(store->d_char_table[0]);
+   (void)hipFree(store->d_char_table[1]);
    delete store;
 }
 
@@ -889,42 +904,39 @@ int silo_gpu_store_append_sequences(
    seqstore.finalized = false;
    seqstore.totals_ready = false;
    const uint32_t positions = seqstore.dev.positions;
-   const uint32_t pitch = (positions + 15u) / 16u * 16u;
+   const uint32_t pitch = positions;  // rows stay contiguous: ONE host-to-device copy per batch
 
-   uint8_t table[256];
-   fillCharTable(seqstore.alphabet, table);
-
-   uint8_t* d_chars = nullptr;
-   uint8_t* d_null = nullptr;
-   uint8_t* d_table = nullptr;
-   auto release = [&]() {
-      (void)hipFree(d_chars);
-      (void)hipFree(d_null);
-      (void)hipFree(d_table);
-   };
-   hipError_t err = hipMalloc(&d_chars, static_cast<size_t>(n_sequences) * pitch);
-   if (err == hipSuccess) {
-      err = hipMemset(d_chars, 0, static_cast<size_t>(n_sequences) * pitch);
+   const size_t stage_bytes = static_cast<size_t>(n_sequences) * pitch;
+   if (stage_bytes > store->stage_capacity) {
+      (void)hipFree(store->d_stage);
+      store->d_stage = nullptr;
+      store->stage_capacity = 0;
+      HIP_TRY(hipMalloc(&store->d_stage, stage_bytes));
+      store->stage_capacity = stage_bytes;
    }
-   if (err == hipSuccess) {
-      err = hipMemcpy2D(d_chars, pitch, chars, positions, positions, n_sequences, hipMemcpyHostToDevice);
+   if (is_null != nullptr && n_sequences > store->stage_null_capacity) {
+      (void)hipFree(store->d_stage_null);
+      store->d_stage_null = nullptr;
+      store->stage_null_capacity = 0;
+      HIP_TRY(hipMalloc(&store->d_stage_null, n_sequences));
+      store->stage_null_capacity = n_sequences;
    }
-   if (err == hipSuccess && is_null != nullptr) {
-      err = hipMalloc(&d_null, n_sequences);
-      if (err == hipSuccess) {
-         err = hipMemcpy(d_null, is_null, n_sequences, hipMemcpyHostToDevice);
-      }
+   uint8_t*& d_table_slot = store->d_char_table[seqstore.alphabet == SILO_GPU_ALPHABET_NUCLEOTIDE ? 0 : 1];
+   if (d_table_slot == nullptr) {
+      uint8_t table[256];
+      fillCharTable(seqstore.alphabet, table);
+      HIP_TRY(hipMalloc(&d_table_slot, 256));
+      HIP_TRY(hipMemcpy(d_table_slot, table, 256, hipMemcpyHostToDevice));
    }
-   if (err == hipSuccess) {
-      err = hipMalloc(&d_table, 256);
+   uint8_t* d_chars = store->d_stage;
+   uint8_t* d_null = is_null != nullptr ? store->d_stage_null : nullptr;
+   uint8_t* d_table = d_table_slot;
+   auto release = [] {};  // staging is owned by the store
+   HIP_TRY(hipMemcpy(d_chars, chars, stage_bytes, hipMemcpyHostToDevice));
+   if (is_null != nullptr) {
+      HIP_TRY(hipMemcpy(d_null, is_null, n_sequences, hipMemcpyHostToDevice));
    }
-   if (err == hipSuccess) {
-      err = hipMemcpy(d_table, table, 256, hipMemcpyHostToDevice);
-   }
-   if (err != hipSuccess) {
-      release();
-      return fail(SILO_GPU_ERR_HIP, std::string("staging sequences: ") + hipGetErrorString(err));
-   }
+   hipError_t err = hipSuccess;
 
    const uint32_t first_word = first_sequence / 64u;
    const uint32_t last_word = (first_sequence + n_sequences - 1u) / 64u;
