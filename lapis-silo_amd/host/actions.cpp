@@ -134,7 +134,7 @@ std::map<std::string, typename Mutations<SymbolType>::PrefilteredBitmaps> Mutati
 }
 
 template <typename SymbolType>
-std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
+DeviceBuffer Mutations<SymbolType>::calculateMutationsPerPosition(
    const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
 ) {
    // mutations.cpp:139-164 runs and_cardinality(filter, column) per position x symbol under
@@ -143,9 +143,8 @@ std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
    const auto sequence_length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
    constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
    const size_t n_counts = static_cast<size_t>(sequence_length) * n_symbols;
-   std::vector<uint32_t> counts(n_counts, 0);
    if (database.partitions.empty() || n_counts == 0) {
-      return counts;
+      return {};
    }
    // position-range shard of this rank; [0, P) when not sharded by position
    const auto [pos_begin, pos_end] = database.positionWindow(sequence_length);
@@ -169,9 +168,7 @@ std::vector<uint32_t> Mutations<SymbolType>::calculateMutationsPerPosition(
    }
    Trace::mark("scan_launched");
    allReduce(database, device_counts.as<uint32_t>(), n_counts);
-   checkGpu(silo_gpu_memcpy_d2h(counts.data(), device_counts.get(), n_counts * sizeof(uint32_t), queryStream()), "silo_gpu_memcpy_d2h");
-   Trace::mark("counts_on_host");
-   return counts;
+   return device_counts;  // still in flight: execute() launches every sequence store before it fetches any
 }
 
 template <typename SymbolType>
@@ -187,12 +184,21 @@ void Mutations<SymbolType>::validateOrderByFields(const Database& /*database*/) 
 
 template <typename SymbolType>
 void Mutations<SymbolType>::addMutationsToOutput(
-   const Database& database, const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store,
-   const PrefilteredBitmaps& bitmap_filter, std::vector<QueryResultEntry>& output
+   const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const DeviceBuffer& device_counts,
+   std::vector<QueryResultEntry>& output
 ) const {  // mutations.cpp:184-232
    const size_t sequence_length = sequence_store.reference_sequence.size();
    constexpr size_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
-   const std::vector<uint32_t> count_of_mutations_per_position = calculateMutationsPerPosition(database, sequence_store, bitmap_filter);
+   std::vector<uint32_t> count_of_mutations_per_position(sequence_length * n_symbols, 0);
+   if (device_counts) {
+      checkGpu(
+         silo_gpu_memcpy_d2h(
+            count_of_mutations_per_position.data(), device_counts.get(), count_of_mutations_per_position.size() * sizeof(uint32_t), queryStream()
+         ),
+         "silo_gpu_memcpy_d2h"
+      );
+   }
+   Trace::mark("counts_on_host");
 
    for (size_t pos = 0; pos < sequence_length; ++pos) {
       const uint32_t* counts_at_position = count_of_mutations_per_position.data() + pos * n_symbols;
@@ -246,16 +252,24 @@ QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector
    std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, bitmap_filter);
    Trace::mark("filter_materialized");
 
-   std::vector<QueryResultEntry> mutation_proportions;
+   // Launch the scans of every requested sequence store first (they queue on this thread's stream), then fetch
+   // and post-process them in order: the device works on store k+1 while the host builds the rows of store k.
+   const bool sharded = database.shard_world > 1 && database.all_reduce != nullptr;
+   const PrefilteredBitmaps no_bitmaps{};
+   std::vector<std::pair<const std::string*, DeviceBuffer>> in_flight;
    for (const auto& sequence_name : sequence_names_to_evaluate) {
       const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-      const bool sharded = database.shard_world > 1 && database.all_reduce != nullptr;
       if (bitmaps_to_evaluate.count(sequence_name) != 0) {
-         addMutationsToOutput(database, sequence_name, sequence_store, bitmaps_to_evaluate.at(sequence_name), mutation_proportions);
+         in_flight.emplace_back(&sequence_name, calculateMutationsPerPosition(database, sequence_store, bitmaps_to_evaluate.at(sequence_name)));
       } else if (sharded) {
          // this rank's filter is empty but other ranks may contribute: take part in the collective
-         addMutationsToOutput(database, sequence_name, sequence_store, PrefilteredBitmaps{}, mutation_proportions);
+         in_flight.emplace_back(&sequence_name, calculateMutationsPerPosition(database, sequence_store, no_bitmaps));
       }
+   }
+   std::vector<QueryResultEntry> mutation_proportions;
+   for (const auto& [sequence_name, device_counts] : in_flight) {
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(*sequence_name);
+      addMutationsToOutput(*sequence_name, sequence_store, device_counts, mutation_proportions);
    }
    Trace::mark("rows_built");
    return {mutation_proportions};

@@ -454,14 +454,15 @@ class Mutations : public Action {
 
    static std::map<std::string, PrefilteredBitmaps> preFilterBitmaps(const Database& database, std::vector<OperatorResult>& bitmap_filter);
 
-   /// counts[position][valid symbol], summed over partitions (and ranks): the K1 launches.
-   static std::vector<uint32_t> calculateMutationsPerPosition(
+   /// Launches the K1 scans of one sequence store: counts[position][valid symbol] on the device, summed over
+   /// partitions (and ranks); returned while still in flight on this thread's stream.
+   static DeviceBuffer calculateMutationsPerPosition(
       const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
    );
 
    void addMutationsToOutput(
-      const Database& database, const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store,
-      const PrefilteredBitmaps& bitmap_filter, std::vector<QueryResultEntry>& output
+      const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const DeviceBuffer& device_counts,
+      std::vector<QueryResultEntry>& output
    ) const;
 
    void validateOrderByFields(const Database& database) const override;
