@@ -1,0 +1,99 @@
+"""Size-independent properties of the device path at a size the oracles cannot reach in seconds
+(3 M sequences x 1 500 positions, 3.4 GB of planes): linearity of the Mutations table in the filter,
+complement, per-position conservation, idempotence and agreement of the kernel variants — plus the empty
+edge cases (no rows, no partitions)."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, P, L = 3_000_000, 1500, 300
+
+
+@pytest.fixture(scope="module")
+def big(built):
+    from silo_amd import binding, synth
+
+    tree = synth.make_lineage_tree(L)
+    lineage = synth.assign_lineages(N, tree, 21)
+    ref = synth.random_reference(P, "nuc", 22)
+    model = synth.make_model(N, ref, "nuc", tree, lineage, seed=23)
+    store = binding.GpuStore(N, [dict(name="main", alphabet="nuc", reference=ref)])
+    store.generate_synthetic(0, model)
+    store.finalize()
+    yield store, tree, lineage
+    store.close()
+
+
+def lineage_filter(store, tree, roots):
+    member = np.zeros(L, dtype=np.uint8)
+    for root in roots:
+        member |= tree.subtree(root)
+    ptr = store.bitset_alloc()
+    store.bitset_from_lineages(ptr, member)
+    return ptr, member
+
+
+def test_linearity_complement_and_conservation(big):
+    from silo_amd import binding as b
+
+    store, tree, lineage = big
+    f1, m1 = lineage_filter(store, tree, [1])   # subtree B.1
+    f2, m2 = lineage_filter(store, tree, [2])   # subtree B.2 (disjoint from B.1)
+    f12, m12 = lineage_filter(store, tree, [1, 2])
+    assert not (m1 & m2).any()
+    c1, c2, c12 = store.mutations_scan(0, f1), store.mutations_scan(0, f2), store.mutations_scan(0, f12)
+    call = store.mutations_scan(0, None)
+    assert np.array_equal(c1.astype(np.int64) + c2, c12)            # additive over disjoint filters
+    # complement through the fused evaluator: NOT f12
+    not12 = store.bitset_alloc()
+    cnt = store.count_buffer()
+    store.filter_eval(b.encode(b.OP_NOT, 0, b.LEAF_OPERAND + 0), [f12], 1, not12, cnt)
+    n12 = int(m12[lineage].sum())
+    assert store.read_count(cnt) == N - n12 and store.popcount(f12) == n12
+    assert np.array_equal(store.mutations_scan(0, not12).astype(np.int64) + c12, call)
+    # conservation: every filtered row has exactly one symbol per position (valid, missing or ambiguous)
+    assert (c12.sum(axis=1) <= n12).all() and (call.sum(axis=1) <= N).all()
+    for position in (0, 7, P // 2, P - 1):
+        other = 0
+        for symbol in range(5, 16):
+            words = store.plane_download(0, position, symbol)
+            other += int(sum(bin(int(w)).count("1") for w in words[words != 0]))
+        assert int(call[position].sum()) + other == N
+    # idempotence / determinism and the kernel variants agree bit for bit
+    assert np.array_equal(store.mutations_scan(0, f12), c12)
+    for variant in (2, 10, 12):
+        store.tune(1, variant)
+        assert np.array_equal(store.mutations_scan(0, f12), c12), variant
+    store.tune(1, 0)
+    # sub-ranges tile the full range
+    parts = [store.mutations_scan(0, f1, lo, hi) for lo, hi in ((0, 1), (1, 700), (700, P))]
+    assert np.array_equal(np.concatenate(parts), c1)
+
+
+def test_empty_database_and_empty_partition(built):
+    from silo_amd.engine import Engine
+
+    genomes = {"nucleotideSequences": [{"name": "main", "sequence": "ACGTACGT"}], "genes": [{"name": "S", "sequence": "MK*"}]}
+    queries = [
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "True"}},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "Not", "child": {"type": "NucleotideEquals", "position": 3, "symbol": "G"}}},
+        {"action": {"type": "Mutations", "minProportion": 0}, "filterExpression": {"type": "True"}},
+        {"action": {"type": "AminoAcidMutations", "minProportion": 0}, "filterExpression": {"type": "Maybe", "child": {"type": "NucleotideEquals", "position": 1, "symbol": "A"}}},
+    ]
+    with Engine(genomes) as engine:            # no partitions at all
+        engine.finalize()
+        assert [engine.execute_query(q) for q in queries] == [[{"count": 0}], [{"count": 0}], [], []]
+    with Engine(genomes) as engine:            # one partition without rows next to one with two rows
+        engine.add_partition(0)
+        part = engine.add_partition(2)
+        engine.append_sequences(part, "main", False, 0, ["ACGTACGT", None])
+        engine.append_sequences(part, "S", True, 0, ["MK*", "MR*"])
+        engine.set_lineage_column(part, "pango_lineage", ["B.1", None])
+        engine.finalize()
+        got = [engine.execute_query(q) for q in queries]
+        assert got[0] == [{"count": 2}] and got[1] == [{"count": 1}]
+        assert got[2] == []                    # the only non-null genome equals the reference
+        assert got[3] == [{"count": 1, "mutation": "K2R", "proportion": 0.5, "sequenceName": "S"}]
