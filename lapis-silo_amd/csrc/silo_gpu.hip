@@ -319,6 +319,106 @@ __global__ __launch_bounds__(SCAN_THREADS, (WPT <= 8 ? 8 : 4)) void k_scan_tiled
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1c: the same scan for Q filters at once (a batch of concurrent Mutations queries over one store).
+// Every plane row is loaded ONCE and ANDed with the Q filter tiles held in registers, so Q queries cost
+// one pass over the planes; at Q = 4 the extra AND / popcount / DPP work still fits under the HBM time.
+// 8 words per thread (Q * 16 filter registers), out-of-row chunks read word 0 against zero filters.
+// ------------------------------------------------------------------------------------------------
+struct ScanBatchArgs {
+   const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
+   uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
+};
+
+template <int Q>
+__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tiled_batch(
+   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, uint32_t row_words, uint32_t n_rows, uint32_t rows_per_block,
+   uint32_t n_tiles
+) {
+   constexpr int WPT = 8;
+   constexpr int CHUNKS = WPT / 2;
+   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
+   __shared__ uint32_t s_partial[2][SCAN_WAVES][SCAN_ROWS_BATCH][Q];
+
+   const uint32_t tid = threadIdx.x;
+   const uint32_t wave = tid >> 6;
+   const bool writer = (tid & 63u) == 63u;
+   const uint32_t tile = blockIdx.x % n_tiles;
+   const uint32_t row_group = blockIdx.x / n_tiles;
+   const uint32_t row_begin = row_group * rows_per_block;
+   const uint32_t row_end = min(n_rows, row_begin + rows_per_block);
+   const uint32_t last_row = row_end - 1;
+
+   uint32_t word[CHUNKS];
+   ulonglong2 f[Q][CHUNKS];
+#pragma unroll
+   for (int j = 0; j < CHUNKS; ++j) {
+      word[j] = tile * TILE_WORDS + (j * SCAN_THREADS + tid) * 2;
+      const bool inside = word[j] < row_words;
+      if (!inside) {
+         word[j] = 0;
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+         f[q][j] = inside ? *reinterpret_cast<const ulonglong2*>(batch.filters[q] + word[j]) : make_ulonglong2(0, 0);
+      }
+   }
+   auto load_row = [&](uint32_t row, ulonglong2 (&dst)[CHUNKS]) {
+      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
+#pragma unroll
+      for (int j = 0; j < CHUNKS; ++j) {
+         dst[j] = loadPlane16<true>(row_ptr + word[j]);
+      }
+   };
+   auto reduce_row = [&](const ulonglong2 (&src)[CHUNKS], uint32_t buffer, uint32_t slot, bool store) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+         uint32_t acc = 0;
+#pragma unroll
+         for (int j = 0; j < CHUNKS; ++j) {
+            acc += popc128(src[j], f[q][j]);
+         }
+         acc = waveSumToLane63(acc);
+         if (writer && store) {
+            s_partial[buffer][wave][slot][q] = acc;
+         }
+      }
+   };
+   auto flush = [&](uint32_t batch_first_row, uint32_t n_batch, uint32_t buffer) {
+      __syncthreads();
+      for (uint32_t item = tid; item < n_batch * Q; item += SCAN_THREADS) {
+         const uint32_t row = item / Q;
+         const uint32_t q = item % Q;
+         uint32_t total = 0;
+#pragma unroll
+         for (int w = 0; w < SCAN_WAVES; ++w) {
+            total += s_partial[buffer][w][row][q];
+         }
+         if (total != 0) {
+            atomicAdd(&batch.counts[q][batch_first_row + row], total);
+         }
+      }
+   };
+
+   ulonglong2 buf_a[CHUNKS];
+   ulonglong2 buf_b[CHUNKS];
+   load_row(row_begin, buf_a);
+   uint32_t buffer = 0;
+   uint32_t batch_first_row = row_begin;
+   for (uint32_t row = row_begin; row < row_end; row += 2) {
+      load_row(min(row + 1, last_row), buf_b);
+      reduce_row(buf_a, buffer, row - batch_first_row, true);
+      load_row(min(row + 2, last_row), buf_a);
+      reduce_row(buf_b, buffer, row + 1 - batch_first_row, row + 1 < row_end);
+      const uint32_t done = min(row + 2, row_end) - batch_first_row;
+      if (done >= SCAN_ROWS_BATCH || row + 2 >= row_end) {
+         flush(batch_first_row, done, buffer);
+         batch_first_row += done;
+         buffer ^= 1u;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1b: one wave per row, for short rows (small N) where a 256-thread column tile would be empty.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan_rowwave(
@@ -1156,6 +1256,75 @@ int silo_gpu_malloc(size_t bytes, void** out_dev) {
 
 void silo_gpu_free(void* dev_ptr) {
    (void)hipFree(dev_ptr);
+}
+
+int silo_gpu_mutations_scan_batch(
+   const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* const* filters_dev, uint32_t n_filters, uint32_t pos_begin,
+   uint32_t pos_end, uint32_t* const* counts_out_dev, void* stream
+) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || filters_dev == nullptr || counts_out_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_batch: bad arguments");
+   }
+   for (uint32_t q = 0; q < n_filters; ++q) {
+      if (filters_dev[q] == nullptr || counts_out_dev[q] == nullptr) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_batch: null filter or counts buffer");
+      }
+   }
+   const SeqStoreDev& dev = store->seqstores[seqstore_id].dev;
+   if (pos_begin > pos_end || pos_end > dev.positions) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");
+   }
+   constexpr uint32_t TILE_WORDS = SCAN_THREADS * 8;
+   // short rows (one wave per row kernel) and single filters take the one-filter path
+   if (n_filters == 1 || dev.row_words < TILE_WORDS) {
+      for (uint32_t q = 0; q < n_filters; ++q) {
+         const int rc = silo_gpu_mutations_scan(store, seqstore_id, filters_dev[q], pos_begin, pos_end, counts_out_dev[q], stream);
+         if (rc != SILO_GPU_OK) {
+            return rc;
+         }
+      }
+      return SILO_GPU_OK;
+   }
+   if (pos_begin == pos_end || dev.n_scan == 0 || n_filters == 0) {
+      return SILO_GPU_OK;
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   const uint32_t row_words = dev.row_words;
+   const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
+   const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
+   const uint32_t rows_per_block = 64;
+   const uint32_t n_tiles = (row_words + TILE_WORDS - 1) / TILE_WORDS;
+   const dim3 grid(n_tiles * ((n_rows + rows_per_block - 1) / rows_per_block));
+   for (uint32_t first = 0; first < n_filters; first += SILO_GPU_MAX_SCAN_BATCH) {
+      const uint32_t q_count = std::min<uint32_t>(SILO_GPU_MAX_SCAN_BATCH, n_filters - first);
+      ScanBatchArgs batch{};
+      for (uint32_t q = 0; q < q_count; ++q) {
+         batch.filters[q] = filters_dev[first + q];
+         batch.counts[q] = counts_out_dev[first + q];
+      }
+      switch (q_count) {
+         case 1: {  // the odd one out of a batch: the single-filter kernel
+            const int rc = silo_gpu_mutations_scan(store, seqstore_id, batch.filters[0], pos_begin, pos_end, batch.counts[0], stream);
+            if (rc != SILO_GPU_OK) {
+               return rc;
+            }
+            break;
+         }
+         case 2:
+            k_scan_tiled_batch<2><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
+            break;
+         case 3:
+            k_scan_tiled_batch<3><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
+            break;
+         default:
+            k_scan_tiled_batch<4><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
+            break;
+      }
+      HIP_TRY(hipGetLastError());
+   }
+   g_last_scan_kernel = "k_scan_tiled_batch";
+   return SILO_GPU_OK;
 }
 
 int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) {

@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
-    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
 ]
@@ -135,6 +135,7 @@ def load_library():
     lib.silo_gpu_filter_eval.argtypes = [vp, ctypes.POINTER(BitProg), vp, vp, vp]
     lib.silo_gpu_popcount.argtypes = [vp, vp, vp, vp]
     lib.silo_gpu_mutations_scan.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_mutations_scan_batch.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), vp]
     lib.silo_gpu_memset_async.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
     lib.silo_gpu_event_create.argtypes = [ctypes.POINTER(vp)]
     lib.silo_gpu_event_record.argtypes = [vp, vp]
@@ -406,6 +407,25 @@ class GpuStore:
         out = self.read(counts, np.uint32, n, stream).reshape(pos_end - pos_begin, n_scan)
         self.free(counts)
         return out
+
+    def mutations_scan_batch(self, seqstore_id, filter_ptrs, pos_begin=0, pos_end=None, stream=None):
+        """One pass over the planes for several filters; returns a list of uint32 count tables."""
+        if pos_end is None:
+            pos_end = self.positions(seqstore_id)
+        n_scan = len(self.scan_symbols[seqstore_id])
+        n = (pos_end - pos_begin) * n_scan
+        outs = []
+        for _ in filter_ptrs:
+            buf = self.malloc(max(4, 4 * n))
+            self.memset(buf, 0, max(4, 4 * n), stream)
+            outs.append(buf)
+        filters = (ctypes.c_void_p * len(filter_ptrs))(*[(f.value if isinstance(f, ctypes.c_void_p) else f) for f in filter_ptrs])
+        counts = (ctypes.c_void_p * len(outs))(*[o.value for o in outs])
+        _check(self.lib.silo_gpu_mutations_scan_batch(self.handle, seqstore_id, filters, len(filter_ptrs), pos_begin, pos_end, counts, stream))
+        tables = [self.read(o, np.uint32, n, stream).reshape(pos_end - pos_begin, n_scan) for o in outs]
+        for o in outs:
+            self.free(o)
+        return tables
 
     def last_scan_kernel(self):
         return self.lib.silo_gpu_last_scan_kernel().decode()

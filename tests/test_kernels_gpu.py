@@ -184,3 +184,26 @@ def test_synthetic_store_matches_cpu_twin(built):
             got = store.mutations_scan(0, fptr)
             want = dense.mutation_counts(sym, filt, list(store.scan_symbols[0]))
             assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,alphabet", [(5000, "nuc"), (140000, "aa"), (300001, "nuc")])
+def test_batched_scan_matches_single_scans(built, n, alphabet):
+    """K1c: one pass over the planes for 1..9 filters gives exactly the tables of the single-filter scans."""
+    rng = np.random.default_rng(n + 3)
+    positions = 19
+    sym = random_symbols(rng, n, positions, alphabet)
+    chars = (NUC_CHARS if alphabet == "nuc" else AA_CHARS)[sym]
+    with make_store(n, [dict(name="s", alphabet=alphabet, reference=sym[0].copy())]) as store:
+        store.append_sequences(0, 0, chars)
+        store.finalize()
+        scan_symbols = list(store.scan_symbols[0])
+        masks = [rng.random(n) < p for p in (0.5, 0.01, 0.9, 0.3, 0.0, 1.0, 0.6, 0.2, 0.75)]
+        ptrs = []
+        for mask in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            ptrs.append(ptr)
+        for count in (1, 2, 3, 4, 5, 9):
+            tables = store.mutations_scan_batch(0, ptrs[:count], 2, 17)
+            for mask, table in zip(masks, tables):
+                assert np.array_equal(table, dense.mutation_counts(sym, mask, scan_symbols, 2, 17)), count
