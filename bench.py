@@ -242,6 +242,38 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
     }
 
 
+def batch_workload(engine, positions, n_sequences, sync, reps=5):
+    """4 concurrent Mutations queries with different lineage filters: one by one vs. one silo_engine_execute_batch
+    call in which their scans share a single pass over the planes (K1c)."""
+    queries = [json.dumps({
+        "action": {"type": "Mutations", "minProportion": 0.05},
+        "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": lineage, "includeSublineages": True},
+    }).encode() for lineage in ("B.1", "B.2", "B.3", "B.1.1")]
+    one_by_one = [engine.execute_text(q) for q in queries]
+    batched = engine.execute_batch_text(queries)
+    if batched != one_by_one:
+        raise AssertionError("batched results differ from one-by-one results")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for q in queries:
+            engine.execute_text(q)
+    sync()
+    sequential = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        engine.execute_batch_text(queries)
+    sync()
+    together = (time.perf_counter() - t0) / reps
+    return {
+        "workload": f"4 Mutations queries (PangoLineage B.1*, B.2*, B.3*, B.1.1*), {n_sequences} sequences; responses identical both ways",
+        "ms_one_by_one": sequential * 1e3,
+        "ms_one_batch": together * 1e3,
+        "value_one_batch": 4 * n_sequences * positions / together,
+        "unit": "positions*sequences/s",
+    }
+
+
 def run_steps(engine, query, steps, warmup, sync):
     query = query.encode()
     for _ in range(warmup):
@@ -404,6 +436,7 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
     if rank == 0 and world == 1 and not use_dist and not args.no_also:
         result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
+        result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)
     lib.silo_gpu_free(filt)
     lib.silo_gpu_free(counts_dev)
     engine.close()

@@ -82,6 +82,18 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
  * result or the error document; *out_http_status is 200, 400 or 500.  Returns 0 unless the arguments
  * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */
 int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status);
+
+/* Executes `n_queries` queries as one batch: every query is parsed, compiled and its filter evaluated, then
+ * the Mutations / AminoAcidMutations scans of all of them are launched together so that queries over the same
+ * sequence store share passes over the planes (up to SILO_GPU_MAX_SCAN_BATCH filters per pass), then the rows
+ * of each query are built.  Results are exactly those of n_queries silo_engine_execute_query calls, in order:
+ * out_jsons[i] (malloc'ed, free each with silo_engine_free_string) and out_http_statuses[i] per query; one
+ * failing query does not affect the others.  Stands where silo_api's request handler (src/silo_api/
+ * query_handler.cpp:26-73) would hand several queued requests to the engine at once.  Returns 0 unless the
+ * arguments themselves are invalid.  With collectives installed (silo_engine_set_sharding) queries run one by one. */
+int silo_engine_execute_batch(
+   const silo_engine* engine, const char* const* query_jsons, uint32_t n_queries, char** out_jsons, int* out_http_statuses
+);
 void silo_engine_free_string(char* text);
 
 /* The reference's two per-query timings (query_engine.cpp:63-65) of the last query on this thread. */

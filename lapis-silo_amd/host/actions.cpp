@@ -55,15 +55,86 @@ void Action::setOrdering(const std::vector<OrderByField>& order_by_fields_, std:
    offset = offset_;
 }
 
-QueryResult Action::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
-   validateOrderByFields(database);
-   QueryResult result = execute(database, std::move(bitmap_filter));
+QueryResult Action::orderAndLimit(QueryResult result) const {  // action.cpp:110-116
    if (offset.has_value() && offset.value() >= result.query_result.size()) {
       return {};
    }
    applySort(result);
    applyOffsetAndLimit(result);
    return result;
+}
+
+QueryResult Action::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
+   validateOrderByFields(database);
+   return orderAndLimit(execute(database, std::move(bitmap_filter)));
+}
+
+std::unique_ptr<Action::Pending> Action::begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
+   validateOrderByFields(database);
+   auto pending = std::make_unique<Pending>();
+   pending->bitmap_filter = std::move(bitmap_filter);
+   return pending;
+}
+
+QueryResult Action::finish(const Database& database, Pending& pending) const {
+   return orderAndLimit(execute(database, std::move(pending.bitmap_filter)));
+}
+
+// ---- ScanBatcher ---------------------------------------------------------------------------------
+namespace {
+thread_local ScanBatcher* g_active_batcher = nullptr;
+}
+
+ScanBatcher::ScanBatcher() : previous(g_active_batcher) {
+   g_active_batcher = this;
+}
+
+ScanBatcher::~ScanBatcher() {
+   g_active_batcher = previous;
+}
+
+ScanBatcher* ScanBatcher::active() {
+   return g_active_batcher;
+}
+
+void ScanBatcher::flush() {
+   // requests over the same planes (store, sequence store, position range) share passes
+   std::vector<bool> done(requests.size(), false);
+   for (size_t i = 0; i < requests.size(); ++i) {
+      if (done[i]) {
+         continue;
+      }
+      const Request& first = requests[i];
+      std::vector<const uint64_t*> filters;
+      std::vector<uint32_t*> counts;
+      for (size_t k = i; k < requests.size(); ++k) {
+         const Request& other = requests[k];
+         if (done[k] || other.store != first.store || other.seqstore_id != first.seqstore_id || other.pos_begin != first.pos_begin ||
+             other.pos_end != first.pos_end) {
+            continue;
+         }
+         done[k] = true;
+         if (other.filter == nullptr) {  // full filter: cached totals, no pass over the planes
+            checkGpu(
+               silo_gpu_mutations_scan(other.store, other.seqstore_id, nullptr, other.pos_begin, other.pos_end, other.counts, queryStream()),
+               "silo_gpu_mutations_scan"
+            );
+         } else {
+            filters.push_back(other.filter);
+            counts.push_back(other.counts);
+         }
+      }
+      if (!filters.empty()) {
+         checkGpu(
+            silo_gpu_mutations_scan_batch(
+               first.store, first.seqstore_id, filters.data(), static_cast<uint32_t>(filters.size()), first.pos_begin, first.pos_end,
+               counts.data(), queryStream()
+            ),
+            "silo_gpu_mutations_scan_batch"
+         );
+      }
+   }
+   requests.clear();
 }
 
 namespace {
@@ -154,17 +225,23 @@ DeviceBuffer Mutations<SymbolType>::calculateMutationsPerPosition(
    uint32_t* window = device_counts.as<uint32_t>() + static_cast<size_t>(pos_begin) * n_symbols;
    // the device store of a rank holds exactly its window: local positions [0, pos_end - pos_begin)
    const uint32_t local_positions = pos_end - pos_begin;
+   // inside a batch of queries the scans are only recorded; collectives need their scan right away
+   ScanBatcher* batcher = database.all_reduce == nullptr ? ScanBatcher::active() : nullptr;
+   const auto scan = [&](const SequenceStorePartition<SymbolType>& store, const uint64_t* filter) {
+      if (batcher != nullptr) {
+         batcher->add({store.store, store.seqstore_id, filter, 0, local_positions, window});
+      } else {
+         checkGpu(
+            silo_gpu_mutations_scan(store.store, store.seqstore_id, filter, 0, local_positions, window, queryStream()), "silo_gpu_mutations_scan"
+         );
+      }
+   };
    for (const auto& [filter, store] : bitmap_filter.bitmaps) {
-      checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, filter.bitset(), 0, local_positions, window, queryStream()),
-         "silo_gpu_mutations_scan"
-      );
+      scan(store, filter.bitset());
    }
    for (const auto& [filter, store] : bitmap_filter.full_bitmaps) {
       // full filter: the reference reads plain cardinalities (mutations.cpp:98-136); NULL = all rows
-      checkGpu(
-         silo_gpu_mutations_scan(store.store, store.seqstore_id, nullptr, 0, local_positions, window, queryStream()), "silo_gpu_mutations_scan"
-      );
+      scan(store, nullptr);
    }
    Trace::mark("scan_launched");
    allReduce(database, device_counts.as<uint32_t>(), n_counts);
@@ -235,7 +312,9 @@ void Mutations<SymbolType>::addMutationsToOutput(
 }
 
 template <typename SymbolType>
-QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // mutations.cpp:234-272
+std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
+   // first half of mutations.cpp:234-272: validate, pre-filter, queue the scans of every requested store
+   validateOrderByFields(database);
    std::vector<std::string> sequence_names_to_evaluate;
    for (const auto& sequence_name : sequence_names) {
       CHECK_SILO_QUERY(
@@ -249,27 +328,52 @@ QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector
          sequence_names_to_evaluate.emplace_back(sequence_name);
       }
    }
-   std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, bitmap_filter);
+   auto pending = std::make_unique<PendingScans>();
+   pending->bitmap_filter = std::move(bitmap_filter);  // the scans read these bitsets: they live as long as the scans
+   std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, pending->bitmap_filter);
    Trace::mark("filter_materialized");
 
-   // Launch the scans of every requested sequence store first (they queue on this thread's stream), then fetch
-   // and post-process them in order: the device works on store k+1 while the host builds the rows of store k.
+   // Queue the scans of every requested sequence store first (they run in order on this thread's stream), then
+   // finish() fetches and post-processes them: the device works on store k+1 while the host builds the rows of
+   // store k — and inside a batch of queries the scans of different queries share passes over the planes.
    const bool sharded = database.shard_world > 1 && database.all_reduce != nullptr;
    const PrefilteredBitmaps no_bitmaps{};
-   std::vector<std::pair<const std::string*, DeviceBuffer>> in_flight;
    for (const auto& sequence_name : sequence_names_to_evaluate) {
       const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
       if (bitmaps_to_evaluate.count(sequence_name) != 0) {
-         in_flight.emplace_back(&sequence_name, calculateMutationsPerPosition(database, sequence_store, bitmaps_to_evaluate.at(sequence_name)));
+         pending->in_flight.emplace_back(sequence_name, calculateMutationsPerPosition(database, sequence_store, bitmaps_to_evaluate.at(sequence_name)));
       } else if (sharded) {
          // this rank's filter is empty but other ranks may contribute: take part in the collective
-         in_flight.emplace_back(&sequence_name, calculateMutationsPerPosition(database, sequence_store, no_bitmaps));
+         pending->in_flight.emplace_back(sequence_name, calculateMutationsPerPosition(database, sequence_store, no_bitmaps));
       }
    }
+   return pending;
+}
+
+template <typename SymbolType>
+QueryResult Mutations<SymbolType>::finish(const Database& database, Action::Pending& pending) const {
+   auto& scans = dynamic_cast<PendingScans&>(pending);
    std::vector<QueryResultEntry> mutation_proportions;
-   for (const auto& [sequence_name, device_counts] : in_flight) {
-      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(*sequence_name);
-      addMutationsToOutput(*sequence_name, sequence_store, device_counts, mutation_proportions);
+   for (const auto& [sequence_name, device_counts] : scans.in_flight) {
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+      addMutationsToOutput(sequence_name, sequence_store, device_counts, mutation_proportions);
+   }
+   Trace::mark("rows_built");
+   return orderAndLimit({mutation_proportions});
+}
+
+template <typename SymbolType>
+QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // mutations.cpp:234-272
+   // unordered result of the two phases run back to back (executeAndOrder applies the ordering)
+   auto pending = begin(database, std::move(bitmap_filter));
+   auto& scans = dynamic_cast<PendingScans&>(*pending);
+   if (ScanBatcher* batcher = ScanBatcher::active(); batcher != nullptr) {
+      batcher->flush();
+   }
+   std::vector<QueryResultEntry> mutation_proportions;
+   for (const auto& [sequence_name, device_counts] : scans.in_flight) {
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+      addMutationsToOutput(sequence_name, sequence_store, device_counts, mutation_proportions);
    }
    Trace::mark("rows_built");
    return {mutation_proportions};

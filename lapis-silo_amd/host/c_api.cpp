@@ -271,6 +271,60 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
    return *out_json != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
 }
 
+int silo_engine_execute_batch(const silo_engine* engine, const char* const* query_jsons, uint32_t n_queries, char** out_jsons, int* out_http_statuses) {
+   if (engine == nullptr || (n_queries != 0 && (query_jsons == nullptr || out_jsons == nullptr || out_http_statuses == nullptr))) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_execute_batch: null argument");
+   }
+   std::vector<std::string> queries;
+   queries.reserve(n_queries);
+   for (uint32_t i = 0; i < n_queries; ++i) {
+      if (query_jsons[i] == nullptr) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_execute_batch: null query");
+      }
+      queries.emplace_back(query_jsons[i]);
+      out_jsons[i] = nullptr;
+   }
+   std::vector<silo::query_engine::QueryEngine::BatchOutcome> outcomes;
+   std::exception_ptr whole_batch_error;
+   try {
+      const silo::query_engine::QueryEngine query_engine(engine->database);
+      outcomes = query_engine.executeQueries(queries);
+   } catch (...) {  // a failed shared launch fails every query of the batch
+      whole_batch_error = std::current_exception();
+      outcomes.assign(n_queries, {});
+   }
+   bool out_of_memory = false;
+   for (uint32_t i = 0; i < n_queries; ++i) {
+      // per query the exception -> HTTP mapping of src/silo_api/query_handler.cpp:42-73
+      try {
+         const std::exception_ptr error = whole_batch_error != nullptr ? whole_batch_error : outcomes[i].error;
+         if (error != nullptr) {
+            std::rethrow_exception(error);
+         }
+         out_jsons[i] = duplicate(silo::query_engine::toJson(outcomes[i].result).dump());
+         out_http_statuses[i] = 200;
+      } catch (const silo::QueryParseException& ex) {
+         out_jsons[i] = duplicate(errorDocument("Bad request", ex.what()));
+         out_http_statuses[i] = 400;
+      } catch (const std::exception& ex) {
+         out_jsons[i] = duplicate(errorDocument("Internal Server Error", ex.what()));
+         out_http_statuses[i] = 500;
+      } catch (...) {
+         out_jsons[i] = duplicate(errorDocument("Internal Server Error", "non recoverable error message"));
+         out_http_statuses[i] = 500;
+      }
+      out_of_memory = out_of_memory || out_jsons[i] == nullptr;
+   }
+   if (out_of_memory) {
+      for (uint32_t i = 0; i < n_queries; ++i) {
+         std::free(out_jsons[i]);
+         out_jsons[i] = nullptr;
+      }
+      return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+   }
+   return 0;
+}
+
 void silo_engine_free_string(char* text) {
    std::free(text);
 }

@@ -72,6 +72,44 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
    return query_result;
 }
 
+std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries) const {
+   Trace::reset();
+   std::vector<BatchOutcome> outcomes(queries.size());
+   std::vector<std::unique_ptr<Query>> parsed(queries.size());
+   std::vector<std::unique_ptr<actions::Action::Pending>> pending(queries.size());
+   actions::ScanBatcher batcher;  // active on this thread until the end of the function
+   for (size_t i = 0; i < queries.size(); ++i) {  // phase 1: parse, compile, evaluate filters, queue scans
+      try {
+         parsed[i] = std::make_unique<Query>(queries[i]);
+         std::vector<OperatorResult> partition_filters(database.partitions.size());
+         for (size_t partition_index = 0; partition_index != database.partitions.size(); partition_index++) {
+            partition_filters[partition_index] =
+               parsed[i]
+                  ->filter->compile(database, database.partitions[partition_index], filter_expressions::Expression::AmbiguityMode::NONE)
+                  ->evaluate();
+         }
+         pending[i] = parsed[i]->action->begin(database, std::move(partition_filters));
+      } catch (...) {
+         outcomes[i].error = std::current_exception();
+      }
+   }
+   Trace::mark("batch_queued");
+   batcher.flush();  // the scans of all queries, several filters per pass over the planes
+   Trace::mark("batch_launched");
+   for (size_t i = 0; i < queries.size(); ++i) {  // phase 2: fetch, build rows, order
+      if (outcomes[i].error != nullptr) {
+         continue;
+      }
+      try {
+         outcomes[i].result = parsed[i]->action->finish(database, *pending[i]);
+      } catch (...) {
+         outcomes[i].error = std::current_exception();
+      }
+   }
+   Trace::mark("batch_done");
+   return outcomes;
+}
+
 json::Value toJson(const QueryResult& query_result) {  // query_result.cpp:10-25
    json::Value rows = json::Value::array();
    for (const auto& entry : query_result.query_result) {

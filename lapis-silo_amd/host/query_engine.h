@@ -408,6 +408,30 @@ struct OrderByField {
    bool ascending;
 };
 
+/// Scans of several queries that read the same planes are collected here and issued as batched launches
+/// (silo_gpu_mutations_scan_batch: one pass over the planes for up to 4 filters).  A batcher is active on a
+/// thread only inside QueryEngine::executeQueries; otherwise every scan is launched at once.
+class ScanBatcher {
+  public:
+   struct Request {
+      silo_gpu_store* store;
+      uint32_t seqstore_id;
+      const uint64_t* filter;  // nullptr = full filter
+      uint32_t pos_begin, pos_end;
+      uint32_t* counts;
+   };
+   ScanBatcher();
+   ~ScanBatcher();
+   ScanBatcher(const ScanBatcher&) = delete;
+   static ScanBatcher* active();
+   void add(const Request& request) { requests.push_back(request); }
+   void flush();
+
+  private:
+   std::vector<Request> requests;
+   ScanBatcher* previous;
+};
+
 class Action {
   protected:
    std::vector<OrderByField> order_by_fields;
@@ -420,9 +444,24 @@ class Action {
    [[nodiscard]] virtual QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const = 0;
 
   public:
+   /// State of an action between its two phases (see begin / finish).
+   struct Pending {
+      virtual ~Pending() = default;
+      std::vector<OperatorResult> bitmap_filter;
+   };
+
    virtual ~Action() = default;
    void setOrdering(const std::vector<OrderByField>& order_by_fields, std::optional<uint32_t> limit, std::optional<uint32_t> offset);
    [[nodiscard]] virtual QueryResult executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const;
+
+   /// Two-phase form of executeAndOrder for batches of queries: begin() validates and queues the device
+   /// work (with a ScanBatcher active the scans are only recorded), finish() fetches the results, builds the
+   /// rows and applies ordering / offset / limit.  The default runs everything in finish().
+   [[nodiscard]] virtual std::unique_ptr<Pending> begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const;
+   [[nodiscard]] virtual QueryResult finish(const Database& database, Pending& pending) const;
+
+  protected:
+   [[nodiscard]] QueryResult orderAndLimit(QueryResult result) const;
 };
 
 /// action.cpp:144-187
@@ -468,7 +507,14 @@ class Mutations : public Action {
    void validateOrderByFields(const Database& database) const override;
    [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
 
+   struct PendingScans : public Action::Pending {
+      std::vector<std::pair<std::string, DeviceBuffer>> in_flight;  // per sequence store, in output order
+   };
+
   public:
+   [[nodiscard]] std::unique_ptr<Action::Pending> begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+   [[nodiscard]] QueryResult finish(const Database& database, Action::Pending& pending) const override;
+
    Mutations(std::vector<std::string>&& sequence_names, double min_proportion)
        : sequence_names(std::move(sequence_names)), min_proportion(min_proportion) {}
 };
@@ -490,6 +536,16 @@ class QueryEngine {
    explicit QueryEngine(const Database& database) : database(database) {}
    virtual ~QueryEngine() = default;
    [[nodiscard]] virtual QueryResult executeQuery(const std::string& query) const;
+
+   /// Outcome of one query of a batch: a result, or the exception it raised (mapped to 400 / 500 by the caller
+   /// exactly as for a single query, silo_api/query_handler.cpp:42-73).
+   struct BatchOutcome {
+      QueryResult result;
+      std::exception_ptr error;
+   };
+   /// Executes a batch of independent queries: filters are evaluated per query, then the Mutations scans of all
+   /// queries that read the same sequence store are issued together, several filters per pass over the planes.
+   [[nodiscard]] std::vector<BatchOutcome> executeQueries(const std::vector<std::string>& queries) const;
 };
 
 }  // namespace query_engine

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_execute_query", "silo_engine_free_string",
+    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
@@ -50,6 +50,7 @@ def load_library():
     lib.silo_engine_set_sharding.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ALL_REDUCE_FN, vp]
     lib.silo_engine_set_broadcast.argtypes = [vp, BROADCAST_FN, vp]
     lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
+    lib.silo_engine_execute_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_free_string.argtypes = [vp]
     lib.silo_engine_free_string.restype = None
     lib.silo_engine_last_timings.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
@@ -232,6 +233,27 @@ class Engine:
         finally:
             self.lib.silo_engine_free_string(out)
         return status.value, body
+
+    def execute_batch_text(self, queries):
+        """One silo_engine_execute_batch call: [(http_status, response body as bytes)] in the order of `queries`."""
+        texts = [q if isinstance(q, (str, bytes)) else json.dumps(q) for q in queries]
+        texts = [t.encode() if isinstance(t, str) else t for t in texts]
+        n = len(texts)
+        array = (ctypes.c_char_p * max(n, 1))(*texts)
+        outs = (ctypes.c_void_p * max(n, 1))()
+        statuses = (ctypes.c_int * max(n, 1))()
+        _check(self.lib.silo_engine_execute_batch(self.handle, array, n, outs, statuses))
+        results = []
+        for i in range(n):
+            try:
+                results.append((statuses[i], ctypes.string_at(outs[i])))
+            finally:
+                self.lib.silo_engine_free_string(outs[i])
+        return results
+
+    def execute_batch(self, queries):
+        """[(http_status, parsed JSON document)] of a batch of queries sharing passes over the planes."""
+        return [(status, json.loads(body.decode())) for status, body in self.execute_batch_text(queries)]
 
     def execute_raw(self, query):
         """Returns (http_status, parsed JSON document)."""

@@ -201,3 +201,36 @@ def test_full_filter_uses_cached_totals_and_matches_scan(engines):
     everything = {"action": query["action"], "filterExpression": {"type": "Or", "children": [
         {"type": "NucleotideEquals", "position": 5, "symbol": "A"}, {"type": "Not", "child": {"type": "NucleotideEquals", "position": 5, "symbol": "A"}}]}}
     assert engine.execute_query(everything) == want
+
+
+def test_batch_equals_individual_queries(engines):
+    """silo_engine_execute_batch: queries whose scans share passes over the planes (K1c) give exactly the
+    documents and statuses of one-by-one execution, in order; a failing query does not disturb the others."""
+    engine, oracle_db = engines
+    rng = random.Random(4242)
+    queries = []
+    for _ in range(30):
+        expression = random_expression(rng, 2)
+        action = rng.choice([
+            {"type": "Aggregated"},
+            {"type": "Mutations", "minProportion": 0.05},
+            {"type": "Mutations", "minProportion": 0.0, "sequenceName": ["main", "testSecondSequence"],
+             "orderByFields": [{"field": "count", "order": "descending"}, "mutation"], "limit": 20},
+            {"type": "AminoAcidMutations", "minProportion": 0.1, "sequenceName": "S"},
+            {"type": "AminoAcidMutations", "minProportion": 0.02},
+        ])
+        queries.append({"action": action, "filterExpression": expression})
+    queries.insert(3, {"action": {"type": "Mutations", "minProportion": 2}, "filterExpression": {"type": "True"}})  # 400
+    queries.insert(7, "{ not json")  # 400
+    queries.insert(11, {"action": {"type": "Mutations", "sequenceName": "nope"}, "filterExpression": {"type": "True"}})  # 400
+    queries.insert(13, {"action": {"type": "Aggregated"}, "filterExpression": {"type": "HasNucleotideMutation", "position": 0}})  # 500
+    queries.insert(17, {"action": {"type": "Mutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}})  # cached totals
+    expected = [engine.execute_raw(q) for q in queries]
+    assert sorted({status for status, _ in expected}) == [200, 400, 500]
+    assert engine.execute_batch(queries) == expected
+    assert engine.execute_batch([]) == []
+    assert engine.execute_batch(queries[:1]) == expected[:1]
+    # and against the oracle for the successful ones
+    for query, (status, document) in zip(queries, engine.execute_batch(queries)):
+        if status == 200:
+            assert document["queryResult"] == json.loads(json.dumps(so.execute_query(oracle_db, query))), json.dumps(query)
