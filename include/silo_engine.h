@@ -78,6 +78,11 @@ int silo_engine_set_sharding(
 typedef int (*silo_engine_broadcast_bytes)(void* context, void* device_bytes, size_t bytes, uint32_t root, void* stream);
 int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes broadcast, void* context);
 
+/* Tunables.  "mutation_row_capacity": Mutations / AminoAcidMutations select their result rows on the device into a
+ * list of this many cells per query (default 4096); a query selecting more fetches the whole count table
+ * and selects on the host; 0 = always the host selection.  Results are identical either way.  Unknown name: error. */
+int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value);
+
 /* Executes one query.  *out_json is malloc'ed (free with silo_engine_free_string) and holds either the
  * result or the error document; *out_http_status is 200, 400 or 500.  Returns 0 unless the arguments
  * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */
@@ -90,7 +95,8 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
  * out_jsons[i] (malloc'ed, free each with silo_engine_free_string) and out_http_statuses[i] per query; one
  * failing query does not affect the others.  Stands where silo_api's request handler (src/silo_api/
  * query_handler.cpp:26-73) would hand several queued requests to the engine at once.  Returns 0 unless the
- * arguments themselves are invalid.  With collectives installed (silo_engine_set_sharding) queries run one by one. */
+ * arguments themselves are invalid.  With collectives installed (silo_engine_set_sharding) every rank must pass the
+ * same batch; the count tables of the batch are all-reduced after its scans were launched, in query order. */
 int silo_engine_execute_batch(
    const silo_engine* engine, const char* const* query_jsons, uint32_t n_queries, char** out_jsons, int* out_http_statuses
 );

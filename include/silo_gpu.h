@@ -134,6 +134,12 @@ void silo_gpu_free(void* dev_ptr);
 int silo_gpu_malloc(size_t bytes, void** out_dev);
 int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream); /* synchronises */
 int silo_gpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream); /* synchronises */
+/* Result tables fetched without stalling the stream: page-locked host memory + a copy that is only enqueued
+ * (wait for it with an event recorded after it, silo_gpu_event_synchronize).  The host mirror fetches the
+ * counts[P][S] table of sequence store k while the scans of stores k+1.. are still running. */
+int silo_gpu_host_alloc(size_t bytes, void** out_host);
+void silo_gpu_host_free(void* host);
+int silo_gpu_memcpy_d2h_async(void* dst_pinned_host, const void* src_dev, size_t bytes, void* stream);
 int silo_gpu_stream_synchronize(void* stream);
 /* A non-blocking HIP stream (does not synchronise with the null stream); every `void* stream` parameter of
  * this ABI accepts one, or NULL for the null stream. */
@@ -201,6 +207,26 @@ int silo_gpu_filter_eval(
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
 int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* shards, accumulated */, void* stream);
 
+/* ---- K4: row selection of Mutations (mutations.cpp:184-232) ------------------------------------------
+ * For every position p < n_positions with total = sum_s counts[p][s] > 0, every symbol index s != reference_index[p]
+ * (0xFF = the reference symbol is not a valid mutation symbol) with
+ *     counts[p][s] > (min_proportion == 0 ? 0 : (uint32_t)(ceil((double)total * min_proportion) - 1))
+ * is appended to the list in out_dev: word 0 = number of selected cells (may exceed `capacity`: then only the
+ * first `capacity` appended rows are stored and the caller falls back to the whole table), words 1-3 unused,
+ * rows from word 4.  Rows are unordered.  out_dev holds 16 + 16 * capacity bytes. */
+typedef struct silo_gpu_mutation_row {
+   uint32_t position;     /* 0-based, relative to counts_dev */
+   uint32_t symbol_index; /* index into the sequence store's valid mutation symbols */
+   uint32_t count;
+   uint32_t total;
+} silo_gpu_mutation_row;
+int silo_gpu_mutations_select(
+   const uint32_t* counts_dev, const uint8_t* reference_index_dev, uint32_t n_positions, uint32_t n_symbols, double min_proportion,
+   uint32_t capacity, uint32_t* out_dev, void* stream
+);
+/* Plain byte upload into a fresh device allocation (free with silo_gpu_free). */
+int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev);
+
 /* ---- K1: Mutations scan (mutations.cpp:64-164) ---------------------------------------------------
  * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & plane[p][scan_symbols[s]])
  * for p in [pos_begin, pos_end).  The buffer is ACCUMULATED into (the reference sums partitions into
@@ -230,6 +256,7 @@ int silo_gpu_tune(int knob, int value);
  * (bench.py measures the roofline numbers with these, on the stream the kernels are launched on). */
 int silo_gpu_event_create(void** out_event);
 int silo_gpu_event_record(void* event, void* stream);
+int silo_gpu_event_synchronize(void* event); /* blocks the calling thread until the event has happened */
 int silo_gpu_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop */
 void silo_gpu_event_destroy(void* event);
 

@@ -762,6 +762,50 @@ __global__ void k_add_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict
    }
 }
 
+// K4: the row selection of Mutations::addMutationsToOutput (mutations.cpp:184-232) on the device: one thread per
+// position sums its valid-symbol counts, applies the reference's threshold ceil(total * minProportion) - 1 in
+// IEEE double exactly as the host code does, and appends the surviving (position, symbol) cells to a compact
+// list.  The list is unordered (the host sorts a few hundred rows); past `capacity` only the counter advances.
+__global__ __launch_bounds__(256) void k_mutations_select(
+   const uint32_t* __restrict__ counts, const uint8_t* __restrict__ reference_index, uint32_t n_positions, uint32_t n_symbols,
+   double min_proportion, uint32_t capacity, uint32_t* __restrict__ out
+) {
+   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+   if (pos >= n_positions) {
+      return;
+   }
+   const uint32_t* at_position = counts + static_cast<size_t>(pos) * n_symbols;
+   uint32_t total = 0;
+   for (uint32_t s = 0; s < n_symbols; ++s) {
+      total += at_position[s];
+   }
+   if (total == 0) {
+      return;
+   }
+   const uint32_t threshold_count =
+      min_proportion == 0 ? 0u : static_cast<uint32_t>(ceil(static_cast<double>(total) * min_proportion) - 1);
+   const uint32_t reference = reference_index[pos];
+   uint32_t selected = 0;  // bit s: symbol s passes
+   for (uint32_t s = 0; s < n_symbols; ++s) {
+      if (s != reference && at_position[s] > threshold_count) {
+         selected |= 1u << s;
+      }
+   }
+   if (selected == 0) {
+      return;
+   }
+   uint32_t slot = atomicAdd(&out[0], static_cast<uint32_t>(__popc(selected)));
+   auto* rows = reinterpret_cast<silo_gpu_mutation_row*>(out + 4);
+   for (uint32_t s = 0; s < n_symbols; ++s) {
+      if ((selected >> s) & 1u) {
+         if (slot < capacity) {
+            rows[slot] = silo_gpu_mutation_row{pos, s, at_position[s], total};
+         }
+         ++slot;
+      }
+   }
+}
+
 __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence_count) {
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
    if (w < row_words) {
@@ -1360,6 +1404,28 @@ int silo_gpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void*
    return SILO_GPU_OK;
 }
 
+int silo_gpu_host_alloc(size_t bytes, void** out_host) {
+   if (out_host == nullptr || bytes == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_host_alloc: bad arguments");
+   }
+   HIP_TRY(hipHostMalloc(out_host, bytes, hipHostMallocDefault));
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_host_free(void* host) {
+   if (host != nullptr) {
+      (void)hipHostFree(host);
+   }
+}
+
+int silo_gpu_memcpy_d2h_async(void* dst_pinned_host, const void* src_dev, size_t bytes, void* stream) {
+   if (dst_pinned_host == nullptr || src_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_memcpy_d2h_async: null pointer");
+   }
+   HIP_TRY(hipMemcpyAsync(dst_pinned_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+   return SILO_GPU_OK;
+}
+
 int silo_gpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
@@ -1373,6 +1439,11 @@ int silo_gpu_event_create(void** out_event) {
    hipEvent_t event = nullptr;
    HIP_TRY(hipEventCreate(&event));
    *out_event = event;
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_event_synchronize(void* event) {
+   HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
    return SILO_GPU_OK;
 }
 
@@ -1730,6 +1801,39 @@ int silo_gpu_mutations_scan(
    }
    HIP_TRY(hipGetLastError());
    g_last_scan_kernel = "k_scan_tiled";
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_mutations_select(
+   const uint32_t* counts_dev, const uint8_t* reference_index_dev, uint32_t n_positions, uint32_t n_symbols, double min_proportion,
+   uint32_t capacity, uint32_t* out_dev, void* stream
+) {
+   if (counts_dev == nullptr || reference_index_dev == nullptr || out_dev == nullptr || n_symbols == 0 || n_symbols > 32) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_select: bad arguments");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   HIP_TRY(hipMemsetAsync(out_dev, 0, 4 * sizeof(uint32_t), hip_stream));
+   if (n_positions != 0) {
+      k_mutations_select<<<(n_positions + 255) / 256, 256, 0, hip_stream>>>(
+         counts_dev, reference_index_dev, n_positions, n_symbols, min_proportion, capacity, out_dev
+      );
+      HIP_TRY(hipGetLastError());
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev) {
+   if (src_host == nullptr || out_dev == nullptr || bytes == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_upload_bytes: bad arguments");
+   }
+   void* dev = nullptr;
+   HIP_TRY(hipMalloc(&dev, bytes));
+   const hipError_t status = hipMemcpy(dev, src_host, bytes, hipMemcpyHostToDevice);
+   if (status != hipSuccess) {
+      (void)hipFree(dev);
+      HIP_TRY(status);
+   }
+   *out_dev = dev;
    return SILO_GPU_OK;
 }
 

@@ -82,6 +82,20 @@ QueryResult Action::finish(const Database& database, Pending& pending) const {
 
 // ---- ScanBatcher ---------------------------------------------------------------------------------
 namespace {
+
+/// Sums `n` uint32 across ranks in place on the device (no-op for a single rank).
+void allReduce(const Database& database, uint32_t* device_values, size_t n) {
+   if (database.all_reduce != nullptr) {  // also with a single rank: lets a 1-GPU box exercise the collective path
+      const int status = database.all_reduce(database.all_reduce_context, device_values, n, queryStream());
+      if (status != 0) {
+         throw DeviceException("all-reduce of counts failed with status " + std::to_string(status));
+      }
+   }
+}
+
+}  // namespace
+
+namespace {
 thread_local ScanBatcher* g_active_batcher = nullptr;
 }
 
@@ -135,21 +149,15 @@ void ScanBatcher::flush() {
       }
    }
    requests.clear();
-}
-
-namespace {
-
-/// Sums `n` uint32 across ranks in place on the device (no-op for a single rank).
-void allReduce(const Database& database, uint32_t* device_values, size_t n) {
-   if (database.all_reduce != nullptr) {  // also with a single rank: lets a 1-GPU box exercise the collective path
-      const int status = database.all_reduce(database.all_reduce_context, device_values, n, queryStream());
-      if (status != 0) {
-         throw DeviceException("all-reduce of counts failed with status " + std::to_string(status));
-      }
+   for (const Reduction& reduction : reductions) {
+      allReduce(*reduction.database, reduction.device_values, reduction.n);
    }
+   reductions.clear();
+   for (const auto& callback : after_flush) {
+      callback();
+   }
+   after_flush.clear();
 }
-
-}  // namespace
 
 // ---- Aggregated (aggregated.cpp:58-96; group-by is outside the hot path) -----------------------------
 void Aggregated::validateOrderByFields(const Database& /*database*/) const {
@@ -205,28 +213,20 @@ std::map<std::string, typename Mutations<SymbolType>::PrefilteredBitmaps> Mutati
 }
 
 template <typename SymbolType>
-DeviceBuffer Mutations<SymbolType>::calculateMutationsPerPosition(
-   const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
+void Mutations<SymbolType>::calculateMutationsPerPosition(
+   const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter, uint32_t* device_counts
 ) {
    // mutations.cpp:139-164 runs and_cardinality(filter, column) per position x symbol under
    // tbb::parallel_for; here each (partition, sequence store) is ONE scan kernel (K1) that accumulates
    // into a single device table, exactly as the reference sums partitions into one table (:71,:108).
    const auto sequence_length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
    constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
-   const size_t n_counts = static_cast<size_t>(sequence_length) * n_symbols;
-   if (database.partitions.empty() || n_counts == 0) {
-      return {};
-   }
    // position-range shard of this rank; [0, P) when not sharded by position
    const auto [pos_begin, pos_end] = database.positionWindow(sequence_length);
-   const DatabasePartition& home = database.partitions.front();
-   DeviceBuffer device_counts = home.pool.acquire(n_counts * sizeof(uint32_t));
-   checkGpu(silo_gpu_memset_async(device_counts.get(), 0, n_counts * sizeof(uint32_t), queryStream()), "silo_gpu_memset_async");
-   uint32_t* window = device_counts.as<uint32_t>() + static_cast<size_t>(pos_begin) * n_symbols;
+   uint32_t* window = device_counts + static_cast<size_t>(pos_begin) * n_symbols;
    // the device store of a rank holds exactly its window: local positions [0, pos_end - pos_begin)
    const uint32_t local_positions = pos_end - pos_begin;
-   // inside a batch of queries the scans are only recorded; collectives need their scan right away
-   ScanBatcher* batcher = database.all_reduce == nullptr ? ScanBatcher::active() : nullptr;
+   ScanBatcher* batcher = ScanBatcher::active();  // inside a batch of queries the scans are only recorded
    const auto scan = [&](const SequenceStorePartition<SymbolType>& store, const uint64_t* filter) {
       if (batcher != nullptr) {
          batcher->add({store.store, store.seqstore_id, filter, 0, local_positions, window});
@@ -243,9 +243,6 @@ DeviceBuffer Mutations<SymbolType>::calculateMutationsPerPosition(
       // full filter: the reference reads plain cardinalities (mutations.cpp:98-136); NULL = all rows
       scan(store, nullptr);
    }
-   Trace::mark("scan_launched");
-   allReduce(database, device_counts.as<uint32_t>(), n_counts);
-   return device_counts;  // still in flight: execute() launches every sequence store before it fetches any
 }
 
 template <typename SymbolType>
@@ -261,24 +258,13 @@ void Mutations<SymbolType>::validateOrderByFields(const Database& /*database*/) 
 
 template <typename SymbolType>
 void Mutations<SymbolType>::addMutationsToOutput(
-   const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const DeviceBuffer& device_counts,
+   const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const uint32_t* counts,
    std::vector<QueryResultEntry>& output
 ) const {  // mutations.cpp:184-232
    const size_t sequence_length = sequence_store.reference_sequence.size();
    constexpr size_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
-   std::vector<uint32_t> count_of_mutations_per_position(sequence_length * n_symbols, 0);
-   if (device_counts) {
-      checkGpu(
-         silo_gpu_memcpy_d2h(
-            count_of_mutations_per_position.data(), device_counts.get(), count_of_mutations_per_position.size() * sizeof(uint32_t), queryStream()
-         ),
-         "silo_gpu_memcpy_d2h"
-      );
-   }
-   Trace::mark("counts_on_host");
-
    for (size_t pos = 0; pos < sequence_length; ++pos) {
-      const uint32_t* counts_at_position = count_of_mutations_per_position.data() + pos * n_symbols;
+      const uint32_t* counts_at_position = counts + pos * n_symbols;
       uint32_t total = 0;
       for (size_t s = 0; s < n_symbols; ++s) {
          total += counts_at_position[s];
@@ -312,71 +298,169 @@ void Mutations<SymbolType>::addMutationsToOutput(
 }
 
 template <typename SymbolType>
+void Mutations<SymbolType>::addSelectedRowToOutput(
+   const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, uint32_t position, const silo_gpu_mutation_row& row,
+   std::vector<QueryResultEntry>& output
+) const {  // the four fields of mutations.cpp:213-224 for a cell that k_mutations_select let through
+   const typename SymbolType::Symbol symbol_in_reference_genome = sequence_store.reference_sequence.at(position);
+   const auto symbol = SymbolType::VALID_MUTATION_SYMBOLS.at(row.symbol_index);
+   const double proportion = static_cast<double>(row.count) / static_cast<double>(row.total);
+   QueryResultEntry& entry = output.emplace_back();
+   entry.fields.emplace_hint(entry.fields.end(), COUNT_FIELD_NAME, static_cast<int32_t>(row.count));
+   entry.fields.emplace_hint(
+      entry.fields.end(), MUTATION_FIELD_NAME,
+      SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(position + 1) + SymbolType::symbolToChar(symbol)
+   );
+   entry.fields.emplace_hint(entry.fields.end(), PROPORTION_FIELD_NAME, proportion);
+   entry.fields.emplace_hint(entry.fields.end(), SEQUENCE_FIELD_NAME, sequence_name);
+}
+
+template <typename SymbolType>
 std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const {
    // first half of mutations.cpp:234-272: validate, pre-filter, queue the scans of every requested store
    validateOrderByFields(database);
-   std::vector<std::string> sequence_names_to_evaluate;
+   auto pending = std::make_unique<PendingScans>();
    for (const auto& sequence_name : sequence_names) {
       CHECK_SILO_QUERY(
          database.getSequenceStores<SymbolType>().count(sequence_name) != 0,
          "Database does not contain the " + std::string(SymbolType::SYMBOL_NAME_LOWER_CASE) + " sequence with name: '" + sequence_name + "'"
       )
-      sequence_names_to_evaluate.emplace_back(sequence_name);
+      pending->sequence_names.emplace_back(sequence_name);
    }
    if (sequence_names.empty()) {
       for (const auto& [sequence_name, _] : database.getSequenceStores<SymbolType>()) {
-         sequence_names_to_evaluate.emplace_back(sequence_name);
+         pending->sequence_names.emplace_back(sequence_name);
       }
    }
-   auto pending = std::make_unique<PendingScans>();
    pending->bitmap_filter = std::move(bitmap_filter);  // the scans read these bitsets: they live as long as the scans
    std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate = preFilterBitmaps(database, pending->bitmap_filter);
    Trace::mark("filter_materialized");
 
-   // Queue the scans of every requested sequence store first (they run in order on this thread's stream), then
-   // finish() fetches and post-processes them: the device works on store k+1 while the host builds the rows of
-   // store k — and inside a batch of queries the scans of different queries share passes over the planes.
+   // ONE count table for the query, all stores of the alphabet back to back (MutationTableLayout): one memset,
+   // the scans of every requested store (in order on this thread's stream — or, inside a batch of queries, recorded
+   // so that scans of different queries share passes over the planes), one all-reduce when sharded, one row
+   // selection on the device and one transfer; finish() only waits for that transfer.
    const bool sharded = database.shard_world > 1 && database.all_reduce != nullptr;
+   const MutationTableLayout& layout = database.getMutationTableLayout<SymbolType>();
+   constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
+   const size_t n_counts = static_cast<size_t>(layout.total_positions) * n_symbols;
+   if (database.partitions.empty() || n_counts == 0 || pending->sequence_names.empty() || (bitmaps_to_evaluate.empty() && !sharded)) {
+      return pending;  // nothing selected (and no other rank to contribute): no rows
+   }
+   pending->table_bytes = (n_counts * sizeof(uint32_t) + 15) / 16 * 16;
+   pending->row_capacity = layout.reference_index_device != nullptr ? database.mutation_row_capacity : 0;
+   const size_t list_bytes = 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(pending->row_capacity);
+   pending->device_table = database.partitions.front().pool.acquire(pending->table_bytes + list_bytes);
+   auto* device_counts = static_cast<uint32_t*>(pending->device_table.get());
+   checkGpu(silo_gpu_memset_async(device_counts, 0, pending->table_bytes, queryStream()), "silo_gpu_memset_async");
+
    const PrefilteredBitmaps no_bitmaps{};
-   for (const auto& sequence_name : sequence_names_to_evaluate) {
-      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-      if (bitmaps_to_evaluate.count(sequence_name) != 0) {
-         pending->in_flight.emplace_back(sequence_name, calculateMutationsPerPosition(database, sequence_store, bitmaps_to_evaluate.at(sequence_name)));
-      } else if (sharded) {
-         // this rank's filter is empty but other ranks may contribute: take part in the collective
-         pending->in_flight.emplace_back(sequence_name, calculateMutationsPerPosition(database, sequence_store, no_bitmaps));
+   std::vector<std::string> scanned;  // a store requested twice is scanned once
+   for (const auto& sequence_name : pending->sequence_names) {
+      if (std::find(scanned.begin(), scanned.end(), sequence_name) != scanned.end()) {
+         continue;
       }
+      scanned.push_back(sequence_name);
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+      const auto found = bitmaps_to_evaluate.find(sequence_name);
+      calculateMutationsPerPosition(
+         database, sequence_store, found != bitmaps_to_evaluate.end() ? found->second : no_bitmaps,
+         device_counts + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols
+      );
+   }
+   Trace::mark("scan_launched");
+
+   PendingScans& scans = *pending;
+   const uint8_t* reference_index = layout.reference_index_device.get();
+   const uint32_t total_positions = layout.total_positions;
+   const double proportion = min_proportion;
+   const auto select_and_fetch = [&scans, device_counts, reference_index, total_positions, proportion]() {
+      if (scans.row_capacity == 0) {
+         scans.fetch = HostFetch(device_counts, scans.table_bytes, queryStream());
+         return;
+      }
+      // K4 picks the rows on the device (threshold arithmetic of mutations.cpp:197-211); only they travel
+      auto* list = reinterpret_cast<uint32_t*>(static_cast<char*>(scans.device_table.get()) + scans.table_bytes);
+      checkGpu(
+         silo_gpu_mutations_select(device_counts, reference_index, total_positions, n_symbols, proportion, scans.row_capacity, list, queryStream()),
+         "silo_gpu_mutations_select"
+      );
+      scans.fetch = HostFetch(list, 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(scans.row_capacity), queryStream());
+   };
+   if (ScanBatcher* batcher = ScanBatcher::active(); batcher != nullptr) {
+      if (database.all_reduce != nullptr) {
+         batcher->addReduction(database, device_counts, n_counts);
+      }
+      batcher->afterFlush(select_and_fetch);  // the scans are only recorded so far
+   } else {
+      allReduce(database, device_counts, n_counts);  // the whole query in one collective
+      select_and_fetch();
    }
    return pending;
 }
 
 template <typename SymbolType>
-QueryResult Mutations<SymbolType>::finish(const Database& database, Action::Pending& pending) const {
-   auto& scans = dynamic_cast<PendingScans&>(pending);
+QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScans& scans) const {
    std::vector<QueryResultEntry> mutation_proportions;
-   for (const auto& [sequence_name, device_counts] : scans.in_flight) {
-      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-      addMutationsToOutput(sequence_name, sequence_store, device_counts, mutation_proportions);
+   if (!scans.fetch) {
+      return QueryResult{std::move(mutation_proportions)};
+   }
+   const MutationTableLayout& layout = database.getMutationTableLayout<SymbolType>();
+   constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
+   const auto* words = static_cast<const uint32_t*>(scans.fetch.wait());
+   Trace::mark("counts_on_host");
+   HostFetch whole_table;
+   const uint32_t* table = nullptr;
+   if (scans.row_capacity == 0) {
+      table = words;
+   } else if (words[0] > scans.row_capacity) {  // more rows than the list holds: take the whole table after all
+      whole_table = HostFetch(scans.device_table.get(), scans.table_bytes, queryStream());
+      table = static_cast<const uint32_t*>(whole_table.wait());
+   }
+   if (table != nullptr) {
+      for (const auto& sequence_name : scans.sequence_names) {
+         const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+         addMutationsToOutput(
+            sequence_name, sequence_store, table + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols, mutation_proportions
+         );
+      }
+   } else {
+      // the device appends in no particular order; the reference emits stores in request order, positions
+      // ascending, symbols in VALID_MUTATION_SYMBOLS order (mutations.cpp:190-229, 259-268)
+      const auto* rows = reinterpret_cast<const silo_gpu_mutation_row*>(words + 4);
+      std::vector<silo_gpu_mutation_row> sorted(rows, rows + words[0]);
+      const auto before = [](const silo_gpu_mutation_row& a, const silo_gpu_mutation_row& b) {
+         return a.position != b.position ? a.position < b.position : a.symbol_index < b.symbol_index;
+      };
+      std::sort(sorted.begin(), sorted.end(), before);
+      mutation_proportions.reserve(sorted.size());
+      for (const auto& sequence_name : scans.sequence_names) {
+         const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+         const uint32_t offset = layout.position_offset.at(sequence_name);
+         const auto length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
+         auto row = std::lower_bound(sorted.begin(), sorted.end(), silo_gpu_mutation_row{offset, 0, 0, 0}, before);
+         for (; row != sorted.end() && row->position < offset + length; ++row) {
+            addSelectedRowToOutput(sequence_name, sequence_store, row->position - offset, *row, mutation_proportions);
+         }
+      }
    }
    Trace::mark("rows_built");
-   return orderAndLimit({mutation_proportions});
+   return QueryResult{std::move(mutation_proportions)};
+}
+
+template <typename SymbolType>
+QueryResult Mutations<SymbolType>::finish(const Database& database, Action::Pending& pending) const {
+   return orderAndLimit(collect(database, dynamic_cast<PendingScans&>(pending)));
 }
 
 template <typename SymbolType>
 QueryResult Mutations<SymbolType>::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // mutations.cpp:234-272
    // unordered result of the two phases run back to back (executeAndOrder applies the ordering)
    auto pending = begin(database, std::move(bitmap_filter));
-   auto& scans = dynamic_cast<PendingScans&>(*pending);
    if (ScanBatcher* batcher = ScanBatcher::active(); batcher != nullptr) {
       batcher->flush();
    }
-   std::vector<QueryResultEntry> mutation_proportions;
-   for (const auto& [sequence_name, device_counts] : scans.in_flight) {
-      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-      addMutationsToOutput(sequence_name, sequence_store, device_counts, mutation_proportions);
-   }
-   Trace::mark("rows_built");
-   return {mutation_proportions};
+   return collect(database, dynamic_cast<PendingScans&>(*pending));
 }
 
 template class Mutations<Nucleotide>;

@@ -249,6 +249,17 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
    return 0;
 }
 
+int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value) {
+   if (engine == nullptr || name == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_option: null argument");
+   }
+   if (std::strcmp(name, "mutation_row_capacity") == 0 && value >= 0 && value <= (1 << 24)) {
+      engine->database.mutation_row_capacity = static_cast<uint32_t>(value);
+      return 0;
+   }
+   return fail(SILO_GPU_ERR_INVALID_ARGUMENT, std::string("silo_engine_set_option: unknown option or bad value: ") + name);
+}
+
 int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status) {
    if (engine == nullptr || query_json == nullptr || out_json == nullptr || out_http_status == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_execute_query: null argument");
@@ -256,7 +267,8 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
    // the exception -> HTTP mapping of src/silo_api/query_handler.cpp:42-73
    try {
       const auto query_result = engine->database.executeQuery(query_json);
-      *out_json = duplicate(silo::query_engine::toJson(query_result).dump());
+      *out_json = duplicate(silo::query_engine::toJsonText(query_result));
+      silo::Trace::mark("serialized");
       *out_http_status = 200;
    } catch (const silo::QueryParseException& ex) {
       *out_json = duplicate(errorDocument("Bad request", ex.what()));
@@ -301,7 +313,7 @@ int silo_engine_execute_batch(const silo_engine* engine, const char* const* quer
          if (error != nullptr) {
             std::rethrow_exception(error);
          }
-         out_jsons[i] = duplicate(silo::query_engine::toJson(outcomes[i].result).dump());
+         out_jsons[i] = duplicate(silo::query_engine::toJsonText(outcomes[i].result));
          out_http_statuses[i] = 200;
       } catch (const silo::QueryParseException& ex) {
          out_jsons[i] = duplicate(errorDocument("Bad request", ex.what()));

@@ -132,6 +132,73 @@ void DevicePool::release(void* ptr, size_t bytes) {
    free_.emplace(bytes, ptr);
 }
 
+// ---- HostFetch ---------------------------------------------------------------------------------
+namespace {
+struct StagingSlot {
+   void* host;
+   void* event;
+};
+// never destroyed: threads may still return slots while the process is shutting down
+std::mutex& stagingMutex() {
+   static auto* mutex = new std::mutex;
+   return *mutex;
+}
+std::multimap<size_t, StagingSlot>& stagingFree() {
+   static auto* slots = new std::multimap<size_t, StagingSlot>;
+   return *slots;
+}
+}  // namespace
+
+HostFetch::HostFetch(const void* device_source, size_t bytes, void* stream) {
+   capacity_ = 64u << 10;
+   while (capacity_ < bytes) {
+      capacity_ <<= 1;
+   }
+   {
+      const std::lock_guard<std::mutex> lock(stagingMutex());
+      const auto found = stagingFree().find(capacity_);
+      if (found != stagingFree().end()) {
+         host_ = found->second.host;
+         event_ = found->second.event;
+         stagingFree().erase(found);
+      }
+   }
+   if (host_ == nullptr) {
+      checkGpu(silo_gpu_host_alloc(capacity_, &host_), "silo_gpu_host_alloc");
+      checkGpu(silo_gpu_event_create(&event_), "silo_gpu_event_create");
+   }
+   checkGpu(silo_gpu_memcpy_d2h_async(host_, device_source, bytes, stream), "silo_gpu_memcpy_d2h_async");
+   checkGpu(silo_gpu_event_record(event_, stream), "silo_gpu_event_record");
+}
+
+HostFetch& HostFetch::operator=(HostFetch&& other) noexcept {
+   if (this != &other) {
+      this->~HostFetch();
+      host_ = other.host_;
+      event_ = other.event_;
+      capacity_ = other.capacity_;
+      other.host_ = nullptr;
+      other.event_ = nullptr;
+      other.capacity_ = 0;
+   }
+   return *this;
+}
+
+HostFetch::~HostFetch() {
+   if (host_ != nullptr) {
+      // the copy may still be in flight (an exception unwound the query): wait before the buffer is reused
+      (void)silo_gpu_event_synchronize(event_);
+      const std::lock_guard<std::mutex> lock(stagingMutex());
+      stagingFree().emplace(capacity_, StagingSlot{host_, event_});
+      host_ = nullptr;
+   }
+}
+
+const void* HostFetch::wait() const {
+   checkGpu(silo_gpu_event_synchronize(event_), "silo_gpu_event_synchronize");
+   return host_;
+}
+
 // ---- pango lineage aliases (pango_lineage_alias.cpp:21-41, 88-102) -------------------------------
 PangoLineageAliasLookup PangoLineageAliasLookup::fromJson(const json::Value& json) {
    std::unordered_map<std::string, std::vector<std::string>> alias_keys;
@@ -406,7 +473,39 @@ DatabasePartition& Database::addPartition(uint32_t sequence_count) {
    return partition;
 }
 
+namespace {
+template <typename SymbolType>
+MutationTableLayout makeMutationTableLayout(const std::map<std::string, SequenceStore<SymbolType>>& stores, bool upload) {
+   MutationTableLayout layout;
+   std::vector<uint8_t> index;
+   for (const auto& [name, store] : stores) {
+      layout.position_offset[name] = layout.total_positions;
+      layout.total_positions += static_cast<uint32_t>(store.reference_sequence.size());
+      for (const auto reference_symbol : store.reference_sequence) {
+         uint8_t found = 0xFF;
+         for (size_t s = 0; s < SymbolType::VALID_MUTATION_SYMBOLS.size(); ++s) {
+            if (SymbolType::VALID_MUTATION_SYMBOLS[s] == reference_symbol) {
+               found = static_cast<uint8_t>(s);
+            }
+         }
+         index.push_back(found);
+      }
+   }
+   if (upload && !index.empty()) {
+      void* device = nullptr;
+      checkGpu(silo_gpu_upload_bytes(index.data(), index.size(), &device), "silo_gpu_upload_bytes");
+      layout.reference_index_device = std::shared_ptr<const uint8_t>(static_cast<const uint8_t*>(device), [](const uint8_t* ptr) {
+         silo_gpu_free(const_cast<uint8_t*>(ptr));
+      });
+   }
+   return layout;
+}
+}  // namespace
+
 void Database::finalize() {
+   const bool device_in_use = !partitions.empty();
+   nuc_mutation_layout = makeMutationTableLayout(nuc_sequences, device_in_use);
+   aa_mutation_layout = makeMutationTableLayout(aa_sequences, device_in_use);
    for (auto& partition : partitions) {
       checkGpu(silo_gpu_store_finalize(partition.store), "silo_gpu_store_finalize");
       for (auto& [name, column] : partition.columns.pango_lineage_columns) {

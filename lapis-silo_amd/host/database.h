@@ -92,6 +92,28 @@ class DevicePool {
    std::multimap<size_t, void*> free_;
 };
 
+/// A device -> host transfer in flight: a page-locked host buffer and the event recorded after the copy.
+/// Buffers and events are recycled through a process-wide free list (hipHostMalloc / hipEventCreate are slow).
+class HostFetch {
+  public:
+   HostFetch() = default;
+   /// Enqueues the copy of `bytes` from `device_source` on `stream` and records the completion event.
+   HostFetch(const void* device_source, size_t bytes, void* stream);
+   HostFetch(HostFetch&& other) noexcept { *this = std::move(other); }
+   HostFetch& operator=(HostFetch&& other) noexcept;
+   HostFetch(const HostFetch&) = delete;
+   HostFetch& operator=(const HostFetch&) = delete;
+   ~HostFetch();
+   /// Blocks until the copy has landed; the data stays valid as long as this object lives.
+   [[nodiscard]] const void* wait() const;
+   explicit operator bool() const { return host_ != nullptr; }
+
+  private:
+   void* host_ = nullptr;
+   void* event_ = nullptr;
+   size_t capacity_ = 0;
+};
+
 class PangoLineageAliasLookup {
   public:
    PangoLineageAliasLookup() = default;
@@ -149,6 +171,17 @@ template <typename SymbolType>
 class SequenceStore {
   public:
    std::vector<typename SymbolType::Symbol> reference_sequence;
+};
+
+/// Layout of the count table of a Mutations query: the stores of one alphabet back to back in name order,
+/// counts[(offset(store) + position) * n_valid_symbols + symbol].  One table per query means one memset, one
+/// all-reduce, one row selection (k_mutations_select) and one transfer however many stores are scanned.
+struct MutationTableLayout {
+   std::map<std::string, uint32_t> position_offset;
+   uint32_t total_positions = 0;
+   /// Per table position the index of the reference symbol within VALID_MUTATION_SYMBOLS (0xFF: not among them),
+   /// on the device; uploaded by Database::finalize.
+   std::shared_ptr<const uint8_t> reference_index_device;
 };
 
 template <typename SymbolType>
@@ -244,6 +277,9 @@ class Database {
    uint32_t shard_rank = 0;
    uint32_t shard_world = 1;
    bool shard_by_position = false;
+   /// Mutations selects its result rows on the device into a list of this many cells; a query that selects more
+   /// (minProportion 0 over a large filter) fetches the whole count table instead. 0 = always fetch the table.
+   uint32_t mutation_row_capacity = 4096;
    AllReduceU32 all_reduce = nullptr;
    void* all_reduce_context = nullptr;
    BroadcastBytes broadcast = nullptr;
@@ -261,6 +297,10 @@ class Database {
 
    template <typename SymbolType>
    [[nodiscard]] const std::map<std::string, SequenceStore<SymbolType>>& getSequenceStores() const;
+   MutationTableLayout nuc_mutation_layout;
+   MutationTableLayout aa_mutation_layout;
+   template <typename SymbolType>
+   [[nodiscard]] const MutationTableLayout& getMutationTableLayout() const;
 
    /// database.cpp:710-714
    [[nodiscard]] virtual query_engine::QueryResult executeQuery(const std::string& query) const;
@@ -289,6 +329,15 @@ inline const std::map<std::string, SequenceStore<Nucleotide>>& Database::getSequ
 template <>
 inline const std::map<std::string, SequenceStore<AminoAcid>>& Database::getSequenceStores<AminoAcid>() const {
    return aa_sequences;
+}
+
+template <>
+inline const MutationTableLayout& Database::getMutationTableLayout<Nucleotide>() const {
+   return nuc_mutation_layout;
+}
+template <>
+inline const MutationTableLayout& Database::getMutationTableLayout<AminoAcid>() const {
+   return aa_mutation_layout;
 }
 
 }  // namespace silo

@@ -102,6 +102,25 @@ class Value {
       return out;
    }
 
+   /// Serialisation primitives, also used by writers that do not build a Value tree first.
+   static void appendString(std::string& out, const std::string& text) { writeString(out, text); }
+   static void appendDouble(std::string& out, double value) {
+      if (!std::isfinite(value)) {
+         out += "null";  // nlohmann dumps non-finite numbers as null
+         return;
+      }
+      char buffer[40];
+      const auto result = std::to_chars(buffer, buffer + sizeof(buffer), value);
+      bool integral = true;
+      for (const char* c = buffer; c != result.ptr; ++c) {
+         integral = integral && *c != '.' && *c != 'e' && *c != 'E';
+      }
+      out.append(buffer, result.ptr);
+      if (integral) {
+         out += ".0";
+      }
+   }
+
   private:
    Kind kind_ = Kind::Null;
    bool bool_ = false;
@@ -143,17 +162,7 @@ class Value {
          case Kind::Unsigned: out += std::to_string(uint_); break;
          case Kind::Integer: out += std::to_string(int_); break;
          case Kind::Float: {
-            if (!std::isfinite(double_)) {
-               out += "null";  // nlohmann dumps non-finite numbers as null
-               break;
-            }
-            char buffer[40];
-            const auto result = std::to_chars(buffer, buffer + sizeof(buffer), double_);
-            std::string text(buffer, result.ptr);
-            if (text.find_first_of(".eE") == std::string::npos) {
-               text += ".0";
-            }
-            out += text;
+            appendDouble(out, double_);
             break;
          }
          case Kind::String: writeString(out, string_); break;

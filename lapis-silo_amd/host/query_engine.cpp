@@ -132,4 +132,41 @@ json::Value toJson(const QueryResult& query_result) {  // query_result.cpp:10-25
    return out;
 }
 
+std::string toJsonText(const QueryResult& query_result) {
+   // same bytes as toJson(query_result).dump(), written straight from the rows (a Mutations response has
+   // hundreds of rows; the Value tree costs more than the text)
+   std::string out;
+   out.reserve(32 + query_result.query_result.size() * 96);
+   out += "{\"queryResult\":[";
+   bool first_row = true;
+   for (const auto& entry : query_result.query_result) {
+      if (!first_row) {
+         out.push_back(',');
+      }
+      first_row = false;
+      out.push_back('{');
+      bool first_field = true;
+      for (const auto& [field, value] : entry.fields) {
+         if (!first_field) {
+            out.push_back(',');
+         }
+         first_field = false;
+         json::Value::appendString(out, field);
+         out.push_back(':');
+         if (!value.has_value()) {
+            out += "null";
+         } else if (std::holds_alternative<std::string>(*value)) {
+            json::Value::appendString(out, std::get<std::string>(*value));
+         } else if (std::holds_alternative<int32_t>(*value)) {
+            out += std::to_string(std::get<int32_t>(*value));
+         } else {
+            json::Value::appendDouble(out, std::get<double>(*value));
+         }
+      }
+      out.push_back('}');
+   }
+   out += "]}";
+   return out;
+}
+
 }  // namespace silo::query_engine

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -53,6 +54,8 @@ struct QueryResult {
 };
 
 json::Value toJson(const QueryResult& query_result);  // {"queryResult": [...]}
+/// The same document as text, without the intermediate tree.
+std::string toJsonText(const QueryResult& query_result);
 
 /// The rows an operator ranges over: the reference passes a bare `row_count`; here it also names
 /// the device shard that holds those rows.
@@ -425,10 +428,22 @@ class ScanBatcher {
    ScanBatcher(const ScanBatcher&) = delete;
    static ScanBatcher* active();
    void add(const Request& request) { requests.push_back(request); }
+   /// With collectives installed: sum `n` counts across ranks after the scans of the batch were launched
+   /// (every rank runs the same batch, so the reductions pair up in recording order).
+   void addReduction(const Database& database, uint32_t* device_values, size_t n) { reductions.push_back({&database, device_values, n}); }
+   /// Work that has to follow the launches (and reductions) of the batch on the stream, e.g. fetching the results.
+   void afterFlush(std::function<void()> callback) { after_flush.push_back(std::move(callback)); }
    void flush();
 
   private:
+   struct Reduction {
+      const Database* database;
+      uint32_t* device_values;
+      size_t n;
+   };
    std::vector<Request> requests;
+   std::vector<Reduction> reductions;
+   std::vector<std::function<void()>> after_flush;
    ScanBatcher* previous;
 };
 
@@ -493,23 +508,37 @@ class Mutations : public Action {
 
    static std::map<std::string, PrefilteredBitmaps> preFilterBitmaps(const Database& database, std::vector<OperatorResult>& bitmap_filter);
 
-   /// Launches the K1 scans of one sequence store: counts[position][valid symbol] on the device, summed over
-   /// partitions (and ranks); returned while still in flight on this thread's stream.
-   static DeviceBuffer calculateMutationsPerPosition(
-      const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter
+   /// Launches the K1 scans of one sequence store into its slice counts[position][valid symbol] of the query's
+   /// count table (accumulating over partitions); returns with the scans in flight on this thread's stream.
+   static void calculateMutationsPerPosition(
+      const Database& database, const SequenceStore<SymbolType>& sequence_store, const PrefilteredBitmaps& bitmap_filter,
+      uint32_t* device_counts
    );
 
+   /// `counts` = the slice counts[position][valid symbol] of one store, on the host.
    void addMutationsToOutput(
-      const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const DeviceBuffer& device_counts,
+      const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const uint32_t* counts,
       std::vector<QueryResultEntry>& output
    ) const;
 
    void validateOrderByFields(const Database& database) const override;
    [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
 
+   /// One row of the result from a cell the device selected.
+   void addSelectedRowToOutput(
+      const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, uint32_t position, const silo_gpu_mutation_row& row,
+      std::vector<QueryResultEntry>& output
+   ) const;
    struct PendingScans : public Action::Pending {
-      std::vector<std::pair<std::string, DeviceBuffer>> in_flight;  // per sequence store, in output order
+      std::vector<std::string> sequence_names;  // the requested stores, in output order
+      /// counts of all stores of the alphabet (MutationTableLayout), then the list written by k_mutations_select:
+      /// [n_rows, -, -, -] + row_capacity rows
+      DeviceBuffer device_table;
+      size_t table_bytes = 0;
+      uint32_t row_capacity = 0;  // 0: the host selects from the whole table
+      HostFetch fetch;            // the list (or the table), enqueued right behind the scans
    };
+   [[nodiscard]] QueryResult collect(const Database& database, PendingScans& scans) const;
 
   public:
    [[nodiscard]] std::unique_ptr<Action::Pending> begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;

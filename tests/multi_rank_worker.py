@@ -131,6 +131,10 @@ def main():
             {"type": "HasAminoAcidMutation", "sequenceName": "S", "position": 100}]}},
     ]
     results = [engine.execute_raw(q) for q in queries]
+    # the same queries as one batch: scans share plane passes, the count tables are reduced after the launches
+    batched = engine.execute_batch(queries)
+    if batched != results:
+        raise AssertionError(f"rank {rank}: batched results differ from one-by-one results")
     dist.barrier()
     if rank == 0:
         print(json.dumps(results), flush=True)

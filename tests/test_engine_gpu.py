@@ -234,3 +234,32 @@ def test_batch_equals_individual_queries(engines):
     for query, (status, document) in zip(queries, engine.execute_batch(queries)):
         if status == 200:
             assert document["queryResult"] == json.loads(json.dumps(so.execute_query(oracle_db, query))), json.dumps(query)
+
+
+def test_device_row_selection_equals_host_selection(engines):
+    """K4 (k_mutations_select) picks the result rows on the device; with the list capacity at 0 the host selects
+    from the whole table, with a tiny capacity the overflow fallback runs: all three give the same documents."""
+    engine, oracle_db = engines
+    rng = random.Random(31)
+    queries = []
+    for min_proportion in (0, 0.0001, 0.05, 0.5, 1):
+        for action_type, names in (("Mutations", ["main", "testSecondSequence"]), ("AminoAcidMutations", [])):
+            action = {"type": action_type, "minProportion": min_proportion}
+            if names:
+                action["sequenceName"] = names
+            queries.append({"action": action, "filterExpression": random_expression(rng, 2)})
+            queries.append({"action": action, "filterExpression": {"type": "True"}})
+    try:
+        documents = {}
+        for capacity in (4096, 0, 3, 1 << 20):
+            engine.set_option("mutation_row_capacity", capacity)
+            documents[capacity] = [engine.execute_raw(q) for q in queries]
+            assert engine.execute_batch(queries) == documents[capacity]
+    finally:
+        engine.set_option("mutation_row_capacity", 4096)
+    assert documents[0] == documents[4096] == documents[3] == documents[1 << 20]
+    for query, (status, document) in zip(queries, documents[4096]):
+        assert status == 200
+        assert document["queryResult"] == json.loads(json.dumps(so.execute_query(oracle_db, query))), json.dumps(query)
+    with pytest.raises(Exception):
+        engine.set_option("no_such_option", 1)
