@@ -297,6 +297,21 @@ class SequenceStorePartition:
     def get_bitmap(self, position, symbol):
         return self.positions[position].bitmaps[symbol]
 
+    def symbol_at(self, position, row):
+        """One cell of reconstructSequence (fasta_aligned.cpp:44-83): the reference symbol, overridden by the deleted
+        (most numerous) symbol of the position, by any stored bitmap that holds the row, then by the missing symbol."""
+        symbol = self.reference_sequence[position]
+        for changed_position, changed_symbol in self.indexing_differences:
+            if changed_position == position:
+                symbol = changed_symbol
+        entry = self.positions[position]
+        for candidate in self.alphabet.SYMBOLS:
+            if candidate != entry.flipped and candidate != entry.deleted and (entry.bitmaps[candidate] >> row) & 1:
+                symbol = candidate
+        if position in self.missing_symbol_bitmaps[row]:
+            symbol = self.alphabet.SYMBOL_MISSING
+        return symbol
+
 
 def get_parent_lineages(value):  # pango_lineage.cpp:25-35
     out = []
@@ -328,17 +343,35 @@ class PangoLineageAliasLookup:  # pango_lineage_alias.cpp
         return lineage
 
 
+    def alias(self, unaliased):  # aliasPangoLineage :43-73: the longest proper prefix of >= 3 elements that is an alias value
+        elements = unaliased.split(".")
+        for i in range(len(elements), 3, -1):
+            search_value = ".".join(elements[: i - 1])
+            for alias, values in self.alias_key.items():
+                if len(values) != 1:
+                    continue
+                if values[0] == search_value:
+                    leftover = ".".join(elements[i - 1 :])
+                    return alias + ("." + leftover if leftover else "")
+        return unaliased
+
+
 class PangoLineageColumnPartition:  # pango_lineage_column.cpp:21-77
     def __init__(self, alias_lookup):
         self.alias = alias_lookup
         self.indexed_values: Dict[str, int] = {}
         self.indexed_sublineage_values: Dict[str, int] = {}
         self.row_count = 0
+        self.values: List[str] = []  # unaliased value per row (value_ids + lookup_unaliased)
+
+    def lookup_aliased_value(self, row):  # lookupAliasedValue(getValues()[row]) :86-88
+        return self.alias.alias(self.values[row])
 
     def insert(self, value):
         resolved = self.alias.unalias(value if value is not None else "")
         row = self.row_count
         self.row_count += 1
+        self.values.append(resolved)
         self.indexed_values[resolved] = self.indexed_values.get(resolved, 0) | (1 << row)
         for parent in get_parent_lineages(resolved):
             self.indexed_sublineage_values[parent] = self.indexed_sublineage_values.get(parent, 0) | (1 << row)
@@ -356,6 +389,49 @@ class DatabasePartition:  # database_partition.h:39-112
     nuc_sequences: Dict[str, SequenceStorePartition] = field(default_factory=dict)
     aa_sequences: Dict[str, SequenceStorePartition] = field(default_factory=dict)
     pango_lineage_columns: Dict[str, PangoLineageColumnPartition] = field(default_factory=dict)
+    # metadata columns (column_group.h): name -> list of raw values; nulls are "" / INT32_MIN / NaN / date 0
+    string_columns: Dict[str, List[str]] = field(default_factory=dict)
+    indexed_string_columns: Dict[str, List[str]] = field(default_factory=dict)
+    int_columns: Dict[str, List[int]] = field(default_factory=dict)
+    float_columns: Dict[str, List[float]] = field(default_factory=dict)
+    date_columns: Dict[str, List[int]] = field(default_factory=dict)
+    insertion_columns: Dict[str, List[str]] = field(default_factory=dict)  # kept as text: only Details reads them here
+
+
+INT32_MIN = -(1 << 31)
+
+
+def string_to_date(value):  # common/date.cpp:22-69: year<<16 | month<<12 | day, 0 = NULL
+    if not value:
+        return 0
+    first = value.find("-")
+    if first == -1:
+        return 0
+    second = value.find("-", first + 1)
+    if second == -1:
+        return 0
+
+    def stoi(text):  # std::stoi: optional whitespace / sign, then leading digits
+        import re
+
+        match = re.match(r"\s*[+-]?\d+", text)
+        if match is None:
+            raise ValueError(text)
+        return int(match.group(0))
+
+    try:
+        year, month, day = stoi(value[:first]), stoi(value[first + 1 :]), stoi(value[second + 1 :])
+    except ValueError:
+        return 0
+    if month > 12 or month == 0 or day > 31 or day == 0:
+        return 0
+    return ((year << 16) + (month << 12) + day) & UINT32
+
+
+def date_to_string(date):  # common/date.cpp:71-86
+    if date == 0:
+        return None
+    return "%04d-%02d-%02d" % (date >> 16, (date >> 12) & 0xF, date & 0xFFF)
 
 
 class Database:
@@ -367,6 +443,52 @@ class Database:
         self.default_nucleotide_sequence = default_nucleotide_sequence
         self.alias = PangoLineageAliasLookup(alias_key or {})
         self.partitions: List[DatabasePartition] = []
+        # database_config.yaml: [(name, column type)] in file order, primaryKey, dateToSortBy
+        self.metadata: List = []
+        self.primary_key = None
+        self.date_to_sort_by = None
+
+    COLUMN_TYPES = ("string", "indexed_string", "pango_lineage", "date", "int", "float", "insertion", "aa_insertion")
+
+    def set_config(self, metadata, primary_key, date_to_sort_by=None):
+        """metadata: [(name, type)] with type in COLUMN_TYPES (database_config.cpp:158-189 getColumnType)."""
+        self.metadata = list(metadata)
+        self.primary_key = primary_key
+        self.date_to_sort_by = date_to_sort_by
+
+    def column_type(self, name):
+        for column, kind in self.metadata:
+            if column == name:
+                return kind
+        return None
+
+    def add_metadata(self, partition, rows):
+        """rows: list of dict column -> raw text ('' = null), as the metadata TSV holds them
+        (column inserts: string_column.cpp:16-24, indexed_string_column.cpp:24-36, int_column.cpp:17-24,
+        float_column.cpp:16-24, date_column.cpp:15-21)."""
+        assert len(rows) == partition.sequence_count
+        for name, kind in self.metadata:
+            raw = [row.get(name) or "" for row in rows]
+            if kind == "string":
+                partition.string_columns[name] = raw
+            elif kind == "indexed_string":
+                partition.indexed_string_columns[name] = raw
+            elif kind == "pango_lineage":
+                if name not in partition.pango_lineage_columns:
+                    column = PangoLineageColumnPartition(self.alias)
+                    for value in raw:
+                        column.insert(value)
+                    partition.pango_lineage_columns[name] = column
+            elif kind == "int":
+                partition.int_columns[name] = [INT32_MIN if value == "" else int(value) for value in raw]
+            elif kind == "float":
+                partition.float_columns[name] = [float("nan") if value == "" else float(value) for value in raw]
+            elif kind == "date":
+                partition.date_columns[name] = [string_to_date(value) for value in raw]
+            elif kind in ("insertion", "aa_insertion"):
+                partition.insertion_columns[name] = raw
+            else:
+                raise ValueError(kind)
 
     def add_partition(self, nuc_genomes, aa_genomes, lineages=None, lineage_column="pango_lineage"):
         """nuc_genomes / aa_genomes: name -> list of str|None, all the same length."""
@@ -400,7 +522,7 @@ class Database:
 # ------------------------------------------------------------------------------------------------
 # operators (operators/*.cpp); evaluate() returns an int bitset
 # ------------------------------------------------------------------------------------------------
-EMPTY, FULL, INDEX_SCAN, INTERSECTION, COMPLEMENT, UNION, THRESHOLD, BITMAP_SELECTION = range(8)
+EMPTY, FULL, INDEX_SCAN, INTERSECTION, COMPLEMENT, UNION, THRESHOLD, BITMAP_SELECTION, SELECTION, RANGE_SELECTION = range(10)
 
 
 class Operator:
@@ -662,33 +784,46 @@ class And(Expression):
 
     def compile_children(self, database, partition, mode):  # and.cpp:101-172
         all_children = [c.compile(database, partition, mode) for c in self.children]
-        non_negated, negated = [], []
-        for child in all_children:
+        non_negated, negated, predicates = [], [], []
+        index = 0
+        while index < len(all_children):  # the list grows while it is walked (:144-155, intended behaviour)
+            child = all_children[index]
+            index += 1
             if child.type == FULL:
                 continue
             if child.type == EMPTY:
-                return [Empty(partition.sequence_count)], []
+                return [Empty(partition.sequence_count)], [], []
             if child.type == INTERSECTION:
                 non_negated.extend(child.children)
                 negated.extend(child.negated_children)
             elif child.type == COMPLEMENT:
                 negated.append(child.negate())
+            elif child.type == SELECTION:
+                predicates.extend(child.predicates)
+                if child.child is not None:
+                    all_children.append(child.child)
             else:
                 non_negated.append(child)
-        return non_negated, negated
+        return non_negated, negated, predicates
 
-    def compile(self, database, partition, mode):  # and.cpp:174-227 (no Selection predicates on this path)
-        non_negated, negated = self.compile_children(database, partition, mode)
+    def compile(self, database, partition, mode):  # and.cpp:174-227
+        non_negated, negated, predicates = self.compile_children(database, partition, mode)
         row_count = partition.sequence_count
         if not non_negated and not negated:
-            return Full(row_count)
+            if not predicates:
+                return Full(row_count)
+            return Selection(predicates, row_count)
         if len(non_negated) == 1 and not negated:
-            return non_negated[0]
-        if len(negated) == 1 and not non_negated:
-            return Complement(negated[0], row_count)
-        if not non_negated:
-            return Complement(Union(negated, row_count), row_count)
-        return Intersection(non_negated, negated, row_count)
+            index_operator = non_negated[0]
+        elif len(negated) == 1 and not non_negated:
+            index_operator = Complement(negated[0], row_count)
+        elif not non_negated:
+            index_operator = Complement(Union(negated, row_count), row_count)
+        else:
+            index_operator = Intersection(non_negated, negated, row_count)
+        if not predicates:
+            return index_operator
+        return Selection(predicates, row_count, index_operator)
 
 
 class Or(Expression):
@@ -1047,7 +1182,229 @@ def parse_expression(node):  # expression.cpp:49-102
             "The field 'includeSublineages' in a PangoLineage expression needs to be a boolean",
         )
         return PangoLineageFilter(node["column"], node["value"], node["includeSublineages"])
+    if kind == "StringEquals":  # string_equals.cpp:70-85
+        check_silo_query("column" in node, "The field 'column' is required in an StringEquals expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in an StringEquals expression needs to be a string")
+        check_silo_query("value" in node, "The field 'value' is required in an StringEquals expression")
+        check_silo_query(
+            node["value"] is None or isinstance(node["value"], str),
+            "The field 'value' in an StringEquals expression needs to be a string or null",
+        )
+        return StringEquals(node["column"], node["value"] if node["value"] is not None else "")
+    if kind == "IntEquals":  # int_equals.cpp:50-67
+        check_silo_query("column" in node, "The field 'column' is required in an IntEquals expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in an IntEquals expression must be a string")
+        check_silo_query("value" in node, "The field 'value' is required in an IntEquals expression")
+        check_silo_query(node["value"] is None or _is_integer(node["value"]), "The field 'value' in an IntEquals expression must be an integer or null")
+        return IntEquals(node["column"], INT32_MIN if node["value"] is None else node["value"])
+    if kind == "IntBetween":  # int_between.cpp:63-88
+        check_silo_query("column" in node, "The field 'column' is required in a IntBetween expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in a IntBetween expression must be a string")
+        check_silo_query("from" in node, "The field 'from' is required in IntBetween expression")
+        check_silo_query(node["from"] is None or _is_integer(node["from"]), "The field 'from' in a IntBetween expression must be an int or null")
+        check_silo_query("to" in node, "The field 'to' is required in a IntBetween expression")
+        check_silo_query(node["to"] is None or _is_integer(node["to"]), "The field 'to' in a IntBetween expression must be an int or null")
+        return IntBetween(node["column"], node["from"], node["to"])
+    if kind == "FloatEquals":  # float_equals.cpp:53-70
+        check_silo_query("column" in node, "The field 'column' is required in an FloatEquals expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in an FloatEquals expression must be a string")
+        check_silo_query("value" in node, "The field 'value' is required in an FloatEquals expression")
+        check_silo_query(node["value"] is None or isinstance(node["value"], float), "The field 'value' in an FloatEquals expression must be a float")
+        return FloatEquals(node["column"], float("nan") if node["value"] is None else node["value"])
+    if kind == "FloatBetween":  # float_between.cpp:72-99
+        check_silo_query("column" in node, "The field 'column' is required in a FloatBetween expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in a FloatBetween expression must be a string")
+        check_silo_query("from" in node, "The field 'from' is required in FloatBetween expression")
+        check_silo_query(node["from"] is None or isinstance(node["from"], float), "The field 'from' in a FloatBetween expression must be a float or null")
+        check_silo_query("to" in node, "The field 'to' is required in a FloatBetween expression")
+        check_silo_query(node["to"] is None or isinstance(node["to"], float), "The field 'to' in a FloatBetween expression must be a float or null")
+        return FloatBetween(node["column"], node["from"], node["to"])
+    if kind == "DateBetween":  # date_between.cpp:103-130
+        check_silo_query("column" in node, "The field 'column' is required in a DateBetween expression")
+        check_silo_query(isinstance(node["column"], str), "The field 'column' in a DateBetween expression needs to be a string")
+        check_silo_query("from" in node, "The field 'from' is required in DateBetween expression")
+        check_silo_query(
+            node["from"] is None or (isinstance(node["from"], str) and True),
+            "The field 'from' in a DateBetween expression needs to be a string or null",
+        )
+        check_silo_query("to" in node, "The field 'to' is required in a DateBetween expression")
+        check_silo_query(
+            node["to"] is None or (isinstance(node["to"], str) and True),
+            "The field 'to' in a DateBetween expression needs to be a non-empty string or null",
+        )
+        return DateBetween(
+            node["column"],
+            string_to_date(node["from"]) if isinstance(node["from"], str) else None,
+            string_to_date(node["to"]) if isinstance(node["to"], str) else None,
+        )
     raise QueryParseException("Unknown object filter type '" + kind + "'")
+
+
+def _is_integer(value):
+    return isinstance(value, int) and not isinstance(value, bool)
+
+
+# ------------------------------------------------------------------------------------------------
+# metadata predicates (operators/selection.cpp, range_selection.cpp; filter_expressions/{string_equals,
+# int_equals,int_between,float_equals,float_between,date_between}.cpp)
+# ------------------------------------------------------------------------------------------------
+EQUALS, NOT_EQUALS, LESS, HIGHER_OR_EQUALS, HIGHER, LESS_OR_EQUALS = "==", "!=", "<", ">=", ">", "<="
+_NEGATED = {EQUALS: NOT_EQUALS, NOT_EQUALS: EQUALS, LESS: HIGHER_OR_EQUALS, HIGHER_OR_EQUALS: LESS, HIGHER: LESS_OR_EQUALS,
+            LESS_OR_EQUALS: HIGHER}
+
+
+class Predicate:  # CompareToValueSelection<T>, selection.cpp:132-230; Python floats compare like IEEE doubles (NaN: all false but !=)
+    def __init__(self, column, comparator, value):
+        self.column, self.comparator, self.value = column, comparator, value
+
+    def match(self, row):
+        v = self.column[row]
+        c = self.comparator
+        if c == EQUALS:
+            return v == self.value
+        if c == NOT_EQUALS:
+            return v != self.value
+        if c == LESS:
+            return v < self.value
+        if c == HIGHER_OR_EQUALS:
+            return v >= self.value
+        if c == HIGHER:
+            return v > self.value
+        return v <= self.value
+
+    def negate(self):  # selection.cpp:195-220: the comparator is negated, NOT the truth value (differs for NaN)
+        return Predicate(self.column, _NEGATED[self.comparator], self.value)
+
+
+class Selection(Operator):
+    type = SELECTION
+
+    def __init__(self, predicates, row_count, child=None):
+        self.predicates, self.row_count, self.child = list(predicates), row_count, child
+
+    def evaluate(self):  # selection.cpp:88-108
+        rows = range(self.row_count) if self.child is None else ids_from_bits(self.child.evaluate())
+        return bits_from_ids([row for row in rows if all(p.match(row) for p in self.predicates)])
+
+    def copy(self):
+        return Selection(self.predicates, self.row_count, None if self.child is None else self.child.copy())
+
+    def negate(self):  # selection.cpp:125-130
+        if self.child is None and len(self.predicates) == 1:
+            return Selection([self.predicates[0].negate()], self.row_count)
+        return Complement(self.copy(), self.row_count)
+
+
+class RangeSelection(Operator):  # range_selection.cpp: union of [start, end) id ranges
+    type = RANGE_SELECTION
+
+    def __init__(self, ranges, row_count):
+        self.ranges, self.row_count = list(ranges), row_count
+
+    def evaluate(self):
+        bits = 0
+        for start, end in self.ranges:
+            if end > start:
+                bits |= ((1 << (end - start)) - 1) << start
+        return bits
+
+    def copy(self):
+        return RangeSelection(self.ranges, self.row_count)
+
+    def negate(self):  # range_selection.cpp:44-66: the complementary ranges
+        out, last = [], 0
+        for start, end in self.ranges:
+            if last != start:
+                out.append((last, start))
+            last = end
+        if last != self.row_count:
+            out.append((last, self.row_count))
+        return RangeSelection(out, self.row_count)
+
+
+class StringEquals(Expression):  # string_equals.cpp:37-68
+    def __init__(self, column, value):
+        self.column, self.value = column, value
+
+    def compile(self, database, partition, mode):
+        rows = partition.sequence_count
+        if self.column in partition.indexed_string_columns:
+            values = partition.indexed_string_columns[self.column]
+            bitmap = bits_from_ids([i for i, v in enumerate(values) if v == self.value])
+            return Empty(rows) if bitmap == 0 else IndexScan(bitmap, rows)
+        if self.column in partition.string_columns:
+            values = partition.string_columns[self.column]
+            # embedString fails (-> Empty) only for a long string that is not in the dictionary: no row can equal it
+            return Selection([Predicate(values, EQUALS, self.value)], rows)
+        return Empty(rows)
+
+
+class IntEquals(Expression):  # int_equals.cpp:30-47
+    def __init__(self, column, value):
+        self.column, self.value = column, value
+
+    def compile(self, database, partition, mode):
+        if self.column not in partition.int_columns:
+            return Empty(partition.sequence_count)
+        return Selection([Predicate(partition.int_columns[self.column], EQUALS, self.value)], partition.sequence_count)
+
+
+class IntBetween(Expression):  # int_between.cpp:37-60 (.at(column): unknown column is a std::out_of_range -> 500)
+    def __init__(self, column, value_from, value_to):
+        self.column, self.value_from, self.value_to = column, value_from, value_to
+
+    def compile(self, database, partition, mode):
+        values = partition.int_columns[self.column]
+        predicates = [Predicate(values, HIGHER_OR_EQUALS, self.value_from if self.value_from is not None else INT32_MIN + 1)]
+        if self.value_to is not None:
+            predicates.append(Predicate(values, LESS_OR_EQUALS, self.value_to))
+        return Selection(predicates, partition.sequence_count)
+
+
+class FloatEquals(Expression):  # float_equals.cpp:33-50
+    def __init__(self, column, value):
+        self.column, self.value = column, value
+
+    def compile(self, database, partition, mode):
+        if self.column not in partition.float_columns:
+            return Empty(partition.sequence_count)
+        return Selection([Predicate(partition.float_columns[self.column], EQUALS, self.value)], partition.sequence_count)
+
+
+class FloatBetween(Expression):  # float_between.cpp:37-69: [from, to) — the upper bound is exclusive
+    def __init__(self, column, value_from, value_to):
+        self.column, self.value_from, self.value_to = column, value_from, value_to
+
+    def compile(self, database, partition, mode):
+        check_silo_query(self.column in partition.float_columns, "The database does not contain the float column '" + self.column + "'")
+        values = partition.float_columns[self.column]
+        predicates = []
+        if self.value_from is not None:
+            predicates.append(Predicate(values, HIGHER_OR_EQUALS, self.value_from))
+        if self.value_to is not None:
+            predicates.append(Predicate(values, LESS, self.value_to))
+        if not predicates:
+            predicates.append(Predicate(values, NOT_EQUALS, float("nan")))  # true for every row, NULLs included
+        return Selection(predicates, partition.sequence_count)
+
+
+class DateBetween(Expression):  # date_between.cpp:49-101
+    def __init__(self, column, date_from, date_to):
+        self.column, self.date_from, self.date_to = column, date_from, date_to
+
+    def compile(self, database, partition, mode):
+        values = partition.date_columns[self.column]
+        rows = partition.sequence_count
+        if database.date_to_sort_by != self.column:  # unsorted column: from <= d < to, the upper bound EXCLUSIVE
+            return Selection(
+                [Predicate(values, HIGHER_OR_EQUALS, self.date_from if self.date_from is not None else 1),
+                 Predicate(values, LESS, self.date_to if self.date_to is not None else UINT32)], rows)
+        # sorted column: lower_bound / upper_bound per chunk, i.e. from <= d <= to, the upper bound INCLUSIVE, NULL (0)
+        # excluded.  The reference's rows are physically sorted by this column; here rows keep the input order, so the
+        # id ranges are restated as the id set (same set, see SURVEY.md §8c on row order).
+        low = self.date_from if self.date_from is not None else 1
+        ids = [i for i, d in enumerate(values) if d >= low and (self.date_to is None or d <= self.date_to)]
+        return IndexScan(bits_from_ids(ids), rows) if ids else RangeSelection([], rows)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1117,20 +1474,161 @@ class Aggregated(Action):
         super().__init__()
         self.group_by_fields = group_by_fields
 
-    def validate_order_by_fields(self, database):  # aggregated.cpp:71-88 (no group-by on this path)
-        if self.group_by_fields:
-            raise NotImplementedError("Aggregated with groupByFields is outside the oracle's path")
+    def validate_order_by_fields(self, database):  # aggregated.cpp:26-38,71-88
+        for name in self.group_by_fields:
+            check_silo_query(database.column_type(name) is not None, "Metadata field '" + name + "' to group by not found")
         for f in self.order_by_fields:
             check_silo_query(
-                f.name == "count",
+                f.name == "count" or f.name in self.group_by_fields,
                 "The orderByField '" + f.name + "' cannot be ordered by, as it does not appear in the groupByFields.",
             )
 
-    def execute(self, database, filters):  # aggregated.cpp:58-66
-        count = 0
-        for bitmap in filters:
-            count = (count + card(bitmap)) & UINT32
-        return [{"count": _to_int32(count)}]
+    def execute(self, database, filters):  # aggregated.cpp:58-66,90-149
+        if not self.group_by_fields:
+            count = 0
+            for bitmap in filters:
+                count = (count + card(bitmap)) & UINT32
+            return [{"count": _to_int32(count)}]
+        for name in self.group_by_fields:
+            check_silo_query(database.column_type(name) is not None, "Metadata field '" + name + "' to group by not found")
+        # tuples are keyed by their raw column values (tuple.cpp:29-80); the row order of the result is the iteration
+        # order of an unordered_map, i.e. unspecified: callers compare as multisets unless orderByFields fixes it
+        counts = {}
+        for partition, bitmap in zip(database.partitions, filters):
+            for row in ids_from_bits(bitmap):
+                key = tuple(raw_tuple_value(database, partition, name, row) for name in self.group_by_fields)
+                counts[key] = counts.get(key, 0) + 1
+        out = []
+        for key, count in counts.items():
+            fields = {name: json_tuple_value(database, name, value) for name, value in zip(self.group_by_fields, key)}
+            fields["count"] = _to_int32(count)
+            out.append(fields)
+        return out
+
+
+def raw_tuple_value(database, partition, name, row):
+    """What assignTupleField stores for a row (tuple.cpp:29-80), with dictionary ids replaced by their strings and a
+    NaN made comparable (bytewise tuple equality: every NULL float is the same std::nan(""))."""
+    kind = database.column_type(name)
+    if kind == "string":
+        return partition.string_columns[name][row]
+    if kind == "indexed_string":
+        return partition.indexed_string_columns[name][row]
+    if kind == "pango_lineage":
+        return partition.pango_lineage_columns[name].lookup_aliased_value(row)
+    if kind == "int":
+        return partition.int_columns[name][row]
+    if kind == "float":
+        value = partition.float_columns[name][row]
+        return "NaN" if value != value else value
+    if kind == "date":
+        return partition.date_columns[name][row]
+    if kind in ("insertion", "aa_insertion"):
+        return partition.insertion_columns[name][row]
+    raise KeyError(name)
+
+
+def json_tuple_value(database, name, raw):
+    """tupleFieldToValueType (tuple.cpp:82-160): NULLs ("" / INT32_MIN / NaN / date 0) become JSON null."""
+    kind = database.column_type(name)
+    if kind == "date":
+        return date_to_string(raw)
+    if kind == "int":
+        return None if raw == INT32_MIN else raw
+    if kind == "float":
+        return None if raw == "NaN" else raw
+    return None if raw == "" else raw
+
+
+def tuple_compare(database, fields, order_by_fields):
+    """Tuple::compareLess (tuple.cpp:372-387) on raw values: dates / ints numerically (NULL = smallest), floats with
+    NaN LAST (compareDouble :162-182), strings bytewise (the NULL "" first)."""
+    import functools
+
+    def compare_values(kind, a, b):
+        if kind == "float":
+            a_nan, b_nan = a == "NaN", b == "NaN"
+            if a_nan or b_nan:
+                return 0 if (a_nan and b_nan) else (1 if a_nan else -1)
+        if isinstance(a, str):
+            a, b = a.encode(), b.encode()
+        return -1 if a < b else (1 if a > b else 0)
+
+    def compare(row_a, row_b):
+        for f in order_by_fields:
+            index = fields.index(f.name)
+            c = compare_values(database.column_type(f.name), row_a[index], row_b[index])
+            if c != 0:
+                return c if f.ascending else -c
+        return 0
+
+    return functools.cmp_to_key(compare)
+
+
+class Details(Action):  # details.cpp
+    def __init__(self, fields):
+        super().__init__()
+        self.fields = fields
+
+    def field_list(self, database):  # parseFields :22-35
+        if not self.fields:
+            return [name for name, _ in database.metadata]
+        for name in self.fields:
+            check_silo_query(database.column_type(name) is not None, "Metadata field " + name + " not found.")
+        return list(self.fields)
+
+    def validate_order_by_fields(self, database):  # :43-59
+        fields = self.field_list(database)
+        for f in self.order_by_fields:
+            check_silo_query(f.name in fields, "OrderByField " + f.name + " is not contained in the result of this operation.")
+
+    def execute_and_order(self, database, filters):  # :186-219
+        self.validate_order_by_fields(database)
+        fields = self.field_list(database)
+        tuples = []
+        for partition, bitmap in zip(database.partitions, filters):
+            for row in ids_from_bits(bitmap):
+                tuples.append(tuple(raw_tuple_value(database, partition, name, row) for name in fields))
+        if self.order_by_fields:
+            tuples.sort(key=tuple_compare(database, fields, self.order_by_fields))
+        if self.limit is not None:
+            tuples = tuples[: self.limit + (self.offset or 0)]
+        result = [{name: json_tuple_value(database, name, value) for name, value in zip(fields, row)} for row in tuples]
+        return self.apply_offset_and_limit(result)
+
+
+class FastaAligned(Action):  # fasta_aligned.cpp
+    def __init__(self, sequence_names):
+        super().__init__()
+        self.sequence_names = sequence_names
+
+    def validate_order_by_fields(self, database):  # :28-42
+        for f in self.order_by_fields:
+            check_silo_query(
+                f.name == database.primary_key or f.name in self.sequence_names,
+                "The only fields returned by the FastaAligned action are " + ",".join(self.sequence_names) + " and " + database.primary_key,
+            )
+
+    def execute(self, database, filters):  # :85-136; reconstructSequence :44-83 = the stored symbol of every cell
+        for name in self.sequence_names:
+            check_silo_query(
+                name in database.nuc_references or name in database.aa_references,
+                "Database does not contain a sequence with name: '" + name + "'",
+            )
+        total = sum(card(bitmap) for bitmap in filters)
+        check_silo_query(total < 10001, "FastaAligned action currently limited to 10000 sequences")
+        out = []
+        for partition, bitmap in zip(database.partitions, filters):
+            for row in ids_from_bits(bitmap):
+                entry = {database.primary_key: json_tuple_value(
+                    database, database.primary_key, raw_tuple_value(database, partition, database.primary_key, row))}
+                for name in self.sequence_names:
+                    is_nuc = name in database.nuc_references
+                    store = (partition.nuc_sequences if is_nuc else partition.aa_sequences)[name]
+                    alphabet = Nucleotide if is_nuc else AminoAcid
+                    entry[name] = "".join(alphabet.symbol_to_char(store.symbol_at(position, row)) for position in range(len(store.positions)))
+                out.append(entry)
+        return out
 
 
 def _to_int32(value):
@@ -1302,7 +1800,26 @@ def parse_action(node):  # action.cpp:144-187
         action = parse_mutations(node, Nucleotide)
     elif kind == "AminoAcidMutations":
         action = parse_mutations(node, AminoAcid)
-    elif kind in ("Details", "Fasta", "FastaAligned", "Insertions", "AminoAcidInsertions"):
+    elif kind == "Details":  # details.cpp:221-224
+        action = Details(list(node.get("fields", [])))
+    elif kind == "FastaAligned":  # fasta_aligned.cpp:138-161
+        check_silo_query(
+            isinstance(node.get("sequenceName"), (str, list)),
+            "FastaAligned action must have the field sequenceName of type string or an array of strings",
+        )
+        names = []
+        if isinstance(node["sequenceName"], list):
+            for child in node["sequenceName"]:
+                check_silo_query(
+                    isinstance(child, str),
+                    "FastaAligned action must have the field sequenceName of type string or an array of strings; while parsing "
+                    "array encountered the element " + json.dumps(child, separators=(",", ":")) + " which is not of type string",
+                )
+                names.append(child)
+        else:
+            names.append(node["sequenceName"])
+        action = FastaAligned(names)
+    elif kind in ("Fasta", "Insertions", "AminoAcidInsertions"):
         raise NotImplementedError(kind + " is outside the oracle's path")
     else:
         raise QueryParseException(kind + " is not a valid action")

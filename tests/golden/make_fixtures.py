@@ -22,6 +22,11 @@ HOT_FILTERS = {
     "HasNucleotideMutation", "HasAminoAcidMutation", "PangoLineage",
 }
 HOT_ACTIONS = {"Aggregated", "Mutations", "AminoAcidMutations"}
+# SURVEY.md §8(f) "next" rows: metadata predicates feeding the filter tree, Aggregated with groupByFields, Details,
+# FastaAligned.  Their fixtures go to queries_next/ and invalidQueries_next/.
+NEXT_FILTERS = HOT_FILTERS | {"StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "DateBetween"}
+NEXT_ACTIONS = HOT_ACTIONS | {"Details", "FastaAligned"}
+NEXT_INVALID = {"GroupByLineageInvalidOrderBy.json", "OffsetNegative.json"}
 HOT_INVALID = {
     "sequencePos0Filter.json", "invalidMutationsMinProportion.json", "nuc_mutations_no_proportion.json",
     "aa_mutations_no_proportion.json", "invalidAction.json",
@@ -101,22 +106,30 @@ def main():
     qsrc = os.path.join(REF, "endToEndTests", "test", "queries")
     qdst = os.path.join(HERE, "queries")
     os.makedirs(qdst, exist_ok=True)
-    kept = []
+    ndst = os.path.join(HERE, "queries_next")
+    os.makedirs(ndst, exist_ok=True)
+    kept, kept_next = [], []
     for name in sorted(os.listdir(qsrc)):
         case = json.load(open(os.path.join(qsrc, name)))
         types = set()
         filter_types(case["query"].get("filterExpression"), types)
         action = case["query"]["action"]
-        if not types <= HOT_FILTERS or action.get("type") not in HOT_ACTIONS or action.get("groupByFields"):
-            continue
-        shutil.copyfile(os.path.join(qsrc, name), os.path.join(qdst, name))
-        kept.append(name)
+        if types <= HOT_FILTERS and action.get("type") in HOT_ACTIONS and not action.get("groupByFields"):
+            shutil.copyfile(os.path.join(qsrc, name), os.path.join(qdst, name))
+            kept.append(name)
+        elif types <= NEXT_FILTERS and action.get("type") in NEXT_ACTIONS:
+            shutil.copyfile(os.path.join(qsrc, name), os.path.join(ndst, name))
+            kept_next.append(name)
     isrc = os.path.join(REF, "endToEndTests", "test", "invalidQueries")
     idst = os.path.join(HERE, "invalidQueries")
     os.makedirs(idst, exist_ok=True)
     for name in sorted(HOT_INVALID):
         shutil.copyfile(os.path.join(isrc, name), os.path.join(idst, name))
+    os.makedirs(os.path.join(HERE, "invalidQueries_next"), exist_ok=True)
+    for name in sorted(NEXT_INVALID):
+        shutil.copyfile(os.path.join(isrc, name), os.path.join(HERE, "invalidQueries_next", name))
     print(f"kept {len(kept)} query fixtures:", " ".join(kept))
+    print(f"kept {len(kept_next)} next-row query fixtures:", " ".join(kept_next))
 
 
 if __name__ == "__main__":

@@ -15,17 +15,20 @@ def build_oracle_db(data, partition_sizes=None):
         {k: [so.AminoAcid.char_to_symbol(c) for c in v] for k, v in data["aa_references"].items()},
         alias_key=data["alias"],
     )
+    config = dataset.load_database_config()
+    db.set_config(config["metadata"], config["primary_key"], config["date_to_sort_by"])
     n = len(data["keys"])
     bounds = [0]
     for size in partition_sizes or [n]:
         bounds.append(bounds[-1] + size)
     assert bounds[-1] == n
     for lo, hi in zip(bounds[:-1], bounds[1:]):
-        db.add_partition(
+        partition = db.add_partition(
             {k: v[lo:hi] for k, v in data["nuc"].items()},
             {k: v[lo:hi] for k, v in data["aa"].items()},
             data["lineages"][lo:hi],
         )
+        db.add_metadata(partition, data["rows"][lo:hi])
     return db
 
 
@@ -51,6 +54,23 @@ def test_e2e_query_goldens(oracle_db, case):
 
 @pytest.mark.parametrize("case", dataset.load_query_fixtures("invalidQueries"), ids=lambda c: c["file"])
 def test_e2e_invalid_query_goldens(oracle_db, case):
+    with pytest.raises(so.QueryParseException) as info:
+        so.execute_query(oracle_db, case["query"])
+    assert {"error": "Bad request", "message": str(info.value)} == case["expectedError"]
+
+
+def as_multiset(rows):
+    return sorted(json.dumps(row, sort_keys=True) for row in rows)
+
+
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("queries_next"), ids=lambda c: c["file"])
+def test_e2e_next_row_query_goldens(oracle_db, case):
+    """metadata predicates, Aggregated with groupByFields, Details, FastaAligned."""
+    dataset.check_next_row_case(case, lambda query: normalise(so.execute_query(oracle_db, query)))
+
+
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("invalidQueries_next"), ids=lambda c: c["file"])
+def test_e2e_next_row_invalid_query_goldens(oracle_db, case):
     with pytest.raises(so.QueryParseException) as info:
         so.execute_query(oracle_db, case["query"])
     assert {"error": "Bad request", "message": str(info.value)} == case["expectedError"]
