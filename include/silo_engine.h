@@ -60,6 +60,18 @@ int silo_engine_set_lineage_column_ids(
 );
 
 /* Call once after loading, before the first query. */
+/* Metadata columns (the reference fills them from the metadata table in
+ * Preprocessor::buildDatabase, preprocessor.cpp:447-503).  silo_engine_set_schema names the primary key and the
+ * dateToSortBy column of database_config.yaml (call it before the first silo_engine_append_metadata).
+ * silo_engine_append_metadata appends n_values rows in text form (NULL or "" = null value) to a column of a
+ * partition; column_type is the type of database_config.yaml — "string", "indexed_string" (string with
+ * generateIndex), "pango_lineage", "date", "int", "float", "insertion", "aaInsertion" — the column is created, and
+ * appended to the schema, on its first call.  Every column must end up with one value per row of the partition.
+ * A "pango_lineage" column also answers PangoLineage filters (no separate silo_engine_set_lineage_column needed). */
+int silo_engine_set_schema(silo_engine* engine, const char* primary_key, const char* date_to_sort_by);
+int silo_engine_append_metadata(
+   silo_engine* engine, int partition, const char* column, const char* column_type, const char* const* values, uint32_t n_values
+);
 int silo_engine_finalize(silo_engine* engine);
 
 /* Multi-GPU (one process per GPU).  Call before silo_engine_add_partition.  shard_by_position != 0:

@@ -207,6 +207,42 @@ int silo_gpu_filter_eval(
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
 int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* shards, accumulated */, void* stream);
 
+/* ---- K5 / K6: metadata columns -------------------------------------------------
+ * A column is a plain device array with one value per row: int32 (int columns, NULL = INT32_MIN), uint32 (dates as
+ * year<<16|month<<12|day, NULL = 0; dictionary ids of string / lineage columns) or double (NULL = NaN).
+ * silo_gpu_bitset_from_compare evaluates one predicate of the reference's Selection operator for all rows:
+ * bit i = values[i] <comparator> *value with the C++ comparison operators (CompareToValueSelection<T>::match,
+ * selection.cpp:145-165) — a metadata predicate enters the fused filter program as this bitset. */
+#define SILO_GPU_VALUE_I32 0
+#define SILO_GPU_VALUE_U32 1
+#define SILO_GPU_VALUE_F64 2
+#define SILO_GPU_CMP_EQUALS 0
+#define SILO_GPU_CMP_NOT_EQUALS 1
+#define SILO_GPU_CMP_LESS 2
+#define SILO_GPU_CMP_HIGHER_OR_EQUALS 3
+#define SILO_GPU_CMP_HIGHER 4
+#define SILO_GPU_CMP_LESS_OR_EQUALS 5
+int silo_gpu_upload_column(const void* src_host, size_t n_rows, int value_type, void** out_dev); /* free: silo_gpu_free */
+int silo_gpu_bitset_from_compare(
+   const silo_gpu_store* store, uint64_t* dst_dev, const void* values_dev, int value_type, int comparator,
+   const void* value /* one int32 / uint32 / double on the host */, void* stream
+);
+/* Aggregated with groupByFields (aggregated.cpp:100-149) for columns given as dictionary ids: for every row i of
+ * the filter (NULL = all rows) counts_dev[sum_c ids[c][i] * stride_c] += 1 with mixed-radix strides, the first
+ * column most significant; prod(cardinalities) <= SILO_GPU_MAX_GROUP_BINS entries, accumulated into (zero them
+ * first; partitions with a shared dictionary may share one table). */
+#define SILO_GPU_MAX_GROUP_COLUMNS 8
+#define SILO_GPU_MAX_GROUP_BINS (1u << 24)
+int silo_gpu_group_count(
+   const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* const* group_ids_dev, const uint32_t* cardinalities,
+   uint32_t n_columns, uint32_t* counts_dev, void* stream
+);
+/* FastaAligned (fasta_aligned.cpp:44-83 reconstructSequence): the stored symbol of every position of the given
+ * rows as characters, out_chars_dev[r * positions + p]; row_ids_dev holds n_rows sequence ids of this store. */
+int silo_gpu_reconstruct_sequences(
+   const silo_gpu_store* store, uint32_t seqstore_id, const uint32_t* row_ids_dev, uint32_t n_rows, char* out_chars_dev, void* stream
+);
+
 /* ---- K4: row selection of Mutations (mutations.cpp:184-232) ------------------------------------------
  * For every position p < n_positions with total = sum_s counts[p][s] > 0, every symbol index s != reference_index[p]
  * (0xFF = the reference symbol is not a valid mutation symbol) with

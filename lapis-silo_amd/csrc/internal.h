@@ -1,0 +1,22 @@
+// internal.h — what the translation units of libsilo_gpu.so share (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "silo_gpu.h"
+
+/// Records `message` as this thread's silo_gpu_last_error() and returns `code`.
+int silo_gpu_internal_fail(int code, const std::string& message);
+
+#define SILO_HIP_TRY(expr)                                                                                  \
+   do {                                                                                                     \
+      hipError_t err_ = (expr);                                                                             \
+      if (err_ != hipSuccess) {                                                                             \
+         (void)hipGetLastError(); /* clear the sticky error so later launch checks start clean */           \
+         return silo_gpu_internal_fail(                                                                     \
+            err_ == hipErrorOutOfMemory ? SILO_GPU_ERR_OUT_OF_MEMORY : SILO_GPU_ERR_HIP,                    \
+            std::string(#expr) + ": " + hipGetErrorString(err_)                                             \
+         );                                                                                                 \
+      }                                                                                                     \
+   } while (0)

@@ -24,6 +24,7 @@
 
 #include "../../include/silo_gpu.h"
 #include "bitprog.h"
+#include "internal.h"
 
 namespace {
 
@@ -37,6 +38,14 @@ int fail(int code, const std::string& msg) {
    g_last_error = msg;
    return code;
 }
+
+}  // namespace
+
+int silo_gpu_internal_fail(int code, const std::string& message) {  // for the other translation units (internal.h)
+   return fail(code, message);
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                          \
    do {                                                                                        \
@@ -144,6 +153,7 @@ struct silo_gpu_store {
    uint8_t* d_stage_null = nullptr;
    size_t stage_null_capacity = 0;
    uint8_t* d_char_table[2] = {nullptr, nullptr};  // per alphabet, uploaded on first use
+   char* d_symbol_chars[2] = {nullptr, nullptr};   // symbol -> character, for FastaAligned
    std::mutex mutex;
 };
 
@@ -813,6 +823,51 @@ __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence
    }
 }
 
+// FastaAligned: one thread per (requested row, position) looks the row's bit up in every dense plane of the
+// position; a cell no dense plane claims holds a sparsely stored symbol (IUPAC code) and is found by binary search
+// for position << 37 | symbol << 32 | sequence in the sorted sparse keys.  A gather (one 8-byte word per plane),
+// sized for the <= 10 000 rows the action allows.
+__global__ __launch_bounds__(256) void k_reconstruct_sequences(
+   const SeqStoreDev store, const uint64_t* __restrict__ sparse_keys, uint32_t n_sparse, const uint32_t* __restrict__ row_ids,
+   const char* __restrict__ symbol_chars, char* __restrict__ out
+) {
+   const uint32_t position = blockIdx.x * blockDim.x + threadIdx.x;
+   if (position >= store.positions) {
+      return;
+   }
+   const uint32_t sequence = row_ids[blockIdx.y];
+   const uint32_t word = sequence >> 6;
+   const uint32_t bit = sequence & 63u;
+   uint32_t found = 0xFFu;
+   for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
+      const uint64_t* plane = planePtr(store, position, symbol);
+      if (plane != nullptr && ((plane[word] >> bit) & 1u) != 0) {
+         found = symbol;
+      }
+   }
+   if (found == 0xFFu) {
+      for (uint32_t symbol = 0; symbol < store.n_symbols && found == 0xFFu; ++symbol) {
+         if (store.kind[symbol] != PLANE_SPARSE) {
+            continue;
+         }
+         const uint64_t key = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32) | sequence;
+         uint32_t lo = 0, hi = n_sparse;
+         while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (sparse_keys[mid] < key) {
+               lo = mid + 1;
+            } else {
+               hi = mid;
+            }
+         }
+         if (lo < n_sparse && sparse_keys[lo] == key) {
+            found = symbol;
+         }
+      }
+   }
+   out[static_cast<size_t>(blockIdx.y) * store.positions + position] = found == 0xFFu ? '?' : symbol_chars[found];
+}
+
 __global__ void k_scatter_sparse(const uint64_t* __restrict__ keys, uint32_t begin, uint32_t end, uint64_t* out) {
    const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
    if (k < end) {
@@ -1016,6 +1071,8 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
    (void)hipFree(store->d_stage_null);
    (void)hipFree(store->d_char_table[0]);
    (void)hipFree(store->d_char_table[1]);
+   (void)hipFree(store->d_symbol_chars[0]);
+   (void)hipFree(store->d_symbol_chars[1]);
    delete store;
 }
 
@@ -1801,6 +1858,45 @@ int silo_gpu_mutations_scan(
    }
    HIP_TRY(hipGetLastError());
    g_last_scan_kernel = "k_scan_tiled";
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_reconstruct_sequences(
+   const silo_gpu_store* store, uint32_t seqstore_id, const uint32_t* row_ids_dev, uint32_t n_rows, char* out_chars_dev, void* stream
+) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || row_ids_dev == nullptr || out_chars_dev == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_reconstruct_sequences: bad arguments");
+   }
+   if (n_rows > 65535) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_reconstruct_sequences: at most 65535 rows per call");
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   auto* mutable_store = const_cast<silo_gpu_store*>(store);  // the symbol -> char table is created on first use
+   const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   if (!seqstore.finalized) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_reconstruct_sequences: store is not finalized");
+   }
+   if (n_rows == 0 || seqstore.dev.positions == 0) {
+      return SILO_GPU_OK;
+   }
+   const uint32_t alphabet = seqstore.alphabet == SILO_GPU_ALPHABET_AMINO_ACID ? 1 : 0;
+   {
+      const std::lock_guard<std::mutex> lock(mutable_store->mutex);
+      if (mutable_store->d_symbol_chars[alphabet] == nullptr) {
+         // enum order of the reference's alphabets (nucleotide_symbols.h:15-34, aa_symbols.h:15-43)
+         const char* chars = alphabet == 0 ? "-ACGTRYSWKMBDHVN" : "-ACDEFGHIKLMNPQRSTVWYBZ*X";
+         char* device = nullptr;
+         HIP_TRY(hipMalloc(&device, SILO_GPU_MAX_SYMBOLS));
+         HIP_TRY(hipMemcpy(device, chars, strlen(chars), hipMemcpyHostToDevice));
+         mutable_store->d_symbol_chars[alphabet] = device;
+      }
+   }
+   const dim3 grid((seqstore.dev.positions + 255) / 256, n_rows);
+   k_reconstruct_sequences<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      seqstore.dev, seqstore.d_sparse, static_cast<uint32_t>(seqstore.sparse_sorted.size()), row_ids_dev,
+      store->d_symbol_chars[alphabet], out_chars_dev
+   );
+   HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }
 

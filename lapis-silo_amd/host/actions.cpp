@@ -160,18 +160,24 @@ void ScanBatcher::flush() {
 }
 
 // ---- Aggregated (aggregated.cpp:58-96; group-by is outside the hot path) -----------------------------
-void Aggregated::validateOrderByFields(const Database& /*database*/) const {
-   if (!group_by_fields.empty()) {
-      throw std::runtime_error("Aggregated with groupByFields is not supported by the MI355X filter engine");
+void Aggregated::validateOrderByFields(const Database& database) const {  // aggregated.cpp:26-38,71-88
+   for (const std::string& group_by_field : group_by_fields) {
+      CHECK_SILO_QUERY(
+         database.database_config.getMetadata(group_by_field).has_value(), "Metadata field '" + group_by_field + "' to group by not found"
+      )
    }
    for (const OrderByField& field : order_by_fields) {
       CHECK_SILO_QUERY(
-         field.name == "count", "The orderByField '" + field.name + "' cannot be ordered by, as it does not appear in the groupByFields."
+         field.name == "count" || std::find(group_by_fields.begin(), group_by_fields.end(), field.name) != group_by_fields.end(),
+         "The orderByField '" + field.name + "' cannot be ordered by, as it does not appear in the groupByFields."
       )
    }
 }
 
 QueryResult Aggregated::execute(const Database& database, std::vector<OperatorResult> bitmap_filters) const {
+   if (!group_by_fields.empty()) {
+      return aggregateWithGrouping(database, bitmap_filters);
+   }
    uint32_t count = 0;  // aggregateWithoutGrouping, aggregated.cpp:58-66
    for (const auto& filter : bitmap_filters) {
       count += filter.cardinality();
@@ -534,9 +540,36 @@ std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:14
       action = parseMutations<Nucleotide>(json);
    } else if (expression_type == "AminoAcidMutations") {
       action = parseMutations<AminoAcid>(json);
-   } else if (expression_type == "Details" || expression_type == "Fasta" || expression_type == "FastaAligned" ||
-              expression_type == "Insertions" || expression_type == "AminoAcidInsertions") {
-      // row materialisation / string work: outside the device hot path
+   } else if (expression_type == "Details") {  // details.cpp:221-224
+      std::vector<std::string> fields;
+      if (json.contains("fields")) {
+         for (const auto& field : json["fields"].items()) {
+            fields.push_back(field.as_string());
+         }
+      }
+      action = std::make_unique<Details>(std::move(fields));
+   } else if (expression_type == "FastaAligned") {  // fasta_aligned.cpp:138-161
+      CHECK_SILO_QUERY(
+         json.contains("sequenceName") && (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
+         "FastaAligned action must have the field sequenceName of type string or an array of strings"
+      )
+      std::vector<std::string> sequence_names;
+      if (json["sequenceName"].is_array()) {
+         for (const auto& child : json["sequenceName"].items()) {
+            CHECK_SILO_QUERY(
+               child.is_string(),
+               "FastaAligned action must have the field sequenceName of type string or an array of strings; while parsing array "
+               "encountered the element " +
+                  child.dump() + " which is not of type string"
+            )
+            sequence_names.emplace_back(child.as_string());
+         }
+      } else {
+         sequence_names.emplace_back(json["sequenceName"].as_string());
+      }
+      action = std::make_unique<FastaAligned>(std::move(sequence_names));
+   } else if (expression_type == "Fasta" || expression_type == "Insertions" || expression_type == "AminoAcidInsertions") {
+      // unaligned sequences and the insertion index are not held by this engine
       throw std::runtime_error("action '" + expression_type + "' is not supported by the MI355X filter engine");
    } else {
       throw QueryParseException(expression_type + " is not a valid action");

@@ -211,6 +211,46 @@ int silo_engine_set_lineage_column_ids(
    });
 }
 
+int silo_engine_set_schema(silo_engine* engine, const char* primary_key, const char* date_to_sort_by) {
+   if (engine == nullptr || primary_key == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_schema: null argument");
+   }
+   engine->database.database_config.primary_key = primary_key;
+   if (date_to_sort_by != nullptr && date_to_sort_by[0] != '\0') {
+      engine->database.database_config.date_to_sort_by = date_to_sort_by;
+   } else {
+      engine->database.database_config.date_to_sort_by.reset();
+   }
+   return 0;
+}
+
+int silo_engine_append_metadata(
+   silo_engine* engine, int partition, const char* column, const char* column_type, const char* const* values, uint32_t n_values
+) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr || column == nullptr || column_type == nullptr || (values == nullptr && n_values > 0)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_append_metadata: bad arguments");
+   }
+   std::optional<silo::config::ColumnType> type;
+   if (std::strcmp(column_type, "indexed_string") == 0) {
+      type = silo::config::ColumnType::INDEXED_STRING;
+   } else {
+      type = silo::config::columnTypeFromConfig(column_type, false);
+   }
+   if (!type.has_value()) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, std::string("silo_engine_append_metadata: unknown column type ") + column_type);
+   }
+   return guarded([&] {
+      std::vector<std::string> texts;
+      texts.reserve(n_values);
+      for (uint32_t row = 0; row < n_values; ++row) {
+         texts.emplace_back(values[row] == nullptr ? "" : values[row]);
+      }
+      engine->database.appendMetadata(*part, column, *type, texts);
+      return 0;
+   });
+}
+
 int silo_engine_finalize(silo_engine* engine) {
    if (engine == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_finalize: null engine");

@@ -236,6 +236,48 @@ std::string PangoLineageAliasLookup::unaliasPangoLineage(const std::string& pang
    return found->second.at(0) + '.' + suffix;
 }
 
+std::string PangoLineageAliasLookup::aliasPangoLineage(const std::string& pango_lineage) const {  // pango_lineage_alias.cpp:43-73
+   std::vector<std::string> elements;
+   std::string::size_type begin = 0;
+   while (true) {
+      const auto dot = pango_lineage.find('.', begin);
+      elements.push_back(pango_lineage.substr(begin, dot == std::string::npos ? std::string::npos : dot - begin));
+      if (dot == std::string::npos) {
+         break;
+      }
+      begin = dot + 1;
+   }
+   const auto join = [&](size_t from, size_t to) {
+      std::string out;
+      for (size_t i = from; i < to; ++i) {
+         if (i != from) {
+            out.push_back('.');
+         }
+         out += elements[i];
+      }
+      return out;
+   };
+   const size_t num_elements = elements.size();
+   // the longest proper prefix of at least three elements that some alias stands for
+   for (size_t i = num_elements; i > 3; i--) {
+      const std::string search_value = join(0, i - 1);
+      for (const auto& [alias, alias_values] : alias_key) {
+         if (alias_values.size() != 1) {
+            continue;
+         }
+         if (alias_values.at(0) == search_value) {
+            const std::string leftover_value = join(i - 1, num_elements);
+            std::string value = alias;
+            if (!leftover_value.empty()) {
+               value += "." + leftover_value;
+            }
+            return value;
+         }
+      }
+   }
+   return pango_lineage;
+}
+
 std::vector<std::string> getParentLineages(const std::string& value) {  // pango_lineage.cpp:25-35
    std::vector<std::string> parent_lineages;
    std::string::size_type pos = 0;
@@ -339,6 +381,7 @@ std::optional<const uint64_t*> PangoLineageColumnPartition::filterIncludingSubli
 // ---- partitions / database ----------------------------------------------------------------------------
 DatabasePartition::~DatabasePartition() {
    columns.pango_lineage_columns.clear();
+   columns.metadata_columns.clear();
    silo_gpu_store_destroy(store);
 }
 
@@ -502,6 +545,44 @@ MutationTableLayout makeMutationTableLayout(const std::map<std::string, Sequence
 }
 }  // namespace
 
+void Database::appendMetadata(
+   DatabasePartition& partition, const std::string& name, config::ColumnType type, const std::vector<std::string>& values
+) {
+   const auto known = database_config.getMetadata(name);
+   if (!known.has_value()) {
+      database_config.metadata.push_back({name, type});
+   } else if (known->type != type) {
+      throw std::runtime_error("metadata column '" + name + "' was declared with another type");
+   }
+   auto found = partition.columns.metadata_columns.find(name);
+   if (found == partition.columns.metadata_columns.end()) {
+      const bool is_sorted = type == config::ColumnType::DATE && database_config.date_to_sort_by.has_value() &&
+                             *database_config.date_to_sort_by == name;
+      found = partition.columns.metadata_columns
+                 .emplace(std::piecewise_construct, std::forward_as_tuple(name), std::forward_as_tuple(type, is_sorted, &alias_key))
+                 .first;
+   }
+   storage::column::MetadataColumnPartition& column = found->second;
+   if (column.numRows() + values.size() > partition.sequence_count) {
+      throw std::runtime_error("metadata column '" + name + "' holds more values than the partition has rows");
+   }
+   column.reserve(partition.sequence_count);
+   for (const std::string& value : values) {
+      column.insert(value);
+   }
+   if (type == config::ColumnType::INDEXED_PANGOLINEAGE) {
+      auto lineage = partition.columns.pango_lineage_columns.find(name);
+      if (lineage == partition.columns.pango_lineage_columns.end()) {
+         lineage = partition.columns.pango_lineage_columns
+                      .emplace(std::piecewise_construct, std::forward_as_tuple(name), std::forward_as_tuple(alias_key, partition))
+                      .first;
+      }
+      for (const std::string& value : values) {
+         lineage->second.insert(value);
+      }
+   }
+}
+
 void Database::finalize() {
    const bool device_in_use = !partitions.empty();
    nuc_mutation_layout = makeMutationTableLayout(nuc_sequences, device_in_use);
@@ -509,6 +590,12 @@ void Database::finalize() {
    for (auto& partition : partitions) {
       checkGpu(silo_gpu_store_finalize(partition.store), "silo_gpu_store_finalize");
       for (auto& [name, column] : partition.columns.pango_lineage_columns) {
+         column.finalize();
+      }
+      for (auto& [name, column] : partition.columns.metadata_columns) {
+         if (column.numRows() != partition.sequence_count) {
+            throw std::runtime_error("metadata column '" + name + "' does not have one value per row");
+         }
          column.finalize();
       }
    }

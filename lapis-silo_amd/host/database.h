@@ -26,6 +26,7 @@
 
 #include "json.h"
 #include "silo_gpu.h"
+#include "metadata_columns.h"
 #include "symbols.h"
 
 namespace silo {
@@ -121,6 +122,7 @@ class PangoLineageAliasLookup {
        : alias_key(std::move(alias_key)) {}
    static PangoLineageAliasLookup fromJson(const json::Value& json);
    [[nodiscard]] std::string unaliasPangoLineage(const std::string& pango_lineage) const;
+   [[nodiscard]] std::string aliasPangoLineage(const std::string& unaliased_pango_lineage) const;
 
   private:
    std::unordered_map<std::string, std::vector<std::string>> alias_key;
@@ -231,6 +233,15 @@ class DatabasePartition {
    std::map<std::string, SequenceStorePartition<AminoAcid>> aa_sequences;
    struct ColumnPartitionGroup {
       std::map<std::string, storage::column::PangoLineageColumnPartition> pango_lineage_columns;
+      /// Every metadata column of database_config.metadata by name (column_group.h keeps one map per type; the
+      /// type is a member here).  A lineage column appears in both maps: the one above answers PangoLineage
+      /// filters, this one renders and groups its values.
+      std::map<std::string, storage::column::MetadataColumnPartition> metadata_columns;
+
+      [[nodiscard]] const storage::column::MetadataColumnPartition* find(const std::string& name, config::ColumnType type) const {
+         const auto found = metadata_columns.find(name);
+         return found != metadata_columns.end() && found->second.type == type ? &found->second : nullptr;
+      }
    } columns;
 
    mutable DevicePool pool;
@@ -264,9 +275,8 @@ class Database {
    std::deque<DatabasePartition> partitions;
    std::map<std::string, SequenceStore<Nucleotide>> nuc_sequences;
    std::map<std::string, SequenceStore<AminoAcid>> aa_sequences;
-   struct DatabaseConfig {
-      std::string default_nucleotide_sequence = "main";
-   } database_config;
+   /// database_config.yaml: default nucleotide sequence; metadata columns in file order, primary key, dateToSortBy
+   config::DatabaseConfig database_config;
    PangoLineageAliasLookup alias_key;
    int device = 0;
 
@@ -311,6 +321,10 @@ class Database {
    // --- construction (replaces Preprocessor::buildDatabase, preprocessor.cpp:447-503) -----------
    void setReferenceGenomes(const json::Value& reference_genomes);
    DatabasePartition& addPartition(uint32_t sequence_count);
+   /// Appends `values` (text form, "" = NULL) to metadata column `name` of `partition`, creating the column and its
+   /// entry in database_config.metadata on first use.  A lineage column also feeds the PangoLineage filter index.
+   /// Replaces the column inserts of Preprocessor::buildDatabase (preprocessor.cpp:447-503, column_group.cpp).
+   void appendMetadata(DatabasePartition& partition, const std::string& name, config::ColumnType type, const std::vector<std::string>& values);
    void finalize();
 };
 

@@ -3,6 +3,9 @@
 // including the algebraic rewrites and the observable quirks listed in SURVEY.md §8(a).
 #include <algorithm>
 
+#include <cmath>
+#include <climits>
+
 #include "query_engine.h"
 
 namespace silo::query_engine::filter_expressions {
@@ -135,7 +138,7 @@ std::string And::toString(const Database& database) const {
    return "And(" + join(child_strings, " & ") + ")";
 }
 
-std::pair<OperatorVector, OperatorVector> And::compileChildren(
+std::tuple<OperatorVector, OperatorVector, std::vector<operators::Predicate>> And::compileChildren(
    const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
 ) const {
    OperatorVector all_child_operators;
@@ -144,14 +147,17 @@ std::pair<OperatorVector, OperatorVector> And::compileChildren(
    }
    OperatorVector non_negated_child_operators;
    OperatorVector negated_child_operators;
-   for (auto& child : all_child_operators) {
+   std::vector<operators::Predicate> predicates;
+   // by index: the child of a Selection is appended to the list while it is walked (and.cpp:138-151)
+   for (size_t index = 0; index < all_child_operators.size(); ++index) {
+      auto& child = all_child_operators[index];
       if (child->type() == operators::FULL) {
          continue;
       }
       if (child->type() == operators::EMPTY) {
          OperatorVector empty;
          empty.emplace_back(std::make_unique<operators::Empty>(rowsOf(database_partition)));
-         return {std::move(empty), OperatorVector()};
+         return {std::move(empty), OperatorVector(), std::vector<operators::Predicate>{}};
       }
       if (child->type() == operators::INTERSECTION) {
          auto* intersection_child = dynamic_cast<operators::Intersection*>(child.get());
@@ -163,30 +169,45 @@ std::pair<OperatorVector, OperatorVector> And::compileChildren(
          }
       } else if (child->type() == operators::COMPLEMENT) {
          negated_child_operators.emplace_back(child->negate());
+      } else if (child->type() == operators::SELECTION) {
+         auto* selection_child = dynamic_cast<operators::Selection*>(child.get());
+         predicates.insert(predicates.end(), selection_child->predicates.begin(), selection_child->predicates.end());
+         if (selection_child->child != nullptr) {
+            std::unique_ptr<Operator> grandchild = std::move(selection_child->child);
+            all_child_operators.push_back(std::move(grandchild));  // may reallocate: `child` is not used afterwards
+         }
       } else {
          non_negated_child_operators.push_back(std::move(child));
       }
    }
-   return {std::move(non_negated_child_operators), std::move(negated_child_operators)};
+   return {std::move(non_negated_child_operators), std::move(negated_child_operators), std::move(predicates)};
 }
 
 std::unique_ptr<Operator> And::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   auto [non_negated_child_operators, negated_child_operators] = compileChildren(database, database_partition, mode);
+   auto [non_negated_child_operators, negated_child_operators, predicates] = compileChildren(database, database_partition, mode);
    const RowSpace rows = rowsOf(database_partition);
    if (non_negated_child_operators.empty() && negated_child_operators.empty()) {
-      return std::make_unique<operators::Full>(rows);
+      if (predicates.empty()) {
+         return std::make_unique<operators::Full>(rows);
+      }
+      return std::make_unique<operators::Selection>(std::move(predicates), rows);
    }
+   std::unique_ptr<Operator> index_arithmetic_operator;
    if (non_negated_child_operators.size() == 1 && negated_child_operators.empty()) {
-      return std::move(non_negated_child_operators[0]);
-   }
-   if (negated_child_operators.size() == 1 && non_negated_child_operators.empty()) {
-      return std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
-   }
-   if (non_negated_child_operators.empty()) {
+      index_arithmetic_operator = std::move(non_negated_child_operators[0]);
+   } else if (negated_child_operators.size() == 1 && non_negated_child_operators.empty()) {
+      index_arithmetic_operator = std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
+   } else if (non_negated_child_operators.empty()) {
       auto union_ret = std::make_unique<operators::Union>(std::move(negated_child_operators), rows);
-      return std::make_unique<operators::Complement>(std::move(union_ret), rows);
+      index_arithmetic_operator = std::make_unique<operators::Complement>(std::move(union_ret), rows);
+   } else {
+      index_arithmetic_operator =
+         std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
    }
-   return std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
+   if (predicates.empty()) {
+      return index_arithmetic_operator;
+   }
+   return std::make_unique<operators::Selection>(std::move(index_arithmetic_operator), std::move(predicates), rows);
 }
 
 // ---- Or (or.cpp:41-94) ---------------------------------------------------------------------------
@@ -524,6 +545,154 @@ std::unique_ptr<Operator> PangoLineageFilter::compile(
    return std::make_unique<operators::IndexScan>(bitmap.value(), rows);
 }
 
+// ---- metadata predicates ------------------------------------------------------
+namespace {
+
+operators::Predicate predicateOf(const storage::column::MetadataColumnPartition& column, int comparator) {
+   operators::Predicate predicate{};
+   predicate.column = &column;
+   predicate.comparator = comparator;
+   return predicate;
+}
+operators::Predicate intPredicate(const storage::column::MetadataColumnPartition& column, int comparator, int32_t value) {
+   operators::Predicate predicate = predicateOf(column, comparator);
+   predicate.value.as_int = value;
+   return predicate;
+}
+operators::Predicate wordPredicate(const storage::column::MetadataColumnPartition& column, int comparator, uint32_t value) {
+   operators::Predicate predicate = predicateOf(column, comparator);
+   predicate.value.as_word = value;
+   return predicate;
+}
+operators::Predicate doublePredicate(const storage::column::MetadataColumnPartition& column, int comparator, double value) {
+   operators::Predicate predicate = predicateOf(column, comparator);
+   predicate.value.as_double = value;
+   return predicate;
+}
+std::unique_ptr<Operator> selectionOf(std::vector<operators::Predicate> predicates, RowSpace rows) {
+   return std::make_unique<operators::Selection>(std::move(predicates), rows);
+}
+
+}  // namespace
+
+std::string StringEquals::toString(const Database& /*database*/) const {
+   return column + " = '" + value + "'";
+}
+std::unique_ptr<Operator> StringEquals::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // string_equals.cpp:37-68
+   const RowSpace rows = rowsOf(database_partition);
+   const auto* indexed = database_partition.columns.find(column, config::ColumnType::INDEXED_STRING);
+   const auto* plain = database_partition.columns.find(column, config::ColumnType::STRING);
+   const auto* string_column = indexed != nullptr ? indexed : plain;
+   if (string_column == nullptr) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   // Both kinds are dictionary encoded here: the filter is "dictionary id == id of the value", one compare pass
+   // over 4 bytes per row (the reference keeps a roaring bitmap per value for indexed columns and probes the
+   // embedded strings row by row for plain ones).  A value that is not in the dictionary matches no row.
+   const auto value_id = string_column->lookupId(value);
+   if (!value_id.has_value()) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   return selectionOf({wordPredicate(*string_column, SILO_GPU_CMP_EQUALS, *value_id)}, rows);
+}
+
+std::string IntEquals::toString(const Database& /*database*/) const {
+   return column + " = '" + std::to_string(value) + "'";
+}
+std::unique_ptr<Operator> IntEquals::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // int_equals.cpp:30-47
+   const RowSpace rows = rowsOf(database_partition);
+   const auto* int_column = database_partition.columns.find(column, config::ColumnType::INT);
+   if (int_column == nullptr) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   return selectionOf({intPredicate(*int_column, SILO_GPU_CMP_EQUALS, value)}, rows);
+}
+
+std::string IntBetween::toString(const Database& /*database*/) const {
+   return "[IntBetween " + (from.has_value() ? std::to_string(*from) : "unbounded") + " - " + (to.has_value() ? std::to_string(*to) : "unbounded") + "]";
+}
+std::unique_ptr<Operator> IntBetween::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // int_between.cpp:37-60
+   const auto* int_column = database_partition.columns.find(column, config::ColumnType::INT);
+   if (int_column == nullptr) {
+      throw std::out_of_range("map::at");  // int_columns.at(column): an unknown column is a 500 in the reference
+   }
+   std::vector<operators::Predicate> predicates;
+   predicates.push_back(intPredicate(*int_column, SILO_GPU_CMP_HIGHER_OR_EQUALS, from.value_or(INT32_MIN + 1)));
+   if (to.has_value()) {
+      predicates.push_back(intPredicate(*int_column, SILO_GPU_CMP_LESS_OR_EQUALS, to.value()));
+   }
+   return selectionOf(std::move(predicates), rowsOf(database_partition));
+}
+
+std::string FloatEquals::toString(const Database& /*database*/) const {
+   return column + " = '" + std::to_string(value) + "'";
+}
+std::unique_ptr<Operator> FloatEquals::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // float_equals.cpp:33-50
+   const RowSpace rows = rowsOf(database_partition);
+   const auto* float_column = database_partition.columns.find(column, config::ColumnType::FLOAT);
+   if (float_column == nullptr) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   return selectionOf({doublePredicate(*float_column, SILO_GPU_CMP_EQUALS, value)}, rows);
+}
+
+std::string FloatBetween::toString(const Database& /*database*/) const {
+   return "[FloatBetween " + (from.has_value() ? std::to_string(*from) : "unbounded") + " - " + (to.has_value() ? std::to_string(*to) : "unbounded") + "]";
+}
+std::unique_ptr<Operator> FloatBetween::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // float_between.cpp:37-69: [from, to) — the upper bound is exclusive
+   const auto* float_column = database_partition.columns.find(column, config::ColumnType::FLOAT);
+   CHECK_SILO_QUERY(float_column != nullptr, "The database does not contain the float column '" + column + "'")
+   std::vector<operators::Predicate> predicates;
+   if (from.has_value()) {
+      predicates.push_back(doublePredicate(*float_column, SILO_GPU_CMP_HIGHER_OR_EQUALS, from.value()));
+   }
+   if (to.has_value()) {
+      predicates.push_back(doublePredicate(*float_column, SILO_GPU_CMP_LESS, to.value()));
+   }
+   if (predicates.empty()) {
+      predicates.push_back(doublePredicate(*float_column, SILO_GPU_CMP_NOT_EQUALS, std::nan("")));  // true for every row
+   }
+   return selectionOf(std::move(predicates), rowsOf(database_partition));
+}
+
+std::string DateBetween::toString(const Database& /*database*/) const {
+   return "[Date-between " + (date_from.has_value() ? common::dateToString(*date_from).value_or("") : "unbounded") + " and " +
+          (date_to.has_value() ? common::dateToString(*date_to).value_or("") : "unbounded") + "]";
+}
+std::unique_ptr<Operator> DateBetween::compile(
+   const Database& /*database*/, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // date_between.cpp:49-101
+   const auto* date_column = database_partition.columns.find(column, config::ColumnType::DATE);
+   if (date_column == nullptr) {
+      throw std::out_of_range("map::at");  // date_columns.at(column)
+   }
+   std::vector<operators::Predicate> predicates;
+   if (!date_column->is_sorted) {
+      // from <= d < to: on an unsorted column the upper bound is EXCLUSIVE (:58-73)
+      predicates.push_back(wordPredicate(*date_column, SILO_GPU_CMP_HIGHER_OR_EQUALS, date_from.value_or(common::Date{1})));
+      predicates.push_back(wordPredicate(*date_column, SILO_GPU_CMP_LESS, date_to.value_or(common::Date{UINT32_MAX})));
+   } else {
+      // the dateToSortBy column: the reference binary-searches its physically sorted rows, lower_bound(from or 1) to
+      // upper_bound(to) — from <= d <= to, the upper bound INCLUSIVE, NULL (0) excluded (:83-101).  Rows keep their
+      // input order here, so the same set comes from two compare passes instead of id ranges.
+      predicates.push_back(wordPredicate(*date_column, SILO_GPU_CMP_HIGHER_OR_EQUALS, date_from.value_or(common::Date{1})));
+      if (date_to.has_value()) {
+         predicates.push_back(wordPredicate(*date_column, SILO_GPU_CMP_LESS_OR_EQUALS, date_to.value()));
+      }
+   }
+   return selectionOf(std::move(predicates), rowsOf(database_partition));
+}
+
 // ---- JSON -> Expression (the from_json functions) ------------------------------------------------------
 namespace {
 
@@ -664,14 +833,94 @@ std::unique_ptr<Expression> parseExpression(const json::Value& json) {  // expre
       )
       return std::make_unique<PangoLineageFilter>(json["column"].as_string(), json["value"].as_string(), json["includeSublineages"].as_bool());
    }
-   static const char* const metadata_filters[] = {
-      "DateBetween", "StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "InsertionContains", "AminoAcidInsertionContains",
-   };
-   for (const char* name : metadata_filters) {
-      if (expression_type == name) {
-         // host-side metadata predicates are outside the device hot path
-         throw std::runtime_error("filter type '" + expression_type + "' is not supported by the MI355X filter engine");
+   if (expression_type == "StringEquals") {  // string_equals.cpp:70-85
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in an StringEquals expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in an StringEquals expression needs to be a string")
+      CHECK_SILO_QUERY(json.contains("value"), "The field 'value' is required in an StringEquals expression")
+      CHECK_SILO_QUERY(
+         json["value"].is_string() || json["value"].is_null(), "The field 'value' in an StringEquals expression needs to be a string or null"
+      )
+      return std::make_unique<StringEquals>(json["column"].as_string(), json["value"].is_null() ? "" : json["value"].as_string());
+   }
+   if (expression_type == "IntEquals") {  // int_equals.cpp:50-67
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in an IntEquals expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in an IntEquals expression must be a string")
+      CHECK_SILO_QUERY(json.contains("value"), "The field 'value' is required in an IntEquals expression")
+      CHECK_SILO_QUERY(
+         json["value"].is_number_integer() || json["value"].is_null(), "The field 'value' in an IntEquals expression must be an integer or null"
+      )
+      return std::make_unique<IntEquals>(
+         json["column"].as_string(), json["value"].is_null() ? INT32_MIN : static_cast<int32_t>(json["value"].as_int64())
+      );
+   }
+   if (expression_type == "IntBetween") {  // int_between.cpp:63-88
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in a IntBetween expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in a IntBetween expression must be a string")
+      CHECK_SILO_QUERY(json.contains("from"), "The field 'from' is required in IntBetween expression")
+      CHECK_SILO_QUERY(
+         json["from"].is_null() || json["from"].is_number_integer(), "The field 'from' in a IntBetween expression must be an int or null"
+      )
+      CHECK_SILO_QUERY(json.contains("to"), "The field 'to' is required in a IntBetween expression")
+      CHECK_SILO_QUERY(json["to"].is_null() || json["to"].is_number_integer(), "The field 'to' in a IntBetween expression must be an int or null")
+      std::optional<int32_t> value_from;
+      if (json["from"].is_number_integer()) {
+         value_from = static_cast<int32_t>(json["from"].as_int64());
       }
+      std::optional<int32_t> value_to;
+      if (json["to"].is_number_integer()) {
+         value_to = static_cast<int32_t>(json["to"].as_int64());
+      }
+      return std::make_unique<IntBetween>(json["column"].as_string(), value_from, value_to);
+   }
+   if (expression_type == "FloatEquals") {  // float_equals.cpp:53-70
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in an FloatEquals expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in an FloatEquals expression must be a string")
+      CHECK_SILO_QUERY(json.contains("value"), "The field 'value' is required in an FloatEquals expression")
+      CHECK_SILO_QUERY(json["value"].is_number_float() || json["value"].is_null(), "The field 'value' in an FloatEquals expression must be a float")
+      return std::make_unique<FloatEquals>(json["column"].as_string(), json["value"].is_null() ? std::nan("") : json["value"].as_double());
+   }
+   if (expression_type == "FloatBetween") {  // float_between.cpp:72-99
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in a FloatBetween expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in a FloatBetween expression must be a string")
+      CHECK_SILO_QUERY(json.contains("from"), "The field 'from' is required in FloatBetween expression")
+      CHECK_SILO_QUERY(
+         json["from"].is_null() || json["from"].is_number_float(), "The field 'from' in a FloatBetween expression must be a float or null"
+      )
+      CHECK_SILO_QUERY(json.contains("to"), "The field 'to' is required in a FloatBetween expression")
+      CHECK_SILO_QUERY(json["to"].is_null() || json["to"].is_number_float(), "The field 'to' in a FloatBetween expression must be a float or null")
+      std::optional<double> value_from;
+      if (json["from"].is_number_float()) {
+         value_from = json["from"].as_double();
+      }
+      std::optional<double> value_to;
+      if (json["to"].is_number_float()) {
+         value_to = json["to"].as_double();
+      }
+      return std::make_unique<FloatBetween>(json["column"].as_string(), value_from, value_to);
+   }
+   if (expression_type == "DateBetween") {  // date_between.cpp:103-130
+      CHECK_SILO_QUERY(json.contains("column"), "The field 'column' is required in a DateBetween expression")
+      CHECK_SILO_QUERY(json["column"].is_string(), "The field 'column' in a DateBetween expression needs to be a string")
+      CHECK_SILO_QUERY(json.contains("from"), "The field 'from' is required in DateBetween expression")
+      // nlohmann's empty() is false for every string, so "non-empty" never rejects anything (:112-115)
+      CHECK_SILO_QUERY(json["from"].is_null() || json["from"].is_string(), "The field 'from' in a DateBetween expression needs to be a string or null")
+      CHECK_SILO_QUERY(json.contains("to"), "The field 'to' is required in a DateBetween expression")
+      CHECK_SILO_QUERY(
+         json["to"].is_null() || json["to"].is_string(), "The field 'to' in a DateBetween expression needs to be a non-empty string or null"
+      )
+      std::optional<common::Date> date_from;
+      if (json["from"].is_string()) {
+         date_from = common::stringToDate(json["from"].as_string());
+      }
+      std::optional<common::Date> date_to;
+      if (json["to"].is_string()) {
+         date_to = common::stringToDate(json["to"].as_string());
+      }
+      return std::make_unique<DateBetween>(json["column"].as_string(), date_from, date_to);
+   }
+   if (expression_type == "InsertionContains" || expression_type == "AminoAcidInsertionContains") {
+      // the insertion index stays on the host in the reference too and is not built here
+      throw std::runtime_error("filter type '" + expression_type + "' is not supported by the MI355X filter engine");
    }
    throw QueryParseException("Unknown object filter type '" + expression_type + "'");
 }

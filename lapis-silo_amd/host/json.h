@@ -50,6 +50,7 @@ class Value {
    [[nodiscard]] bool is_number() const { return kind_ == Kind::Unsigned || kind_ == Kind::Integer || kind_ == Kind::Float; }
    [[nodiscard]] bool is_number_unsigned() const { return kind_ == Kind::Unsigned; }
    [[nodiscard]] bool is_number_integer() const { return kind_ == Kind::Unsigned || kind_ == Kind::Integer; }
+   [[nodiscard]] bool is_number_float() const { return kind_ == Kind::Float; }
    [[nodiscard]] bool is_string() const { return kind_ == Kind::String; }
    [[nodiscard]] bool is_array() const { return kind_ == Kind::Array; }
    [[nodiscard]] bool is_object() const { return kind_ == Kind::Object; }

@@ -1,0 +1,365 @@
+// metadata_actions.cpp — the actions that read metadata columns:
+//   Aggregated with groupByFields   src/silo/query_engine/actions/aggregated.cpp:100-149
+//   Details                         src/silo/query_engine/actions/details.cpp
+//   FastaAligned                    src/silo/query_engine/actions/fasta_aligned.cpp
+#include <algorithm>
+#include <unordered_map>
+
+#include "query_engine.h"
+
+namespace silo::query_engine::actions {
+
+namespace {
+
+using storage::column::MetadataColumnPartition;
+
+const MetadataColumnPartition& columnOf(const DatabasePartition& partition, const std::string& name) {
+   const auto found = partition.columns.metadata_columns.find(name);
+   if (found == partition.columns.metadata_columns.end()) {
+      throw std::runtime_error("the metadata column '" + name + "' was not loaded into this database");
+   }
+   return found->second;
+}
+
+void requireUnsharded(const Database& database, const char* what) {
+   if (database.shard_world > 1) {
+      throw std::runtime_error(std::string(what) + " is not supported on a sharded (multi-GPU) database");
+   }
+}
+
+/// The set bits of a filter, fetched from the device.
+std::vector<uint32_t> selectedRows(const DatabasePartition& partition, const OperatorResult& filter) {
+   std::vector<uint32_t> rows;
+   const uint32_t cardinality = filter.cardinality();
+   if (cardinality == 0) {
+      return rows;
+   }
+   rows.reserve(cardinality);
+   std::vector<uint64_t> words(partition.rowWords());
+   checkGpu(silo_gpu_memcpy_d2h(words.data(), filter.bitset(), words.size() * sizeof(uint64_t), queryStream()), "silo_gpu_memcpy_d2h");
+   for (size_t word = 0; word < words.size(); ++word) {
+      uint64_t bits = words[word];
+      while (bits != 0) {
+         rows.push_back(static_cast<uint32_t>(word * 64 + static_cast<uint32_t>(__builtin_ctzll(bits))));
+         bits &= bits - 1;
+      }
+   }
+   return rows;
+}
+
+}  // namespace
+
+// ---- Aggregated with groupByFields ---------------------------------------------------------------------
+QueryResult Aggregated::aggregateWithGrouping(const Database& database, std::vector<OperatorResult>& bitmap_filter) const {
+   requireUnsharded(database, "Aggregated with groupByFields");
+   struct Group {
+      uint32_t count = 0;
+      std::vector<JsonValue> values;
+   };
+   // Tuples are keyed by their raw bytes (tuple.cpp:389-391); std::map instead of the reference's unordered_map
+   // makes the (unspecified) order of the result rows deterministic.
+   std::map<std::string, Group> groups;
+   const size_t n_fields = group_by_fields.size();
+
+   struct InFlight {
+      const DatabasePartition* partition;
+      std::vector<const MetadataColumnPartition*> columns;
+      std::vector<uint32_t> cardinalities;
+      DeviceBuffer device_counts;
+      size_t n_bins = 0;
+      HostFetch fetch;
+   };
+   std::vector<InFlight> in_flight;
+   for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
+      const DatabasePartition& partition = database.partitions[partition_id];
+      OperatorResult& filter = bitmap_filter[partition_id];
+      std::vector<const MetadataColumnPartition*> columns;
+      for (const std::string& field : group_by_fields) {
+         columns.push_back(&columnOf(partition, field));
+      }
+      if (partition.sequence_count == 0) {
+         continue;
+      }
+      // dictionary ids per field: a tuple is a mixed-radix number, the histogram of those numbers is the group-by
+      std::vector<const uint32_t*> ids;
+      std::vector<uint32_t> cardinalities;
+      uint64_t n_bins = 1;
+      for (const MetadataColumnPartition* column : columns) {
+         const MetadataColumnPartition::Groups column_groups = column->groups();
+         ids.push_back(column_groups.device_ids);
+         cardinalities.push_back(column_groups.cardinality);
+         n_bins = std::min<uint64_t>(n_bins * std::max<uint32_t>(column_groups.cardinality, 1), uint64_t{1} << 40);
+      }
+      if (n_fields <= SILO_GPU_MAX_GROUP_COLUMNS && n_bins <= SILO_GPU_MAX_GROUP_BINS) {
+         InFlight& launch = in_flight.emplace_back();
+         launch.partition = &partition;
+         launch.columns = columns;
+         launch.cardinalities = cardinalities;
+         launch.n_bins = static_cast<size_t>(n_bins);
+         launch.device_counts = partition.pool.acquire(launch.n_bins * sizeof(uint32_t));
+         checkGpu(silo_gpu_memset_async(launch.device_counts.get(), 0, launch.n_bins * sizeof(uint32_t), queryStream()), "silo_gpu_memset_async");
+         checkGpu(
+            silo_gpu_group_count(
+               partition.store, filter.bitset(), ids.data(), cardinalities.data(), static_cast<uint32_t>(n_fields),
+               static_cast<uint32_t*>(launch.device_counts.get()), queryStream()
+            ),
+            "silo_gpu_group_count"
+         );
+         launch.fetch = HostFetch(launch.device_counts.get(), launch.n_bins * sizeof(uint32_t), queryStream());
+         continue;
+      }
+      // more distinct tuples than the device histogram holds: tuple by tuple on the host, as the reference does
+      std::string key;
+      for (const uint32_t row : selectedRows(partition, filter)) {
+         key.clear();
+         for (const MetadataColumnPartition* column : columns) {
+            column->appendKeyOfRow(row, key);
+         }
+         Group& group = groups[key];
+         if (group.count++ == 0) {
+            for (const MetadataColumnPartition* column : columns) {
+               group.values.push_back(column->jsonOfRow(row));
+            }
+         }
+      }
+   }
+   Trace::mark("groups_launched");
+   for (InFlight& launch : in_flight) {
+      const auto* counts = static_cast<const uint32_t*>(launch.fetch.wait());
+      std::vector<uint32_t> digits(n_fields);
+      std::string key;
+      for (size_t bin = 0; bin < launch.n_bins; ++bin) {
+         if (counts[bin] == 0) {
+            continue;
+         }
+         size_t rest = bin;  // first field most significant
+         for (size_t field = n_fields; field-- > 0;) {
+            digits[field] = static_cast<uint32_t>(rest % launch.cardinalities[field]);
+            rest /= launch.cardinalities[field];
+         }
+         key.clear();
+         for (size_t field = 0; field < n_fields; ++field) {
+            launch.columns[field]->appendKeyOfGroup(digits[field], key);
+         }
+         Group& group = groups[key];
+         if (group.count == 0) {
+            for (size_t field = 0; field < n_fields; ++field) {
+               group.values.push_back(launch.columns[field]->jsonOfGroup(digits[field]));
+            }
+         }
+         group.count += counts[bin];
+      }
+   }
+   Trace::mark("groups_on_host");
+   QueryResult result;  // generateResult, aggregated.cpp:44-56
+   result.query_result.reserve(groups.size());
+   for (auto& [key, group] : groups) {
+      QueryResultEntry& entry = result.query_result.emplace_back();
+      for (size_t field = 0; field < n_fields; ++field) {
+         entry.fields[group_by_fields[field]] = std::move(group.values[field]);
+      }
+      entry.fields["count"] = static_cast<int32_t>(group.count);
+   }
+   return result;
+}
+
+// ---- Details ---------------------------------------------------------------------------------------------
+namespace {
+
+std::vector<storage::ColumnMetadata> parseFields(const Database& database, const std::vector<std::string>& fields) {  // details.cpp:22-35
+   if (fields.empty()) {
+      return database.database_config.metadata;
+   }
+   std::vector<storage::ColumnMetadata> field_metadata;
+   for (const std::string& field : fields) {
+      const auto metadata = database.database_config.getMetadata(field);
+      CHECK_SILO_QUERY(metadata.has_value(), "Metadata field " + field + " not found.")
+      field_metadata.push_back(*metadata);
+   }
+   return field_metadata;
+}
+
+}  // namespace
+
+void Details::validateOrderByFields(const Database& database) const {  // details.cpp:43-59
+   const std::vector<storage::ColumnMetadata> field_metadata = parseFields(database, fields);
+   for (const OrderByField& field : order_by_fields) {
+      CHECK_SILO_QUERY(
+         std::any_of(field_metadata.begin(), field_metadata.end(), [&](const storage::ColumnMetadata& metadata) { return metadata.name == field.name; }),
+         "OrderByField " + field.name + " is not contained in the result of this operation."
+      )
+   }
+}
+
+QueryResult Details::execute(const Database& /*database*/, std::vector<OperatorResult> /*bitmap_filter*/) const {
+   return QueryResult{};  // details.cpp:61-66: everything happens in executeAndOrder
+}
+
+QueryResult Details::finish(const Database& database, Pending& pending) const {
+   return executeAndOrder(database, std::move(pending.bitmap_filter));
+}
+
+QueryResult Details::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // details.cpp:186-219
+   validateOrderByFields(database);
+   requireUnsharded(database, "Details");
+   const std::vector<storage::ColumnMetadata> field_metadata = parseFields(database, fields);
+
+   struct Row {
+      uint32_t partition;
+      uint32_t row;
+   };
+   std::vector<Row> tuples;
+   // columns of every partition, in field order (the TupleFactory of a partition)
+   std::vector<std::vector<const storage::column::MetadataColumnPartition*>> columns(database.partitions.size());
+   for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
+      const DatabasePartition& partition = database.partitions[partition_id];
+      for (const auto& metadata : field_metadata) {
+         columns[partition_id].push_back(&columnOf(partition, metadata.name));
+      }
+      for (const uint32_t row : selectedRows(partition, bitmap_filter[partition_id])) {
+         tuples.push_back({static_cast<uint32_t>(partition_id), row});
+      }
+   }
+   Trace::mark("rows_selected");
+
+   // Tuple::compareLess (tuple.cpp:372-387) over the orderByFields, on the raw column values
+   struct CompareField {
+      size_t index;
+      bool ascending;
+   };
+   std::vector<CompareField> compare_fields;
+   for (const OrderByField& order_by : order_by_fields) {
+      for (size_t index = 0; index < field_metadata.size(); ++index) {
+         if (field_metadata[index].name == order_by.name) {
+            compare_fields.push_back({index, order_by.ascending});
+            break;
+         }
+      }
+   }
+   const auto less = [&](const Row& a, const Row& b) {
+      for (const CompareField& field : compare_fields) {
+         const int compared = columns[a.partition][field.index]->compareRows(a.row, *columns[b.partition][field.index], b.row);
+         if (compared < 0) {
+            return field.ascending;
+         }
+         if (compared > 0) {
+            return !field.ascending;
+         }
+      }
+      return false;
+   };
+   // With a limit the reference keeps the `limit + offset` smallest tuples per partition in a heap and merges
+   // them (:88-147).  Its heap is offered the first row past the prefix twice (:118-134), which can duplicate a
+   // row in the result; that defect is not reproduced: the smallest `limit + offset` tuples, each once.
+   size_t to_produce = tuples.size();
+   if (limit.has_value()) {
+      to_produce = std::min<size_t>(tuples.size(), static_cast<size_t>(limit.value()) + offset.value_or(0));
+   }
+   if (!compare_fields.empty()) {
+      if (to_produce < tuples.size()) {
+         std::partial_sort(tuples.begin(), tuples.begin() + static_cast<int64_t>(to_produce), tuples.end(), less);
+      } else {
+         std::sort(tuples.begin(), tuples.end(), less);
+      }
+   }
+   tuples.resize(to_produce);
+
+   // only the rows that survive offset / limit are rendered (applyOffsetAndLimit, action.cpp:68-91)
+   const size_t begin = std::min<size_t>(offset.value_or(0), tuples.size());
+   QueryResult results_in_format;
+   results_in_format.query_result.reserve(tuples.size() - begin);
+   for (size_t index = begin; index < tuples.size(); ++index) {
+      const Row& tuple = tuples[index];
+      QueryResultEntry& entry = results_in_format.query_result.emplace_back();
+      for (size_t field = 0; field < field_metadata.size(); ++field) {
+         entry.fields[field_metadata[field].name] = columns[tuple.partition][field]->jsonOfRow(tuple.row);
+      }
+   }
+   Trace::mark("rows_built");
+   return results_in_format;
+}
+
+// ---- FastaAligned ----------------------------------------------------------------------------------------
+void FastaAligned::validateOrderByFields(const Database& database) const {  // fasta_aligned.cpp:28-42
+   const std::string& primary_key_field = database.database_config.primary_key;
+   for (const OrderByField& field : order_by_fields) {
+      std::string joined;
+      for (size_t i = 0; i < sequence_names.size(); ++i) {
+         joined += (i == 0 ? "" : ",") + sequence_names[i];
+      }
+      CHECK_SILO_QUERY(
+         field.name == primary_key_field || std::find(sequence_names.begin(), sequence_names.end(), field.name) != sequence_names.end(),
+         "The only fields returned by the FastaAligned action are " + joined + " and " + primary_key_field
+      )
+   }
+}
+
+QueryResult FastaAligned::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // fasta_aligned.cpp:85-136
+   struct Requested {
+      std::string name;
+      bool is_amino_acid;
+   };
+   std::vector<Requested> requested;  // nucleotide sequences first, then genes (:89-103); the row is a map anyway
+   for (const std::string& sequence_name : sequence_names) {
+      CHECK_SILO_QUERY(
+         database.nuc_sequences.count(sequence_name) != 0 || database.aa_sequences.count(sequence_name) != 0,
+         "Database does not contain a sequence with name: '" + sequence_name + "'"
+      )
+      requested.push_back({sequence_name, database.nuc_sequences.count(sequence_name) == 0});
+   }
+   size_t total_count = 0;
+   for (const auto& filter : bitmap_filter) {
+      total_count += filter.cardinality();
+   }
+   CHECK_SILO_QUERY(total_count < 10001, "FastaAligned action currently limited to 10000 sequences")
+   requireUnsharded(database, "FastaAligned");
+
+   const std::string& primary_key_column = database.database_config.primary_key;
+   QueryResult results;
+   for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
+      const DatabasePartition& partition = database.partitions[partition_id];
+      const std::vector<uint32_t> rows = selectedRows(partition, bitmap_filter[partition_id]);
+      if (rows.empty()) {
+         continue;
+      }
+      const size_t first_entry = results.query_result.size();
+      const MetadataColumnPartition& primary_key = columnOf(partition, primary_key_column);
+      for (const uint32_t row : rows) {
+         results.query_result.emplace_back().fields.emplace(primary_key_column, primary_key.jsonOfRow(row));
+      }
+      // reconstructSequence (:44-83) for all selected rows of a store at once: one gather over the planes
+      DeviceBuffer device_rows = partition.pool.acquire(rows.size() * sizeof(uint32_t));
+      checkGpu(silo_gpu_memcpy_h2d(device_rows.get(), rows.data(), rows.size() * sizeof(uint32_t), queryStream()), "silo_gpu_memcpy_h2d");
+      for (const Requested& sequence : requested) {
+         uint32_t seqstore_id = 0;
+         size_t length = 0;
+         if (sequence.is_amino_acid) {
+            const auto& store = partition.aa_sequences.at(sequence.name);
+            seqstore_id = store.seqstore_id;
+            length = store.reference_sequence.size();
+         } else {
+            const auto& store = partition.nuc_sequences.at(sequence.name);
+            seqstore_id = store.seqstore_id;
+            length = store.reference_sequence.size();
+         }
+         std::vector<char> chars(rows.size() * length);
+         if (!chars.empty()) {
+            DeviceBuffer device_chars = partition.pool.acquire(chars.size());
+            checkGpu(
+               silo_gpu_reconstruct_sequences(
+                  partition.store, seqstore_id, static_cast<const uint32_t*>(device_rows.get()), static_cast<uint32_t>(rows.size()),
+                  static_cast<char*>(device_chars.get()), queryStream()
+               ),
+               "silo_gpu_reconstruct_sequences"
+            );
+            checkGpu(silo_gpu_memcpy_d2h(chars.data(), device_chars.get(), chars.size(), queryStream()), "silo_gpu_memcpy_d2h");
+         }
+         for (size_t index = 0; index < rows.size(); ++index) {
+            results.query_result[first_entry + index].fields.emplace(sequence.name, std::string(chars.data() + index * length, length));
+         }
+      }
+   }
+   return results;
+}
+
+}  // namespace silo::query_engine::actions

@@ -220,6 +220,14 @@ const uint64_t* ProgramBuilder::sparsePointer(uint32_t seqstore_id, uint32_t pos
    return pointer;
 }
 
+uint64_t* ProgramBuilder::temporaryBitset() {
+   const DatabasePartition& partition = *rows.partition;
+   DeviceBuffer buffer = partition.pool.acquire(static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t));
+   auto* pointer = buffer.as<uint64_t>();
+   temporaries.push_back(std::move(buffer));
+   return pointer;
+}
+
 uint32_t ProgramBuilder::lowerChild(const operators::Operator& child) {
    const operators::Cost cost = child.cost();
    const size_t instructions_after = code.size() / 2 + cost.instructions + 8;
@@ -337,6 +345,83 @@ uint32_t IndexScan::lower(ProgramBuilder& builder) const {
    // a leaf operand: the kernel stages every leaf in LDS up front, no instruction is emitted here
    const uint32_t index = sparse ? builder.sparseLeaf(seqstore_id, position, symbol) : builder.leaf(bitmap);
    return SILO_GPU_LEAF_OPERAND + index;
+}
+
+// ---- Selection (selection.cpp) ---------------------------------------------------------------------
+Predicate Predicate::negated() const {  // selection.cpp:195-220: NOT (x >= v) becomes x < v — not the same for a NaN row
+   static constexpr int NEGATED[] = {
+      SILO_GPU_CMP_NOT_EQUALS, SILO_GPU_CMP_EQUALS, SILO_GPU_CMP_HIGHER_OR_EQUALS, SILO_GPU_CMP_LESS, SILO_GPU_CMP_LESS_OR_EQUALS,
+      SILO_GPU_CMP_HIGHER};
+   Predicate out = *this;
+   out.comparator = NEGATED[comparator];
+   return out;
+}
+
+std::unique_ptr<Operator> Selection::copy() const {
+   return std::make_unique<Selection>(child != nullptr ? child->copy() : nullptr, predicates, rows);
+}
+
+std::unique_ptr<Operator> Selection::negate() const {  // selection.cpp:125-130
+   if (child == nullptr && predicates.size() == 1) {
+      return std::make_unique<Selection>(std::vector<Predicate>{predicates.at(0).negated()}, rows);
+   }
+   return std::make_unique<Complement>(this->copy(), rows);
+}
+
+Cost Selection::cost() const {
+   Cost total{static_cast<uint32_t>(predicates.size()) + 1, static_cast<uint32_t>(predicates.size())};
+   if (child != nullptr) {
+      const Cost child_cost = child->cost();
+      total.instructions += child_cost.instructions;
+      total.leaves += child_cost.leaves;
+   }
+   return total;
+}
+
+uint32_t Selection::lower(ProgramBuilder& builder) const {
+   // The reference probes every predicate row by row (selection.cpp:88-108).  Here each predicate is one pass of
+   // k_bitset_from_compare over its column (4-8 bytes per row, on the query's stream, ahead of the fused program),
+   // and the program ANDs the resulting bitsets like any other stored columns.
+   std::vector<const uint64_t*> columns;
+   for (const Predicate& predicate : predicates) {
+      uint64_t* bitset = builder.temporaryBitset();
+      checkGpu(
+         silo_gpu_bitset_from_compare(
+            rows.partition->store, bitset, predicate.column->deviceValues(), predicate.column->deviceValueType(), predicate.comparator,
+            &predicate.value, queryStream()
+         ),
+         "silo_gpu_bitset_from_compare"
+      );
+      columns.push_back(bitset);
+   }
+   uint32_t acc = 0;
+   bool have = false;
+   if (columns.size() >= 2) {
+      acc = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_AND_N, acc, 0, 0, builder.leafRun(columns));
+      have = true;
+   } else if (columns.size() == 1) {
+      acc = SILO_GPU_LEAF_OPERAND + builder.leaf(columns[0]);
+      have = true;
+   }
+   if (child != nullptr) {
+      const uint32_t child_operand = builder.lowerChild(*child);
+      if (!have) {
+         return child_operand;
+      }
+      const uint32_t dst = isLeafOperand(acc) ? (isLeafOperand(child_operand) ? builder.allocSlot() : child_operand) : acc;
+      builder.emit(SILO_GPU_OP_AND, dst, acc, child_operand);
+      if (dst != child_operand && !isLeafOperand(child_operand)) {
+         builder.freeSlot(child_operand);
+      }
+      return dst;
+   }
+   if (!have) {  // no predicate at all: every row
+      const uint32_t slot = builder.allocSlot();
+      builder.emit(SILO_GPU_OP_ONES, slot);
+      return slot;
+   }
+   return acc;
 }
 
 // ---- BitmapSelection (bitmap_selection.cpp:33-71) -----------------------------------------------

@@ -106,6 +106,8 @@ class ProgramBuilder {
    /// Leaf for a symbol that is stored sparsely: scattered into a cached / pooled bitset before launch.
    uint32_t sparseLeaf(uint32_t seqstore_id, uint32_t position, uint32_t symbol);
    const uint64_t* sparsePointer(uint32_t seqstore_id, uint32_t position, uint32_t symbol);
+   /// A row bitset from the partition's pool that lives as long as this builder (filled by the caller before run()).
+   uint64_t* temporaryBitset();
    /// Appends `columns` as consecutive leaves; returns the imm of an n-ary instruction (first | count << 16).
    uint32_t leafRun(const std::vector<const uint64_t*>& columns);
    /// Children that are stored columns (foldable by one n-ary instruction) vs composite sub-trees.
@@ -269,6 +271,36 @@ class Union : public Operator {
    OperatorVector children;
 };
 
+/// One comparison of a metadata column with a constant (CompareToValueSelection<T>, selection.h:52-70): on the
+/// device a k_bitset_from_compare launch that turns the column into a row bitset.
+struct Predicate {
+   const storage::column::MetadataColumnPartition* column;
+   int comparator;  // SILO_GPU_CMP_*
+   union {
+      int32_t as_int;
+      uint32_t as_word;
+      double as_double;
+   } value;
+   [[nodiscard]] Predicate negated() const;  // the comparator is negated, selection.cpp:195-220
+};
+
+/// selection.cpp: rows (of `child`, or all) that satisfy every predicate.
+class Selection : public Operator {
+  public:
+   Selection(std::unique_ptr<Operator> child, std::vector<Predicate> predicates, RowSpace rows)
+       : Operator(rows), child(std::move(child)), predicates(std::move(predicates)) {}
+   Selection(std::vector<Predicate> predicates, RowSpace rows) : Operator(rows), predicates(std::move(predicates)) {}
+   Type type() const override { return SELECTION; }
+   std::string toString() const override { return "Select[" + std::to_string(predicates.size()) + " predicates]"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override;
+
+   std::unique_ptr<Operator> child;  // may be null
+   std::vector<Predicate> predicates;
+};
+
 class Threshold : public Operator {
   public:
    Threshold(OperatorVector&& non_negated_children, OperatorVector&& negated_children, uint32_t number_of_matchers, bool match_exactly, RowSpace rows);
@@ -323,7 +355,7 @@ struct And : public Expression {
    ExpressionVector children;
 
   private:
-   std::pair<operators::OperatorVector, operators::OperatorVector> compileChildren(
+   std::tuple<operators::OperatorVector, operators::OperatorVector, std::vector<operators::Predicate>> compileChildren(
       const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
    ) const;
 };
@@ -400,6 +432,47 @@ struct PangoLineageFilter : public Expression {
    std::string column;
    std::string lineage;
    bool include_sublineages;
+};
+// ---- metadata predicates ----
+struct StringEquals : public Expression {  // string_equals.cpp
+   StringEquals(std::string column, std::string value) : column(std::move(column)), value(std::move(value)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   std::string value;
+};
+struct IntEquals : public Expression {  // int_equals.cpp
+   IntEquals(std::string column, int32_t value) : column(std::move(column)), value(value) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   int32_t value;
+};
+struct IntBetween : public Expression {  // int_between.cpp
+   IntBetween(std::string column, std::optional<int32_t> from, std::optional<int32_t> to) : column(std::move(column)), from(from), to(to) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   std::optional<int32_t> from;
+   std::optional<int32_t> to;
+};
+struct FloatEquals : public Expression {  // float_equals.cpp
+   FloatEquals(std::string column, double value) : column(std::move(column)), value(value) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   double value;
+};
+struct FloatBetween : public Expression {  // float_between.cpp
+   FloatBetween(std::string column, std::optional<double> from, std::optional<double> to) : column(std::move(column)), from(from), to(to) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   std::optional<double> from;
+   std::optional<double> to;
+};
+struct DateBetween : public Expression {  // date_between.cpp
+   DateBetween(std::string column, std::optional<common::Date> date_from, std::optional<common::Date> date_to)
+       : column(std::move(column)), date_from(date_from), date_to(date_to) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::string column;
+   std::optional<common::Date> date_from;
+   std::optional<common::Date> date_to;
 };
 
 }  // namespace filter_expressions
@@ -486,9 +559,35 @@ class Aggregated : public Action {
    std::vector<std::string> group_by_fields;
    void validateOrderByFields(const Database& database) const override;
    [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+   /// aggregated.cpp:100-149 — per partition one k_group_count launch over the dictionary ids of the fields
+   [[nodiscard]] QueryResult aggregateWithGrouping(const Database& database, std::vector<OperatorResult>& bitmap_filter) const;
 
   public:
    explicit Aggregated(std::vector<std::string> group_by_fields) : group_by_fields(std::move(group_by_fields)) {}
+};
+
+/// details.cpp: the metadata of the selected rows.  The filter runs on the device; the rows are read from the host
+/// copies of the columns.
+class Details : public Action {
+   std::vector<std::string> fields;
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   explicit Details(std::vector<std::string> fields) : fields(std::move(fields)) {}
+   [[nodiscard]] QueryResult executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+   [[nodiscard]] QueryResult finish(const Database& database, Pending& pending) const override;
+};
+
+/// fasta_aligned.cpp: primary key + the aligned sequences of the selected rows, gathered from the planes on the
+/// device (k_reconstruct_sequences).
+class FastaAligned : public Action {
+   std::vector<std::string> sequence_names;
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   explicit FastaAligned(std::vector<std::string>&& sequence_names) : sequence_names(std::move(sequence_names)) {}
 };
 
 template <typename SymbolType>

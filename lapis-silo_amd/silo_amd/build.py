@@ -52,7 +52,7 @@ def hipcc_path():
 def build_gpu(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libsilo_gpu.so")
-    sources = [os.path.join(CSRC, "silo_gpu.hip")]
+    sources = _glob(CSRC, (".hip",))
     deps = sources + _glob(CSRC, (".h",)) + _glob(INCLUDE, (".h",))
     if force or _newer(target, deps):
         _run([

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string",
+    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
@@ -49,6 +49,8 @@ def load_library():
     lib.silo_engine_finalize.argtypes = [vp]
     lib.silo_engine_set_sharding.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ALL_REDUCE_FN, vp]
     lib.silo_engine_set_broadcast.argtypes = [vp, BROADCAST_FN, vp]
+    lib.silo_engine_set_schema.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    lib.silo_engine_append_metadata.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
     lib.silo_engine_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_execute_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
@@ -220,6 +222,15 @@ class Engine:
         callback = BROADCAST_FN(trampoline)
         self._callbacks.append(callback)
         _check(self.lib.silo_engine_set_broadcast(self.handle, callback, None))
+
+    def set_schema(self, primary_key, date_to_sort_by=None):
+        _check(self.lib.silo_engine_set_schema(self.handle, primary_key.encode(), date_to_sort_by.encode() if date_to_sort_by else None))
+
+    def append_metadata(self, partition, column, column_type, values):
+        """values: texts as the metadata TSV holds them (None / '' = null); column_type as in database_config.yaml
+        plus 'indexed_string' for a string column with generateIndex."""
+        array = (ctypes.c_char_p * max(len(values), 1))(*[None if v is None else str(v).encode() for v in values])
+        _check(self.lib.silo_engine_append_metadata(self.handle, partition, column.encode(), column_type.encode(), array, len(values)))
 
     def set_option(self, name, value):
         _check(self.lib.silo_engine_set_option(self.handle, name.encode(), int(value)))

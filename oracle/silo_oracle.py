@@ -300,10 +300,9 @@ class SequenceStorePartition:
     def symbol_at(self, position, row):
         """One cell of reconstructSequence (fasta_aligned.cpp:44-83): the reference symbol, overridden by the deleted
         (most numerous) symbol of the position, by any stored bitmap that holds the row, then by the missing symbol."""
-        symbol = self.reference_sequence[position]
-        for changed_position, changed_symbol in self.indexing_differences:
-            if changed_position == position:
-                symbol = changed_symbol
+        if getattr(self, "_differences_at", None) is None or len(self._differences_at) != len(self.indexing_differences):
+            self._differences_at = dict(self.indexing_differences)  # position -> deleted symbol (one entry per position)
+        symbol = self._differences_at.get(position, self.reference_sequence[position])
         entry = self.positions[position]
         for candidate in self.alphabet.SYMBOLS:
             if candidate != entry.flipped and candidate != entry.deleted and (entry.bitmaps[candidate] >> row) & 1:

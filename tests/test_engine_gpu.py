@@ -17,6 +17,9 @@ def build_engine(data, partition_sizes=None):
 
     genomes = json.load(open(dataset.GOLDEN + "/exampleDataset/reference_genomes.json"))
     engine = Engine(genomes, data["alias"])
+    config = dataset.load_database_config()
+    engine.set_schema(config["primary_key"], config["date_to_sort_by"])
+    column_types = {"aa_insertion": "aaInsertion"}
     n = len(data["keys"])
     bounds = [0]
     for size in partition_sizes or [n]:
@@ -27,7 +30,8 @@ def build_engine(data, partition_sizes=None):
             engine.append_sequences(part, name, False, 0, genomes_list[lo:hi])
         for name, genomes_list in data["aa"].items():
             engine.append_sequences(part, name, True, 0, genomes_list[lo:hi])
-        engine.set_lineage_column(part, "pango_lineage", data["lineages"][lo:hi])
+        for column, kind in config["metadata"]:  # the lineage column also feeds the PangoLineage filter
+            engine.append_metadata(part, column, column_types.get(kind, kind), [row.get(column) or "" for row in data["rows"][lo:hi]])
     engine.finalize()
     return engine
 
@@ -263,3 +267,106 @@ def test_device_row_selection_equals_host_selection(engines):
         assert document["queryResult"] == json.loads(json.dumps(so.execute_query(oracle_db, query))), json.dumps(query)
     with pytest.raises(Exception):
         engine.set_option("no_such_option", 1)
+
+
+# ---- metadata predicates, Aggregated with groupByFields, Details, FastaAligned -------------
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("queries_next"), ids=lambda c: c["file"])
+def test_reference_e2e_next_row_goldens(engines, case):
+    engine, _ = engines
+
+    def execute(query):
+        status, document = engine.execute_raw(query)
+        assert status == 200, document
+        return document["queryResult"]
+
+    dataset.check_next_row_case(case, execute)
+
+
+@pytest.mark.parametrize("case", dataset.load_query_fixtures("invalidQueries_next"), ids=lambda c: c["file"])
+def test_reference_e2e_next_row_invalid_goldens(engines, case):
+    engine, _ = engines
+    status, document = engine.execute_raw(case["query"])
+    assert status == 400
+    assert document == case["expectedError"]
+
+
+def random_metadata_leaf(rng):
+    kind = rng.choice(["string", "indexed", "int_eq", "int_between", "float_eq", "float_between", "date", "unsorted_date"])
+    if kind == "string":
+        return {"type": "StringEquals", "column": "gisaid_epi_isl", "value": rng.choice(["EPI_ISL_1749899", "EPI_ISL_1408408", "nope", None])}
+    if kind == "indexed":
+        column, values = rng.choice([("country", ["Switzerland", "Germany", None, ""]), ("division", ["Bern", "Aargau", "Zürich", None, "x"]),
+                                     ("region", ["Europe", "Asia"])])
+        return {"type": "StringEquals", "column": column, "value": rng.choice(values)}
+    if kind == "int_eq":
+        return {"type": "IntEquals", "column": "age", "value": rng.choice([4, 50, 54, 0, None])}
+    if kind == "int_between":
+        return {"type": "IntBetween", "column": "age", "from": rng.choice([None, 0, 30, 55]), "to": rng.choice([None, 40, 60, 10])}
+    if kind == "float_eq":
+        return {"type": "FloatEquals", "column": "qc_value", "value": rng.choice([0.9, 0.98, 0.5, None])}
+    if kind == "float_between":
+        return {"type": "FloatBetween", "column": "qc_value", "from": rng.choice([None, 0.9, 0.95]), "to": rng.choice([None, 0.93, 0.99])}
+    column = "date" if kind == "date" else "unsorted_date"
+    return {"type": "DateBetween", "column": column, "from": rng.choice([None, "2021-01-01", "2020-11-24", "bogus"]),
+            "to": rng.choice([None, "2021-03-18", "2021-06-01", "2020-12-31"])}
+
+
+def random_mixed_expression(rng, depth):
+    if depth == 0 or rng.random() < 0.3:
+        return random_metadata_leaf(rng) if rng.random() < 0.6 else random_leaf(rng)
+    kind = rng.choice(["And", "And", "Or", "Not", "N-Of", "Maybe"])
+    if kind in ("And", "Or"):
+        return {"type": kind, "children": [random_mixed_expression(rng, depth - 1) for _ in range(rng.randint(0, 4))]}
+    if kind == "N-Of":
+        k = rng.randint(1, 4)
+        return {"type": "N-Of", "children": [random_mixed_expression(rng, depth - 1) for _ in range(k)],
+                "numberOfMatchers": rng.randint(0, k), "matchExactly": rng.random() < 0.5}
+    return {"type": kind, "child": random_mixed_expression(rng, depth - 1)}
+
+
+def as_multiset(rows):
+    return sorted(json.dumps(row, sort_keys=True) for row in rows)
+
+
+def test_random_metadata_filters_match_oracle(engines):
+    """Metadata predicates mixed with sequence predicates under And / Or / Not / N-Of (the Selection operator, its
+    comparator-negating Not and its merge into And) against the oracle."""
+    engine, oracle_db = engines
+    rng = random.Random(606)
+    for trial in range(200):
+        query = {"action": {"type": "Aggregated"}, "filterExpression": random_mixed_expression(rng, 3)}
+        assert engine.execute_query(query) == so.execute_query(oracle_db, query), json.dumps(query)
+
+
+def test_random_group_by_and_details_match_oracle(engines):
+    engine, oracle_db = engines
+    rng = random.Random(707)
+    columns = ["gisaid_epi_isl", "date", "unsorted_date", "region", "country", "pango_lineage", "division", "age", "qc_value",
+               "nucleotideInsertions", "aminoAcidInsertions"]
+    for trial in range(40):
+        expression = random_mixed_expression(rng, 2)
+        group_by = rng.sample(columns, rng.randint(1, 3))
+        query = {"action": {"type": "Aggregated", "groupByFields": group_by}, "filterExpression": expression}
+        want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+        got = engine.execute_query(query)
+        assert as_multiset(got) == as_multiset(want), json.dumps(query)  # row order is unspecified without orderByFields
+        # Details ordered by the primary key (unique): exact row order
+        fields = rng.sample(columns, rng.randint(1, 4))
+        action = {"type": "Details", "fields": fields + ["gisaid_epi_isl"],
+                  "orderByFields": [{"field": rng.choice(fields), "order": rng.choice(["ascending", "descending"])}, "gisaid_epi_isl"]}
+        if rng.random() < 0.5:
+            action["limit"] = rng.randint(0, 30)
+        if rng.random() < 0.5:
+            action["offset"] = rng.randint(0, 10)
+        query = {"action": action, "filterExpression": expression}
+        want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+        assert engine.execute_query(query) == want, json.dumps(query)
+
+
+def test_fasta_aligned_matches_oracle(engines):
+    engine, oracle_db = engines
+    query = {"action": {"type": "FastaAligned", "sequenceName": ["main", "S", "testSecondSequence"], "orderByFields": ["gisaid_epi_isl"]},
+             "filterExpression": {"type": "IntBetween", "column": "age", "from": 50, "to": 52}}
+    want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+    got = engine.execute_query(query)
+    assert len(got) > 0 and got == want
