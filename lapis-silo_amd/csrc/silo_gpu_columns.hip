@@ -6,6 +6,8 @@
 //                               dictionary ids of the filtered rows
 //
 // Both stream a 4- or 8-byte column once (HBM-bound, 4..8 B per row) and write 1 bit / a few counters per row.
+#include <algorithm>
+
 #include "internal.h"
 
 namespace {
@@ -22,21 +24,34 @@ __device__ __forceinline__ bool compareValues(T row_value, int comparator, T val
    }
 }
 
-// One wave per bitset word: lane l tests row 64 * word + l (a coalesced 256- or 512-byte read per wave), the
-// ballot is the word.  Words past the last row (row padding) are written as zero.
+// One wave per COMPARE_WORDS bitset words: lane l tests rows 64 * word + l of each of them — COMPARE_WORDS
+// independent, fully coalesced 256- or 512-byte reads in flight per wave — and the ballot of each test is the
+// word.  Words past the last row (row padding) are written as zero.
+constexpr uint32_t COMPARE_WORDS = 8;
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_bitset_from_compare(
    const T* __restrict__ values, uint32_t n_rows, uint32_t row_words, int comparator, T value, uint64_t* __restrict__ out
 ) {
-   const uint32_t word = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-   if (word >= row_words) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t first_word = (blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * COMPARE_WORDS;
+   if (first_word >= row_words) {
       return;
    }
-   const uint32_t row = word * 64 + (threadIdx.x & 63u);
-   const bool match = row < n_rows && compareValues<T>(values[row], comparator, value);
-   const uint64_t ballot = __ballot(match);
-   if ((threadIdx.x & 63u) == 0) {
-      out[word] = ballot;
+   T row_values[COMPARE_WORDS];
+#pragma unroll
+   for (uint32_t k = 0; k < COMPARE_WORDS; ++k) {
+      const uint32_t row = (first_word + k) * 64 + lane;
+      row_values[k] = row < n_rows ? values[row] : value;
+   }
+#pragma unroll
+   for (uint32_t k = 0; k < COMPARE_WORDS; ++k) {
+      const uint32_t row = (first_word + k) * 64 + lane;
+      const bool match = row < n_rows && compareValues<T>(row_values[k], comparator, value);
+      const uint64_t ballot = __ballot(match);
+      if (lane == 0 && first_word + k < row_words) {
+         out[first_word + k] = ballot;
+      }
    }
 }
 
@@ -49,67 +64,106 @@ struct GroupCountArgs {
    uint32_t n_columns;
 };
 
-// Adds one to bins[key] for every active lane; lanes that share the key of the first active lane are counted by
-// one atomic (a few rounds of that take the sting out of skewed columns, where most rows fall into one group).
+// Adds one to bins[key] for every active lane.  The lanes that share the key of the first active lane are counted
+// by ONE atomic (takes the sting out of skewed columns, where most rows of a wave fall into one group); the rest
+// add individually.
 template <typename Add>
 __device__ __forceinline__ void aggregatedIncrement(bool active, uint32_t key, Add add) {
-#pragma unroll 1
-   for (int round = 0; round < 4; ++round) {
-      const uint64_t pending = __ballot(active);
-      if (pending == 0) {
-         return;
-      }
-      const int leader = __ffsll(static_cast<long long>(pending)) - 1;
-      const uint32_t leader_key = __shfl(key, leader);
-      const bool same = active && key == leader_key;
-      const uint64_t group = __ballot(same);
-      if (static_cast<int>(threadIdx.x & 63u) == leader) {
-         add(leader_key, static_cast<uint32_t>(__popcll(group)));
-      }
-      active = active && !same;
+   const uint64_t pending = __ballot(active);
+   if (pending == 0) {
+      return;
    }
-   if (active) {
+   const int leader = __ffsll(static_cast<long long>(pending)) - 1;
+   const uint32_t leader_key = __shfl(key, leader);
+   const bool same = active && key == leader_key;
+   const uint64_t group = __ballot(same);
+   if (static_cast<int>(threadIdx.x & 63u) == leader) {
+      add(leader_key, static_cast<uint32_t>(__popcll(group)));
+   } else if (active && !same) {
       add(key, 1u);
    }
 }
 
-template <bool USE_LDS>
+// Blocks walk the rows in chunks of 256 * GROUP_ROWS_PER_THREAD (grid-stride, about two blocks per CU, so the
+// per-block flush of the LDS table is paid a few hundred times, not once per chunk); the ids of all of a thread's
+// rows of a chunk are fetched first (GROUP_ROWS_PER_THREAD independent coalesced loads per column in flight), then
+// counted.
+//   DENSE  (n_bins <= GROUP_LDS_BINS): the whole histogram lives in LDS, in `copies` interleaved replicas
+//          (bin * copies + lane % copies) so that lanes of a wave that hit the same small bin use different banks.
+//   !DENSE (up to SILO_GPU_MAX_GROUP_BINS bins): LDS holds a direct-mapped cache key -> count; a key that loses
+//          its slot to another key goes to the global table at once.  Hot groups stay in LDS and reach HBM once
+//          per block.
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_group_count(
-   const uint64_t* __restrict__ filter, uint32_t n_rows, const GroupCountArgs args, uint32_t n_bins, uint32_t* __restrict__ counts
+   const uint64_t* __restrict__ filter, uint32_t n_rows, const GroupCountArgs args, uint32_t n_bins, uint32_t copies,
+   uint32_t* __restrict__ counts
 ) {
-   __shared__ uint32_t s_bins[USE_LDS ? GROUP_LDS_BINS : 1];
-   if (USE_LDS) {
-      for (uint32_t bin = threadIdx.x; bin < n_bins; bin += blockDim.x) {
-         s_bins[bin] = 0;
+   __shared__ uint32_t s_counts[GROUP_LDS_BINS];
+   __shared__ uint32_t s_keys[DENSE ? 1 : GROUP_LDS_BINS];  // key + 1, 0 = free
+   for (uint32_t slot = threadIdx.x; slot < GROUP_LDS_BINS; slot += blockDim.x) {
+      s_counts[slot] = 0;
+      if (!DENSE) {
+         s_keys[slot] = 0;
       }
-      __syncthreads();
    }
-   const uint32_t block_first = blockIdx.x * (blockDim.x * GROUP_ROWS_PER_THREAD);
-#pragma unroll 1
-   for (uint32_t step = 0; step < GROUP_ROWS_PER_THREAD; ++step) {
-      const uint32_t row = block_first + step * blockDim.x + threadIdx.x;  // consecutive lanes, consecutive rows
-      bool active = row < n_rows;
-      if (active && filter != nullptr) {
-         active = (filter[row >> 6] >> (row & 63u)) & 1u;
-      }
-      uint32_t key = 0;
-      if (active) {
-         for (uint32_t column = 0; column < args.n_columns; ++column) {
-            key += args.ids[column][row] * args.strides[column];
+   __syncthreads();
+   const uint32_t lane_copy = (threadIdx.x & 63u) & (copies - 1);
+   const auto add = [&](uint32_t key, uint32_t n) {
+      if (DENSE) {
+         atomicAdd(&s_counts[key * copies + lane_copy], n);
+      } else {
+         const uint32_t slot = (key * 2654435761u) >> 20;  // 12 bits: GROUP_LDS_BINS slots
+         const uint32_t owner = atomicCAS(&s_keys[slot], 0u, key + 1);
+         if (owner == 0 || owner == key + 1) {
+            atomicAdd(&s_counts[slot], n);
+         } else {
+            atomicAdd(&counts[key], n);
          }
       }
-      if (USE_LDS) {
-         aggregatedIncrement(active, key, [&](uint32_t bin, uint32_t n) { atomicAdd(&s_bins[bin], n); });
-      } else {
-         aggregatedIncrement(active, key, [&](uint32_t bin, uint32_t n) { atomicAdd(&counts[bin], n); });
+   };
+   constexpr uint32_t CHUNK = 256 * GROUP_ROWS_PER_THREAD;
+   for (uint32_t chunk_first = blockIdx.x * CHUNK; chunk_first < n_rows; chunk_first += gridDim.x * CHUNK) {
+      uint32_t keys[GROUP_ROWS_PER_THREAD];
+      uint32_t active_mask = 0;
+#pragma unroll
+      for (uint32_t step = 0; step < GROUP_ROWS_PER_THREAD; ++step) {
+         const uint32_t row = chunk_first + step * blockDim.x + threadIdx.x;  // consecutive lanes, consecutive rows
+         bool active = row < n_rows;
+         if (active && filter != nullptr) {
+            active = (filter[row >> 6] >> (row & 63u)) & 1u;
+         }
+         active_mask |= (active ? 1u : 0u) << step;
+         keys[step] = 0;
+      }
+      for (uint32_t column = 0; column < args.n_columns; ++column) {
+         const uint32_t* ids = args.ids[column];
+         const uint32_t stride = args.strides[column];
+#pragma unroll
+         for (uint32_t step = 0; step < GROUP_ROWS_PER_THREAD; ++step) {
+            const uint32_t row = min(chunk_first + step * blockDim.x + threadIdx.x, n_rows - 1);
+            keys[step] += ids[row] * stride;
+         }
+      }
+#pragma unroll
+      for (uint32_t step = 0; step < GROUP_ROWS_PER_THREAD; ++step) {
+         aggregatedIncrement((active_mask >> step) & 1u, keys[step], add);
       }
    }
-   if (USE_LDS) {
-      __syncthreads();
+   __syncthreads();
+   if (DENSE) {
       for (uint32_t bin = threadIdx.x; bin < n_bins; bin += blockDim.x) {
-         const uint32_t n = s_bins[bin];
+         uint32_t n = 0;
+         for (uint32_t copy = 0; copy < copies; ++copy) {
+            n += s_counts[bin * copies + copy];
+         }
          if (n != 0) {
             atomicAdd(&counts[bin], n);
+         }
+      }
+   } else {
+      for (uint32_t slot = threadIdx.x; slot < GROUP_LDS_BINS; slot += blockDim.x) {
+         if (s_keys[slot] != 0) {
+            atomicAdd(&counts[s_keys[slot] - 1], s_counts[slot]);
          }
       }
    }
@@ -137,7 +191,7 @@ int silo_gpu_bitset_from_compare(
    const uint32_t n_rows = silo_gpu_store_sequence_count(store);
    const uint32_t row_words = silo_gpu_store_row_words(store);
    auto hip_stream = static_cast<hipStream_t>(stream);
-   const dim3 grid((row_words + 3) / 4);
+   const dim3 grid((row_words + 4 * COMPARE_WORDS - 1) / (4 * COMPARE_WORDS));
    switch (value_type) {
       case SILO_GPU_VALUE_I32:
          k_bitset_from_compare<int32_t><<<grid, 256, 0, hip_stream>>>(
@@ -191,12 +245,17 @@ int silo_gpu_group_count(
       return SILO_GPU_OK;
    }
    auto hip_stream = static_cast<hipStream_t>(stream);
-   const uint32_t rows_per_block = 256 * GROUP_ROWS_PER_THREAD;
-   const dim3 grid((n_rows + rows_per_block - 1) / rows_per_block);
+   const uint32_t rows_per_chunk = 256 * GROUP_ROWS_PER_THREAD;
+   const uint32_t n_chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
+   const dim3 grid(std::min<uint32_t>(n_chunks, 512));  // ~2 blocks per CU, each walks its share of the chunks
    if (n_bins <= GROUP_LDS_BINS) {
-      k_group_count<true><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), counts_dev);
+      uint32_t copies = 1;  // replicas of the LDS histogram: the largest power of two <= min(32, GROUP_LDS_BINS / n_bins)
+      while (copies < 32 && static_cast<uint64_t>(copies) * 2 * n_bins <= GROUP_LDS_BINS) {
+         copies *= 2;
+      }
+      k_group_count<true><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), copies, counts_dev);
    } else {
-      k_group_count<false><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), counts_dev);
+      k_group_count<false><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), 1, counts_dev);
    }
    SILO_HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;

@@ -289,8 +289,14 @@ std::unordered_map<std::string, std::string> readFlatYaml(const std::string& pat
 
 struct DatabaseSchema {
    std::string primary_key;
+   std::optional<std::string> date_to_sort_by;
    std::optional<std::string> default_nucleotide_sequence;
-   std::vector<std::string> pango_lineage_columns;
+   struct Column {
+      std::string name;
+      std::string type;
+      bool generate_index = false;
+   };
+   std::vector<Column> metadata;  // in file order
 };
 
 DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config.cpp:47-90
@@ -300,7 +306,6 @@ DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config
       throw PreprocessingException("cannot open " + path);
    }
    std::string line;
-   std::string current_name;
    while (std::getline(stream, line)) {
       const auto colon = line.find(':');
       if (colon == std::string::npos) {
@@ -308,21 +313,70 @@ DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config
       }
       std::string key = unquote(line.substr(0, colon));
       const std::string value = unquote(line.substr(colon + 1));
+      bool starts_item = false;
       if (!key.empty() && key.front() == '-') {
          key = unquote(key.substr(1));
+         starts_item = true;
+      }
+      if (starts_item) {
+         schema.metadata.emplace_back();
       }
       if (key == "primaryKey") {
          schema.primary_key = value;
+      } else if (key == "dateToSortBy") {
+         schema.date_to_sort_by = value;
       } else if (key == "defaultNucleotideSequence") {
          schema.default_nucleotide_sequence = value;
-      } else if (key == "name") {
-         current_name = value;
-      } else if (key == "type" && value == "pango_lineage" && !current_name.empty()) {
-         schema.pango_lineage_columns.push_back(current_name);
+      } else if (key == "name" && !schema.metadata.empty()) {
+         schema.metadata.back().name = value;
+      } else if (key == "type" && !schema.metadata.empty()) {
+         schema.metadata.back().type = value;
+      } else if (key == "generateIndex" && !schema.metadata.empty()) {
+         schema.metadata.back().generate_index = value == "true";
+      }
+   }
+   for (const auto& column : schema.metadata) {
+      if (column.name.empty() || !config::columnTypeFromConfig(column.type, column.generate_index).has_value()) {
+         throw PreprocessingException("database config " + path + ": metadata entry '" + column.name + "' has no valid name / type");
       }
    }
    return schema;
 }
+
+/// Rows of the metadata columns, staged as text and handed to the database in batches.
+class MetadataWriter {
+  public:
+   MetadataWriter(Database& database, DatabasePartition& partition, const DatabaseSchema& schema) : database(database), partition(partition) {
+      for (const auto& column : schema.metadata) {
+         columns.push_back({column.name, *config::columnTypeFromConfig(column.type, column.generate_index), {}});
+      }
+   }
+   [[nodiscard]] size_t size() const { return columns.size(); }
+   [[nodiscard]] const std::string& name(size_t column) const { return columns[column].name; }
+   void add(size_t column, std::string value) { columns[column].values.push_back(std::move(value)); }
+   void rowDone() {
+      if (!columns.empty() && columns.front().values.size() >= BATCH) {
+         flush();
+      }
+   }
+   void flush() {
+      for (auto& column : columns) {
+         database.appendMetadata(partition, column.name, column.type, column.values);
+         column.values.clear();
+      }
+   }
+
+  private:
+   static constexpr size_t BATCH = 65536;
+   struct Column {
+      std::string name;
+      config::ColumnType type;
+      std::vector<std::string> values;
+   };
+   Database& database;
+   DatabasePartition& partition;
+   std::vector<Column> columns;
+};
 
 // ---- staging of one sequence store: batches of equal-length rows appended to the device ---------------------
 class StoreWriter {
@@ -444,7 +498,11 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
    DatasetSummary summary;
    summary.nucleotide_stores = database.nuc_sequences.size();
    summary.amino_acid_stores = database.aa_sequences.size();
-   summary.lineage_columns = schema.pango_lineage_columns.size();
+   for (const auto& column : schema.metadata) {
+      summary.lineage_columns += column.type == "pango_lineage" ? 1 : 0;
+   }
+   database.database_config.primary_key = schema.primary_key;
+   database.database_config.date_to_sort_by = schema.date_to_sort_by;
 
    const bool from_ndjson = config.count("ndjsonInputFilename") != 0;
    const std::string input_path = (root / (from_ndjson ? config["ndjsonInputFilename"] : setting("metadataFilename", "metadata.tsv"))).string();
@@ -466,12 +524,7 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
       throw PreprocessingException("more than 2^32 rows in one partition");
    }
    DatabasePartition& partition = database.addPartition(static_cast<uint32_t>(rows));
-   std::vector<storage::column::PangoLineageColumnPartition*> lineage_columns;
-   for (const std::string& column : schema.pango_lineage_columns) {
-      lineage_columns.push_back(&partition.columns.pango_lineage_columns
-                                    .emplace(std::piecewise_construct, std::forward_as_tuple(column), std::forward_as_tuple(database.alias_key, partition))
-                                    .first->second);
-   }
+   MetadataWriter metadata_writer(database, partition, schema);
    std::vector<std::pair<std::string, StoreWriter>> nuc_writers;
    std::vector<std::pair<std::string, StoreWriter>> aa_writers;
    for (const auto& [name, store] : partition.nuc_sequences) {
@@ -490,14 +543,17 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          }
          const json::Value record = json::parse(line);
          const json::Value& metadata = record.at("metadata");
-         for (size_t k = 0; k < lineage_columns.size(); ++k) {
-            const std::string& column = schema.pango_lineage_columns[k];
-            if (metadata.contains(column) && metadata[column].is_string()) {
-               lineage_columns[k]->insert(metadata[column].as_string());
+         for (size_t k = 0; k < metadata_writer.size(); ++k) {
+            const std::string& column = metadata_writer.name(k);
+            if (!metadata.contains(column) || metadata[column].is_null()) {
+               metadata_writer.add(k, "");
+            } else if (metadata[column].is_string()) {
+               metadata_writer.add(k, metadata[column].as_string());
             } else {
-               lineage_columns[k]->insertNull();
+               metadata_writer.add(k, metadata[column].dump());  // numbers in their JSON text form
             }
          }
+         metadata_writer.rowDone();
          const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const char* section) {
             static const json::Value missing_section;
             const json::Value& sequences = record.contains(section) ? record[section] : missing_section;
@@ -529,9 +585,9 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             return static_cast<size_t>(found - header.begin());
          };
          const size_t key_column = column_of(schema.primary_key);
-         std::vector<size_t> lineage_column_index;
-         for (const std::string& column : schema.pango_lineage_columns) {
-            lineage_column_index.push_back(column_of(column));
+         std::vector<size_t> metadata_column_index;
+         for (size_t k = 0; k < metadata_writer.size(); ++k) {
+            metadata_column_index.push_back(column_of(metadata_writer.name(k)));
          }
          while (reader.next(line)) {
             if (line.find_first_not_of(" \t") == std::string::npos) {
@@ -539,10 +595,11 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             }
             const std::vector<std::string> fields = splitTabs(line);
             keys.push_back(key_column < fields.size() ? fields[key_column] : "");
-            for (size_t k = 0; k < lineage_columns.size(); ++k) {
-               const size_t index = lineage_column_index[k];
-               lineage_columns[k]->insert(index < fields.size() ? fields[index] : "");
+            for (size_t k = 0; k < metadata_writer.size(); ++k) {
+               const size_t index = metadata_column_index[k];
+               metadata_writer.add(k, index < fields.size() ? fields[index] : "");
             }
+            metadata_writer.rowDone();
          }
       }
       const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const std::string& prefix) {
@@ -568,6 +625,7 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
    for (auto& [name, writer] : aa_writers) {
       writer.flush();
    }
+   metadata_writer.flush();
    database.finalize();
    return summary;
 }

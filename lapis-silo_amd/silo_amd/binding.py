@@ -137,6 +137,10 @@ def load_library():
     lib.silo_gpu_mutations_scan.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
     lib.silo_gpu_mutations_scan_batch.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), vp]
     lib.silo_gpu_memset_async.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
+    lib.silo_gpu_upload_column.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.silo_gpu_bitset_from_compare.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.silo_gpu_group_count.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_reconstruct_sequences.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp]
     lib.silo_gpu_event_create.argtypes = [ctypes.POINTER(vp)]
     lib.silo_gpu_event_record.argtypes = [vp, vp]
     lib.silo_gpu_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
@@ -426,6 +430,52 @@ class GpuStore:
         for o in outs:
             self.free(o)
         return tables
+
+    # ---- metadata columns (K5 / K6) and FastaAligned ---------------------------------------------
+    VALUE_TYPES = {np.dtype(np.int32): 0, np.dtype(np.uint32): 1, np.dtype(np.float64): 2}
+    COMPARATORS = {"==": 0, "!=": 1, "<": 2, ">=": 3, ">": 4, "<=": 5}
+
+    def upload_column(self, values):
+        """int32 / uint32 / float64 array with one value per row -> device pointer (free with self.free)."""
+        values = np.ascontiguousarray(values)
+        out = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_upload_column(values.ctypes.data_as(ctypes.c_void_p), len(values), self.VALUE_TYPES[values.dtype], ctypes.byref(out)))
+        return out
+
+    def bitset_from_compare(self, column_ptr, dtype, comparator, value, stream=None):
+        """Row bitset (as downloaded words) of `column <comparator> value`."""
+        dtype = np.dtype(dtype)
+        scalar = np.array([value], dtype=dtype)
+        out = self.bitset_alloc()
+        _check(self.lib.silo_gpu_bitset_from_compare(
+            self.handle, out, column_ptr, self.VALUE_TYPES[dtype], self.COMPARATORS[comparator], scalar.ctypes.data_as(ctypes.c_void_p), stream))
+        words = self.bitset_download(out, stream)
+        self.free(out)
+        return words
+
+    def group_count(self, filter_ptr, id_ptrs, cardinalities, stream=None):
+        """Histogram of the mixed-radix tuple ids (first column most significant) of the filtered rows."""
+        n_bins = int(np.prod(cardinalities, dtype=np.int64))
+        counts = self.malloc(4 * n_bins)
+        self.memset(counts, 0, 4 * n_bins, stream)
+        ids = (ctypes.c_void_p * len(id_ptrs))(*[p.value for p in id_ptrs])
+        cards = (ctypes.c_uint32 * len(cardinalities))(*cardinalities)
+        _check(self.lib.silo_gpu_group_count(self.handle, filter_ptr, ids, cards, len(id_ptrs), counts, stream))
+        out = self.read(counts, np.uint32, n_bins, stream)
+        self.free(counts)
+        return out
+
+    def reconstruct_sequences(self, seqstore_id, rows, stream=None):
+        """The stored characters of the given rows: uint8 array [len(rows)][positions]."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        positions = self.positions(seqstore_id)
+        rows_dev = self.upload_column(rows)
+        out = self.malloc(max(1, len(rows) * positions))
+        _check(self.lib.silo_gpu_reconstruct_sequences(self.handle, seqstore_id, rows_dev, len(rows), out, stream))
+        chars = self.read(out, np.uint8, len(rows) * positions, stream).reshape(len(rows), positions)
+        self.free(out)
+        self.free(rows_dev)
+        return chars
 
     def last_scan_kernel(self):
         return self.lib.silo_gpu_last_scan_kernel().decode()

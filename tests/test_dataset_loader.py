@@ -65,9 +65,17 @@ def run_goldens(engine):
         status, document = engine.execute_raw(case["query"])
         assert status == 200, (case["file"], document)
         assert document == {"queryResult": case["expectedQueryResult"]}, case["file"]
-    for case in dataset.load_query_fixtures("invalidQueries"):
+    for case in dataset.load_query_fixtures("invalidQueries") + dataset.load_query_fixtures("invalidQueries_next"):
         status, document = engine.execute_raw(case["query"])
         assert (status, document) == (400, case["expectedError"]), case["file"]
+
+    def execute(query):
+        status, document = engine.execute_raw(query)
+        assert status == 200, document
+        return document["queryResult"]
+
+    for case in dataset.load_query_fixtures("queries_next"):  # metadata columns read from the TSV / ndjson
+        dataset.check_next_row_case(case, execute)
 
 
 @pytest.mark.gpu

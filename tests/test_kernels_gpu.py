@@ -207,3 +207,71 @@ def test_batched_scan_matches_single_scans(built, n, alphabet):
             tables = store.mutations_scan_batch(0, ptrs[:count], 2, 17)
             for mask, table in zip(masks, tables):
                 assert np.array_equal(table, dense.mutation_counts(sym, mask, scan_symbols, 2, 17)), count
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 250007])
+def test_column_compare_matches_numpy(built, n):
+    """K5: every comparator on int32 / uint32 / float64 columns, NULL markers and NaN included."""
+    rng = np.random.default_rng(n)
+    ref = np.ones(4, dtype=np.uint8)
+    ints = rng.integers(-5, 60, size=n).astype(np.int32)
+    ints[rng.random(n) < 0.05] = np.iinfo(np.int32).min
+    words = rng.integers(0, 1 << 30, size=n).astype(np.uint32)
+    words[rng.random(n) < 0.3] = 7
+    floats = rng.choice([0.9, 0.93, 0.98, -0.0, 0.0, 1e300], size=n)
+    floats[rng.random(n) < 0.1] = np.nan
+    operators = {"==": np.equal, "!=": np.not_equal, "<": np.less, ">=": np.greater_equal, ">": np.greater, "<=": np.less_equal}
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        for column, probes in ((ints, [0, 30, np.iinfo(np.int32).min, -3]), (words, [7, 0, 1 << 29]), (floats, [0.93, 0.0, np.nan, 2.0])):
+            pointer = store.upload_column(column)
+            for probe in probes:
+                for name, function in operators.items():
+                    with np.errstate(invalid="ignore"):
+                        want = function(column, column.dtype.type(probe))
+                    got = store.bitset_from_compare(pointer, column.dtype, name, probe)
+                    assert np.array_equal(dense.unpack_bits(got, n), want), (column.dtype, name, probe)
+                    assert not dense.unpack_bits(got, store.row_words * 64)[n:].any()
+            store.free(pointer)
+
+
+@pytest.mark.parametrize("n", [1, 777, 300001])
+def test_group_count_matches_numpy(built, n):
+    """K6: LDS-privatised and global histograms, skewed and uniform ids, with and without a filter."""
+    rng = np.random.default_rng(n + 1)
+    ref = np.ones(4, dtype=np.uint8)
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        filt = rng.random(n) < 0.4
+        fptr = store.bitset_alloc()
+        store.bitset_upload(fptr, dense.pack_bits(filt))
+        for cardinalities in ([3], [60, 50], [2, 3, 5, 7], [5000], [300, 200]):
+            columns = []
+            for cardinality in cardinalities:
+                ids = rng.integers(0, cardinality, size=n).astype(np.uint32)
+                ids[rng.random(n) < 0.7] = cardinality // 2  # one dominant group
+                columns.append(ids)
+            pointers = [store.upload_column(ids) for ids in columns]
+            key = np.zeros(n, dtype=np.int64)
+            for ids, cardinality in zip(columns, cardinalities):
+                key = key * cardinality + ids
+            n_bins = int(np.prod(cardinalities))
+            assert np.array_equal(store.group_count(fptr, pointers, cardinalities), np.bincount(key[filt], minlength=n_bins))
+            assert np.array_equal(store.group_count(None, pointers, cardinalities), np.bincount(key, minlength=n_bins))
+            for pointer in pointers:
+                store.free(pointer)
+
+
+def test_reconstruct_sequences_matches_input(built):
+    """FastaAligned gather: every stored character comes back, IUPAC codes (sparse planes) and null genomes included."""
+    rng = np.random.default_rng(5)
+    n, positions = 3000, 97
+    for alphabet, chars_of in (("nuc", NUC_CHARS), ("aa", AA_CHARS)):
+        sym = random_symbols(rng, n, positions, alphabet)
+        is_null = (rng.random(n) < 0.02).astype(np.uint8)
+        with make_store(n, [dict(name="s", alphabet=alphabet, reference=sym[0].copy())]) as store:
+            store.append_sequences(0, 0, chars_of[sym], is_null)
+            store.finalize()
+            expected = chars_of[sym].copy()
+            expected[is_null.astype(bool)] = ord("N" if alphabet == "nuc" else "X")
+            rows = np.concatenate([[0, n - 1], rng.choice(n, size=200, replace=False), np.nonzero(is_null)[0][:5]]).astype(np.uint32)
+            got = store.reconstruct_sequences(0, rows)
+            assert np.array_equal(got, expected[rows])
