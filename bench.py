@@ -50,7 +50,7 @@ def load_reference_genomes(with_genes=False):
             "genes": genomes["genes"] if with_genes else []}
 
 
-def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False):
+def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False):
     from silo_amd import alphabet, synth
     from silo_amd.engine import Engine
 
@@ -72,6 +72,8 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
         gene_model = synth.make_model(n_sequences, gene_reference, "aa", tree, lineage, seed=synth.DEFAULT_SEED, store_index=index + 1)
         engine.generate_synthetic(partition, gene["name"], True, gene_model, engine.position_window(gene["name"], True))
     engine.set_lineage_column_ids(partition, "pango_lineage", tree.names, lineage)
+    if with_metadata:
+        add_synthetic_metadata(engine, partition, n_sequences)
     engine.finalize()
     return engine, model, tree, lineage, window
 
@@ -274,6 +276,50 @@ def batch_workload(engine, positions, n_sequences, sync, reps=5):
     }
 
 
+def metadata_workload(engine, n_sequences, sync, seconds=1.0):
+    """SURVEY.md §8(f) row 3 on the 1 M-sequence engine: metadata predicates feeding the filter program (K5) and
+    Aggregated with groupByFields (K6); latency per query through executeQuery."""
+    lineage_filter = json.loads(make_query())["filterExpression"]
+    queries = {
+        "filter: country = C7 AND age in [20,40] AND lineage B.1* -> Aggregated": {
+            "action": {"type": "Aggregated"},
+            "filterExpression": {"type": "And", "children": [
+                {"type": "StringEquals", "column": "country", "value": "C7"},
+                {"type": "IntBetween", "column": "age", "from": 20, "to": 40}, lineage_filter]}},
+        "group by country (50 groups), lineage B.1* filter": {
+            "action": {"type": "Aggregated", "groupByFields": ["country"], "orderByFields": ["country"]}, "filterExpression": lineage_filter},
+        "group by country x age (5000 groups), all rows": {
+            "action": {"type": "Aggregated", "groupByFields": ["country", "age"], "orderByFields": ["country", "age"]},
+            "filterExpression": {"type": "True"}},
+    }
+    out = {}
+    for label, query in queries.items():
+        wire = json.dumps(query).encode()
+        status, body = engine.execute_text(wire)
+        if status != 200:
+            raise RuntimeError(body.decode())
+        rows = json.loads(body.decode())["queryResult"]
+        for _ in range(3):
+            engine.execute_text(wire)
+        sync()
+        n = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            engine.execute_text(wire)
+            n += 1
+        out[label] = {"latency_us": (time.perf_counter() - t0) / n * 1e6, "rows": len(rows),
+                      "count": sum(row["count"] for row in rows)}
+    return {"workload": f"metadata predicates and group-by, {n_sequences} sequences (synthetic country / age columns)", "queries": out}
+
+
+def add_synthetic_metadata(engine, partition, n_sequences):
+    rng = np.random.default_rng(12345)
+    country = rng.integers(0, 50, size=n_sequences)
+    age = rng.integers(0, 100, size=n_sequences)
+    engine.append_metadata(partition, "country", "indexed_string", [f"C{c}" for c in country])
+    engine.append_metadata(partition, "age", "int", [str(a) for a in age])
+
+
 def run_steps(engine, query, steps, warmup, sync):
     query = query.encode()
     for _ in range(warmup):
@@ -443,7 +489,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_also and args.sequences != 1_000_000:
         # BASELINE.json configs[1]: 1 M sequences, same query
-        engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank, with_genes=True)  # no collective
+        engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank, with_genes=True, with_metadata=True)  # no collective
         elapsed1, rows1 = run_steps(engine1, query, args.steps, args.warmup, sync)
         # amino-acid leg of BASELINE.json configs[3]: all 12 genes (9 814 positions x 22 symbols), same filter
         aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
@@ -470,6 +516,7 @@ def main():
             "roofline_frac": alg1 / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "mutation_rows": len(rows1),
         }
+        result["also_metadata"] = metadata_workload(engine1, 1_000_000, sync)
         lib.silo_gpu_free(filt1)
         lib.silo_gpu_free(counts1)
         engine1.close()
