@@ -237,6 +237,20 @@ int silo_gpu_group_count(
    const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* const* group_ids_dev, const uint32_t* cardinalities,
    uint32_t n_columns, uint32_t* counts_dev, void* stream
 );
+/* Insertion index on the device (insertion_index.cpp, insertions.cpp:186-221).  The occurrences of a column's
+ * insertions in one sequence are n_pairs pairs (rows_dev[k], ids_dev[k]): row k carries the distinct insertion
+ * ids_dev[k] (< n_ids).  silo_gpu_bitset_from_pairs: dst = rows of the pairs whose insertion is a member
+ * (membership_by_id on the host: the distinct insertions the search pattern matched, InsertionContains);
+ * silo_gpu_count_pairs: counts_dev[id] += number of pairs of that insertion whose row is in the filter (NULL = all
+ * rows), the and_cardinality per insertion of the Insertions action. */
+int silo_gpu_bitset_from_pairs(
+   const silo_gpu_store* store, uint64_t* dst_dev, const uint32_t* rows_dev, const uint32_t* ids_dev, uint32_t n_pairs,
+   const uint8_t* membership_by_id, uint32_t n_ids, void* stream
+);
+int silo_gpu_count_pairs(
+   const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* rows_dev, const uint32_t* ids_dev, uint32_t n_pairs,
+   uint32_t* counts_dev, void* stream
+);
 /* FastaAligned (fasta_aligned.cpp:44-83 reconstructSequence): the stored symbol of every position of the given
  * rows as characters, out_chars_dev[r * positions + p]; row_ids_dev holds n_rows sequence ids of this store. */
 int silo_gpu_reconstruct_sequences(

@@ -169,6 +169,34 @@ __global__ __launch_bounds__(256) void k_group_count(
    }
 }
 
+// Insertion index (insertion_index.cpp): the occurrences of a column's insertions as pairs (row, distinct
+// insertion id).  K8 marks the rows of the pairs whose insertion matched the search pattern (the regex runs on the
+// host over the distinct insertions of one position, insertion_index.cpp:128-137); K9 counts, per distinct insertion,
+// the pairs whose row is in the filter (insertions.cpp:196-206 and_cardinality per insertion).
+__global__ __launch_bounds__(256) void k_bitset_from_pairs(
+   const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ids, uint32_t n_pairs, const uint8_t* __restrict__ membership,
+   uint64_t* __restrict__ out
+) {
+   const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+   if (pair < n_pairs && membership[ids[pair]] != 0) {
+      const uint32_t row = rows[pair];
+      atomicOr(reinterpret_cast<unsigned long long*>(out + (row >> 6)), 1ull << (row & 63u));
+   }
+}
+
+__global__ __launch_bounds__(256) void k_count_pairs(
+   const uint64_t* __restrict__ filter, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ids, uint32_t n_pairs,
+   uint32_t* __restrict__ counts
+) {
+   const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+   if (pair < n_pairs) {
+      const uint32_t row = rows[pair];
+      if (filter == nullptr || ((filter[row >> 6] >> (row & 63u)) & 1u) != 0) {
+         atomicAdd(&counts[ids[pair]], 1u);
+      }
+   }
+}
+
 }  // namespace
 
 extern "C" {
@@ -257,6 +285,48 @@ int silo_gpu_group_count(
    } else {
       k_group_count<false><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), 1, counts_dev);
    }
+   SILO_HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_bitset_from_pairs(
+   const silo_gpu_store* store, uint64_t* dst_dev, const uint32_t* rows_dev, const uint32_t* ids_dev, uint32_t n_pairs,
+   const uint8_t* membership_by_id, uint32_t n_ids, void* stream
+) {
+   if (store == nullptr || dst_dev == nullptr || (n_pairs != 0 && (rows_dev == nullptr || ids_dev == nullptr || membership_by_id == nullptr || n_ids == 0))) {
+      return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_bitset_from_pairs: bad arguments");
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   SILO_HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(silo_gpu_store_row_words(store)) * sizeof(uint64_t), hip_stream));
+   if (n_pairs == 0) {
+      return SILO_GPU_OK;
+   }
+   uint8_t* d_membership = nullptr;
+   SILO_HIP_TRY(hipMalloc(&d_membership, n_ids));
+   hipError_t err = hipMemcpyAsync(d_membership, membership_by_id, n_ids, hipMemcpyHostToDevice, hip_stream);
+   if (err == hipSuccess) {
+      k_bitset_from_pairs<<<(n_pairs + 255) / 256, 256, 0, hip_stream>>>(rows_dev, ids_dev, n_pairs, d_membership, dst_dev);
+      err = hipStreamSynchronize(hip_stream);  // the membership table is freed below
+   }
+   (void)hipFree(d_membership);
+   if (err != hipSuccess) {
+      (void)hipGetLastError();
+      return silo_gpu_internal_fail(SILO_GPU_ERR_HIP, std::string("k_bitset_from_pairs: ") + hipGetErrorString(err));
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_count_pairs(
+   const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* rows_dev, const uint32_t* ids_dev, uint32_t n_pairs,
+   uint32_t* counts_dev, void* stream
+) {
+   if (store == nullptr || counts_dev == nullptr || (n_pairs != 0 && (rows_dev == nullptr || ids_dev == nullptr))) {
+      return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_count_pairs: bad arguments");
+   }
+   if (n_pairs == 0) {
+      return SILO_GPU_OK;
+   }
+   k_count_pairs<<<(n_pairs + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(filter_dev, rows_dev, ids_dev, n_pairs, counts_dev);
    SILO_HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }

@@ -521,6 +521,41 @@ std::unique_ptr<Action> parseMutations(const json::Value& json) {  // mutations.
    return std::make_unique<Mutations<SymbolType>>(std::move(sequence_names), min_proportion);
 }
 
+template <typename SymbolType>
+std::unique_ptr<Action> parseInsertions(const json::Value& json) {  // insertions.cpp:260-302
+   CHECK_SILO_QUERY(
+      !json.contains("sequenceName") || (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
+      "Insertions action can have the field sequenceName of type string or an array of strings, but no other type"
+   )
+   std::vector<std::string> sequence_names;
+   if (json.contains("sequenceName") && json["sequenceName"].is_array()) {
+      for (const auto& child : json["sequenceName"].items()) {
+         CHECK_SILO_QUERY(
+            child.is_string(), "The field sequenceName of the Insertions action must have type string or an array, if present. Found:" + child.dump()
+         )
+         sequence_names.emplace_back(child.as_string());
+      }
+   } else if (json.contains("sequenceName") && json["sequenceName"].is_string()) {
+      sequence_names.emplace_back(json["sequenceName"].as_string());
+   }
+   CHECK_SILO_QUERY(
+      !json.contains("column") || (json["column"].is_string() || json["column"].is_array()),
+      "Insertions action can have the field column of type string or an array of strings, but no other type"
+   )
+   std::vector<std::string> column_names;
+   if (json.contains("column") && json["column"].is_array()) {
+      for (const auto& child : json["column"].items()) {
+         CHECK_SILO_QUERY(
+            child.is_string(), "The field column of the Insertions action must have type string or an array, if present. Found:" + child.dump()
+         )
+         column_names.emplace_back(child.as_string());
+      }
+   } else if (json.contains("column") && json["column"].is_string()) {
+      column_names.emplace_back(json["column"].as_string());
+   }
+   return std::make_unique<InsertionAggregation<SymbolType>>(std::move(column_names), std::move(sequence_names));
+}
+
 }  // namespace
 
 std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:144-187
@@ -568,8 +603,12 @@ std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:14
          sequence_names.emplace_back(json["sequenceName"].as_string());
       }
       action = std::make_unique<FastaAligned>(std::move(sequence_names));
-   } else if (expression_type == "Fasta" || expression_type == "Insertions" || expression_type == "AminoAcidInsertions") {
-      // unaligned sequences and the insertion index are not held by this engine
+   } else if (expression_type == "Insertions") {
+      action = parseInsertions<Nucleotide>(json);
+   } else if (expression_type == "AminoAcidInsertions") {
+      action = parseInsertions<AminoAcid>(json);
+   } else if (expression_type == "Fasta") {
+      // unaligned sequences are not held by this engine (the reference reads them back from zstd files through DuckDB)
       throw std::runtime_error("action '" + expression_type + "' is not supported by the MI355X filter engine");
    } else {
       throw QueryParseException(expression_type + " is not a valid action");

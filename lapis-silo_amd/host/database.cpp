@@ -382,6 +382,8 @@ std::optional<const uint64_t*> PangoLineageColumnPartition::filterIncludingSubli
 DatabasePartition::~DatabasePartition() {
    columns.pango_lineage_columns.clear();
    columns.metadata_columns.clear();
+   columns.nuc_insertion_columns.clear();
+   columns.aa_insertion_columns.clear();
    silo_gpu_store_destroy(store);
 }
 
@@ -567,6 +569,28 @@ void Database::appendMetadata(
       throw std::runtime_error("metadata column '" + name + "' holds more values than the partition has rows");
    }
    column.reserve(partition.sequence_count);
+   if (type == config::ColumnType::NUC_INSERTION || type == config::ColumnType::AA_INSERTION) {
+      // the index sees every entry; the column holds the standardised text (insertion_column.cpp:76-113).  Entries
+      // without a sequence name belong to the default nucleotide sequence; amino-acid columns have no default
+      // (database.cpp:73-80).
+      const bool is_nucleotide = type == config::ColumnType::NUC_INSERTION;
+      auto& insertion_columns = is_nucleotide ? partition.columns.nuc_insertion_columns : partition.columns.aa_insertion_columns;
+      auto insertion_column = insertion_columns.find(name);
+      if (insertion_column == insertion_columns.end()) {
+         insertion_column = insertion_columns
+                               .emplace(
+                                  std::piecewise_construct, std::forward_as_tuple(name),
+                                  std::forward_as_tuple(
+                                     is_nucleotide ? std::optional<std::string>(database_config.default_nucleotide_sequence) : std::nullopt
+                                  )
+                               )
+                               .first;
+      }
+      for (const std::string& value : values) {
+         column.insert(insertion_column->second.insert(value, static_cast<uint32_t>(column.numRows())));
+      }
+      return;
+   }
    for (const std::string& value : values) {
       column.insert(value);
    }
@@ -590,6 +614,12 @@ void Database::finalize() {
    for (auto& partition : partitions) {
       checkGpu(silo_gpu_store_finalize(partition.store), "silo_gpu_store_finalize");
       for (auto& [name, column] : partition.columns.pango_lineage_columns) {
+         column.finalize();
+      }
+      for (auto& [name, column] : partition.columns.nuc_insertion_columns) {
+         column.finalize();
+      }
+      for (auto& [name, column] : partition.columns.aa_insertion_columns) {
          column.finalize();
       }
       for (auto& [name, column] : partition.columns.metadata_columns) {

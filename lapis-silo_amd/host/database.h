@@ -237,6 +237,12 @@ class DatabasePartition {
       /// type is a member here).  A lineage column appears in both maps: the one above answers PangoLineage
       /// filters, this one renders and groups its values.
       std::map<std::string, storage::column::MetadataColumnPartition> metadata_columns;
+      /// The insertion indexes behind InsertionContains / Insertions; the text of an insertion column is in
+      /// metadata_columns like any other string column.
+      std::map<std::string, storage::column::InsertionColumnPartition> nuc_insertion_columns;
+      std::map<std::string, storage::column::InsertionColumnPartition> aa_insertion_columns;
+      template <typename SymbolType>
+      [[nodiscard]] const std::map<std::string, storage::column::InsertionColumnPartition>& getInsertionColumns() const;
 
       [[nodiscard]] const storage::column::MetadataColumnPartition* find(const std::string& name, config::ColumnType type) const {
          const auto found = metadata_columns.find(name);
@@ -345,6 +351,16 @@ inline const std::map<std::string, SequenceStore<AminoAcid>>& Database::getSeque
    return aa_sequences;
 }
 
+template <>
+inline const std::map<std::string, storage::column::InsertionColumnPartition>& DatabasePartition::ColumnPartitionGroup::getInsertionColumns<
+   Nucleotide>() const {
+   return nuc_insertion_columns;
+}
+template <>
+inline const std::map<std::string, storage::column::InsertionColumnPartition>& DatabasePartition::ColumnPartitionGroup::getInsertionColumns<
+   AminoAcid>() const {
+   return aa_insertion_columns;
+}
 template <>
 inline const MutationTableLayout& Database::getMutationTableLayout<Nucleotide>() const {
    return nuc_mutation_layout;

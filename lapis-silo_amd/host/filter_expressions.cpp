@@ -4,6 +4,8 @@
 #include <algorithm>
 
 #include <cmath>
+#include <regex>
+#include <type_traits>
 #include <climits>
 
 #include "query_engine.h"
@@ -693,6 +695,125 @@ std::unique_ptr<Operator> DateBetween::compile(
    return selectionOf(std::move(predicates), rowsOf(database_partition));
 }
 
+// ---- InsertionContains (insertion_contains.cpp) ------------------------------------------------------
+template <typename SymbolType>
+std::string InsertionContains<SymbolType>::toString(const Database& /*database*/) const {
+   const std::string symbol_name = std::string(SymbolType::SYMBOL_NAME);
+   const std::string sequence_string =
+      sequence_name.has_value() ? "The sequence '" + sequence_name.value() + "'" : "The default " + symbol_name + " sequence ";
+   return sequence_string + " has insertion '" + value + "'";
+}
+
+template <typename SymbolType>
+std::unique_ptr<Operator> InsertionContains<SymbolType>::compile(
+   const Database& database, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
+) const {  // insertion_contains.cpp:65-131
+   const RowSpace rows = rowsOf(database_partition);
+   const auto& insertion_columns = database_partition.columns.getInsertionColumns<SymbolType>();
+   for (const std::string& column_name : column_names) {
+      CHECK_SILO_QUERY(insertion_columns.count(column_name) != 0, "The insertion column '" + column_name + "' does not exist.")
+   }
+   if (insertion_columns.empty()) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   std::string validated_sequence_name;
+   if (sequence_name.has_value()) {
+      validated_sequence_name = sequence_name.value();
+   } else {
+      // only nucleotide sequences have a default (database.cpp:73-80)
+      CHECK_SILO_QUERY(
+         (std::is_same_v<SymbolType, Nucleotide>), "The database has no default " + std::string(SymbolType::SYMBOL_NAME_LOWER_CASE) + " sequence name"
+      )
+      validated_sequence_name = database.database_config.default_nucleotide_sequence;
+   }
+   // InsertionIndex::search (insertion_index.cpp:271-281): the reference pre-selects candidates through a 3-mer index
+   // and then runs regex_search on them; the answer is regex_search over the distinct insertions at the position.
+   // That part stays on the host (a handful of short strings); the rows are gathered on the device.
+   const std::regex search_pattern(value);
+   OperatorVector column_operators;
+   for (const auto& [column_name, insertion_column] : insertion_columns) {
+      if (!column_names.empty() && std::find(column_names.begin(), column_names.end(), column_name) == column_names.end()) {
+         continue;
+      }
+      const auto found = insertion_column.getInsertionIndexes().find(validated_sequence_name);
+      if (found == insertion_column.getInsertionIndexes().end()) {
+         continue;
+      }
+      const auto& index = found->second;
+      std::vector<uint8_t> membership(index.insertions.size(), 0);
+      const auto at_position = index.ids_at_position.find(position);
+      if (at_position != index.ids_at_position.end()) {
+         for (const uint32_t id : at_position->second) {
+            membership[id] = std::regex_search(index.insertions[id], search_pattern) ? 1 : 0;
+         }
+      }
+      column_operators.emplace_back(std::make_unique<operators::BitmapProducer>(&index, std::move(membership), rows));
+   }
+   if (column_operators.empty()) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   if (column_operators.size() == 1) {
+      return std::move(column_operators.at(0));
+   }
+   return std::make_unique<operators::Union>(std::move(column_operators), rows);
+}
+
+template struct InsertionContains<Nucleotide>;
+template struct InsertionContains<AminoAcid>;
+
+namespace {
+
+template <typename SymbolType>
+std::unique_ptr<Expression> parseInsertionContains(const json::Value& json) {  // insertion_contains.cpp:155-214
+   CHECK_SILO_QUERY(
+      !json.contains("column") || (json["column"].is_string() || json["column"].is_array()),
+      "The InsertionsContains filter can have the field column of type string or an array of strings, but no other type"
+   )
+   std::vector<std::string> column_names;
+   if (json.contains("column") && json["column"].is_array()) {
+      for (const auto& child : json["column"].items()) {
+         CHECK_SILO_QUERY(
+            child.is_string(), "The field column of the InsertionsContains filter must have type string or an array, if present. Found:" + child.dump()
+         )
+         column_names.emplace_back(child.as_string());
+      }
+   } else if (json.contains("column") && json["column"].is_string()) {
+      column_names.emplace_back(json["column"].as_string());
+   }
+   CHECK_SILO_QUERY(json.contains("position"), "The field 'position' is required in an InsertionContains expression")
+   CHECK_SILO_QUERY(
+      json["position"].is_number_unsigned() && (json["position"].as_uint32() > 0),
+      "The field 'position' in an InsertionContains expression needs to be a positive number (> 0)"
+   )
+   CHECK_SILO_QUERY(
+      !json.contains("sequenceName") || json["sequenceName"].is_string(),
+      "The optional field 'sequenceName' in an InsertionContains expression needs to be a string"
+   )
+   CHECK_SILO_QUERY(json.contains("value"), "The field 'value' is required in an InsertionContains expression")
+   CHECK_SILO_QUERY(json["value"].is_string(), "The field 'value' in an InsertionContains expression needs to be a string")
+   std::optional<std::string> sequence_name;
+   if (json.contains("sequenceName")) {
+      sequence_name = json["sequenceName"].as_string();
+   }
+   const uint32_t position = json["position"].as_uint32();
+   const std::string& value = json["value"].as_string();
+   CHECK_SILO_QUERY(!value.empty(), "The field 'value' in an InsertionContains expression must not be an empty string")
+   // ^([symbols]|\.\*)*$ (:133-149)
+   std::string valid_pattern = "^([";
+   for (const auto symbol : SymbolType::SYMBOLS) {
+      valid_pattern += SymbolType::symbolToChar(symbol);
+   }
+   valid_pattern += "]|\\.\\*)*$";
+   CHECK_SILO_QUERY(
+      std::regex_search(value, std::regex(valid_pattern)),
+      "The field 'value' in the InsertionContains expression does not contain a valid regex pattern: \"" + value +
+         "\". It must only consist of " + std::string(SymbolType::SYMBOL_NAME_LOWER_CASE) + " symbols and the regex symbol '.*'."
+   )
+   return std::make_unique<InsertionContains<SymbolType>>(std::move(column_names), sequence_name, position, value);
+}
+
+}  // namespace
+
 // ---- JSON -> Expression (the from_json functions) ------------------------------------------------------
 namespace {
 
@@ -918,9 +1039,11 @@ std::unique_ptr<Expression> parseExpression(const json::Value& json) {  // expre
       }
       return std::make_unique<DateBetween>(json["column"].as_string(), date_from, date_to);
    }
-   if (expression_type == "InsertionContains" || expression_type == "AminoAcidInsertionContains") {
-      // the insertion index stays on the host in the reference too and is not built here
-      throw std::runtime_error("filter type '" + expression_type + "' is not supported by the MI355X filter engine");
+   if (expression_type == "InsertionContains") {
+      return parseInsertionContains<Nucleotide>(json);
+   }
+   if (expression_type == "AminoAcidInsertionContains") {
+      return parseInsertionContains<AminoAcid>(json);
    }
    throw QueryParseException("Unknown object filter type '" + expression_type + "'");
 }

@@ -3,6 +3,7 @@
 //   Details                         src/silo/query_engine/actions/details.cpp
 //   FastaAligned                    src/silo/query_engine/actions/fasta_aligned.cpp
 #include <algorithm>
+#include <type_traits>
 #include <unordered_map>
 
 #include "query_engine.h"
@@ -278,6 +279,113 @@ QueryResult Details::executeAndOrder(const Database& database, std::vector<Opera
    Trace::mark("rows_built");
    return results_in_format;
 }
+
+// ---- Insertions / AminoAcidInsertions (insertions.cpp) ---------------------------------------------------
+template <typename SymbolType>
+void InsertionAggregation<SymbolType>::validateOrderByFields(const Database& /*database*/) const {  // :41-59
+   for (const OrderByField& field : order_by_fields) {
+      CHECK_SILO_QUERY(
+         field.name == "position" || field.name == "insertions" || field.name == "sequenceName" || field.name == "count",
+         "OrderByField " + field.name + " is not contained in the result of this operation."
+      )
+   }
+}
+
+template <typename SymbolType>
+QueryResult InsertionAggregation<SymbolType>::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // :126-258
+   const config::ColumnType wanted_type =
+      std::is_same_v<SymbolType, Nucleotide> ? config::ColumnType::NUC_INSERTION : config::ColumnType::AA_INSERTION;
+   for (const std::string& column_name : column_names) {  // validateDatabaseColumnNames
+      const auto metadata = database.database_config.getMetadata(column_name);
+      CHECK_SILO_QUERY(
+         metadata.has_value() && metadata->type == wanted_type,
+         "The database does not contain the " + std::string(SymbolType::SYMBOL_NAME) + " column '" + column_name + "'"
+      )
+   }
+   for (const std::string& sequence_name : sequence_names) {  // validateSequenceNames
+      CHECK_SILO_QUERY(
+         database.getSequenceStores<SymbolType>().count(sequence_name) != 0,
+         "The database does not contain the " + std::string(SymbolType::SYMBOL_NAME) + " sequence '" + sequence_name + "'"
+      )
+   }
+   requireUnsharded(database, "Insertions");
+
+   // One k_count_pairs launch per (partition, column, sequence): the and_cardinality of the filter with the rows of
+   // every distinct insertion at once (:196-206).  Launch all, then fetch.
+   struct InFlight {
+      const std::string* sequence_name;
+      const storage::column::InsertionColumnPartition::SequenceIndex* index;
+      DeviceBuffer device_counts;
+      HostFetch fetch;
+   };
+   std::vector<InFlight> in_flight;
+   for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
+      const DatabasePartition& partition = database.partitions[partition_id];
+      const auto& insertion_columns = partition.columns.getInsertionColumns<SymbolType>();
+      for (const std::string& column_name : column_names) {  // validatePartitionColumnNames
+         CHECK_SILO_QUERY(
+            insertion_columns.count(column_name) != 0,
+            "The database does not contain the " + std::string(SymbolType::SYMBOL_NAME) + " column '" + column_name + "'"
+         )
+      }
+      OperatorResult& filter = bitmap_filter[partition_id];
+      if (filter.cardinality() == 0) {
+         continue;
+      }
+      for (const auto& [column_name, insertion_column] : insertion_columns) {
+         if (!column_names.empty() && std::find(column_names.begin(), column_names.end(), column_name) == column_names.end()) {
+            continue;
+         }
+         for (const auto& [sequence_name, index] : insertion_column.getInsertionIndexes()) {
+            if (!sequence_names.empty() && std::find(sequence_names.begin(), sequence_names.end(), sequence_name) == sequence_names.end()) {
+               continue;
+            }
+            if (index.insertions.empty()) {
+               continue;
+            }
+            InFlight& launch = in_flight.emplace_back();
+            launch.sequence_name = &sequence_name;
+            launch.index = &index;
+            const size_t bytes = index.insertions.size() * sizeof(uint32_t);
+            launch.device_counts = partition.pool.acquire(bytes);
+            checkGpu(silo_gpu_memset_async(launch.device_counts.get(), 0, bytes, queryStream()), "silo_gpu_memset_async");
+            checkGpu(
+               silo_gpu_count_pairs(
+                  partition.store, filter.bitset(), index.device_rows, index.device_ids, static_cast<uint32_t>(index.pair_rows.size()),
+                  static_cast<uint32_t*>(launch.device_counts.get()), queryStream()
+               ),
+               "silo_gpu_count_pairs"
+            );
+            launch.fetch = HostFetch(launch.device_counts.get(), bytes, queryStream());
+         }
+      }
+   }
+   // sequence name -> (position, insertion) -> count; the reference's unordered_maps leave the row order unspecified
+   std::map<std::string, std::map<std::pair<uint32_t, std::string>, uint32_t>> all_insertions;
+   for (const InFlight& launch : in_flight) {
+      const auto* counts = static_cast<const uint32_t*>(launch.fetch.wait());
+      auto& per_sequence = all_insertions[*launch.sequence_name];
+      for (size_t id = 0; id < launch.index->insertions.size(); ++id) {
+         if (counts[id] > 0) {
+            per_sequence[{launch.index->positions[id], launch.index->insertions[id]}] += counts[id];
+         }
+      }
+   }
+   QueryResult result;
+   for (const auto& [sequence_name, per_sequence] : all_insertions) {
+      for (const auto& [position_and_insertion, count] : per_sequence) {
+         QueryResultEntry& entry = result.query_result.emplace_back();
+         entry.fields["position"] = static_cast<int32_t>(position_and_insertion.first);
+         entry.fields["sequenceName"] = sequence_name;
+         entry.fields["insertions"] = position_and_insertion.second;
+         entry.fields["count"] = static_cast<int32_t>(count);
+      }
+   }
+   return result;
+}
+
+template class InsertionAggregation<Nucleotide>;
+template class InsertionAggregation<AminoAcid>;
 
 // ---- FastaAligned ----------------------------------------------------------------------------------------
 void FastaAligned::validateOrderByFields(const Database& database) const {  // fasta_aligned.cpp:28-42

@@ -371,6 +371,110 @@ int MetadataColumnPartition::compareRows(uint32_t row, const MetadataColumnParti
    }
 }
 
+// ---- InsertionColumnPartition ---------------------------------------------------------------------------
+InsertionColumnPartition::InsertionColumnPartition(std::optional<std::string> default_sequence_name)
+    : default_sequence_name_(std::move(default_sequence_name)) {}
+
+InsertionColumnPartition::~InsertionColumnPartition() {
+   for (auto& [name, index] : indexes_) {
+      silo_gpu_free(index.device_rows);
+      silo_gpu_free(index.device_ids);
+   }
+}
+
+namespace {
+
+std::vector<std::string> splitBy(const std::string& value, char delimiter) {  // string_utils.cpp:8-23
+   std::vector<std::string> splits;
+   size_t begin = 0;
+   while (true) {
+      const auto next = value.find(delimiter, begin);
+      splits.push_back(value.substr(begin, next == std::string::npos ? std::string::npos : next - begin));
+      if (next == std::string::npos) {
+         return splits;
+      }
+      begin = next + 1;
+   }
+}
+
+uint32_t parsePosition(const std::string& text, const std::string& whole) {  // boost::lexical_cast<uint32_t>
+   if (text.empty() || text.find_first_not_of("0123456789") != std::string::npos || text.size() > 10) {
+      throw std::runtime_error("Failed to parse insertion due to invalid format: " + whole);
+   }
+   const unsigned long long value = std::stoull(text);
+   if (value > UINT32_MAX) {
+      throw std::runtime_error("Failed to parse insertion due to invalid format: " + whole);
+   }
+   return static_cast<uint32_t>(value);
+}
+
+}  // namespace
+
+std::string InsertionColumnPartition::insert(const std::string& value, uint32_t row) {
+   if (value.empty()) {
+      return "";
+   }
+   std::string standardized_value;
+   for (const std::string& insertion_entry : splitBy(value, ',')) {
+      std::vector<std::string> parts = splitBy(insertion_entry, ':');  // parseInsertion, insertion_column.cpp:31-65
+      for (std::string& part : parts) {
+         part.erase(std::remove(part.begin(), part.end(), '"'), part.end());
+      }
+      std::string sequence_name;
+      uint32_t position = 0;
+      std::string insertion;
+      if (parts.size() == 2 && default_sequence_name_.has_value()) {
+         sequence_name = *default_sequence_name_;
+         position = parsePosition(parts[0], insertion_entry);
+         insertion = parts[1];
+      } else if (parts.size() == 3) {
+         sequence_name = parts[0];
+         position = parsePosition(parts[1], insertion_entry);
+         insertion = parts[2];
+      } else {
+         throw std::runtime_error("Failed to parse insertion due to invalid format: " + insertion_entry);
+      }
+      SequenceIndex& index = indexes_[sequence_name];
+      const auto key = std::make_pair(position, insertion);
+      auto found = index.lookup.find(key);
+      if (found == index.lookup.end()) {
+         const auto id = static_cast<uint32_t>(index.insertions.size());
+         found = index.lookup.emplace(key, id).first;
+         index.positions.push_back(position);
+         index.insertions.push_back(insertion);
+         index.ids_at_position[position].push_back(id);
+      }
+      index.pair_rows.push_back(row);
+      index.pair_ids.push_back(found->second);
+      if (!standardized_value.empty()) {
+         standardized_value += ",";
+      }
+      if (default_sequence_name_.has_value() && *default_sequence_name_ == sequence_name) {
+         standardized_value += std::to_string(position) + ":" + insertion;
+      } else {
+         standardized_value += sequence_name + ":" + std::to_string(position) + ":" + insertion;
+      }
+   }
+   return standardized_value;
+}
+
+void InsertionColumnPartition::finalize() {
+   for (auto& [name, index] : indexes_) {
+      silo_gpu_free(index.device_rows);
+      silo_gpu_free(index.device_ids);
+      index.device_rows = nullptr;
+      index.device_ids = nullptr;
+      if (index.pair_rows.empty()) {
+         continue;
+      }
+      void* device = nullptr;
+      checkGpu(silo_gpu_upload_column(index.pair_rows.data(), index.pair_rows.size(), SILO_GPU_VALUE_U32, &device), "silo_gpu_upload_column");
+      index.device_rows = static_cast<uint32_t*>(device);
+      checkGpu(silo_gpu_upload_column(index.pair_ids.data(), index.pair_ids.size(), SILO_GPU_VALUE_U32, &device), "silo_gpu_upload_column");
+      index.device_ids = static_cast<uint32_t*>(device);
+   }
+}
+
 }  // namespace storage::column
 
 }  // namespace silo

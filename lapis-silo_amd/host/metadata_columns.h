@@ -128,6 +128,38 @@ class MetadataColumnPartition {
    mutable NumericGroups numeric_groups_;
 };
 
+/// The insertion index of one insertion column of one partition (insertion_column.cpp, insertion_index.cpp).
+/// Per sequence name: the distinct (position, insertion) values and their occurrences as (row, id) pairs, on the host
+/// (pattern search over the distinct insertions of a position) and in HBM (k_bitset_from_pairs / k_count_pairs).
+class InsertionColumnPartition {
+  public:
+   explicit InsertionColumnPartition(std::optional<std::string> default_sequence_name);
+   ~InsertionColumnPartition();
+   InsertionColumnPartition(const InsertionColumnPartition&) = delete;
+   InsertionColumnPartition& operator=(const InsertionColumnPartition&) = delete;
+
+   /// Indexes the insertions of row `row` ("" = none) and returns the standardised text the column holds for it
+   /// (insertion_column.cpp:76-113).  Throws std::runtime_error for an entry that is not [sequence:]position:insertion.
+   std::string insert(const std::string& value, uint32_t row);
+   void finalize();  // uploads the pairs
+
+   struct SequenceIndex {
+      std::vector<uint32_t> positions;       // per distinct insertion id
+      std::vector<std::string> insertions;   // per distinct insertion id
+      std::map<uint32_t, std::vector<uint32_t>> ids_at_position;
+      std::map<std::pair<uint32_t, std::string>, uint32_t> lookup;
+      std::vector<uint32_t> pair_rows;
+      std::vector<uint32_t> pair_ids;
+      uint32_t* device_rows = nullptr;
+      uint32_t* device_ids = nullptr;
+   };
+   [[nodiscard]] const std::map<std::string, SequenceIndex>& getInsertionIndexes() const { return indexes_; }
+
+  private:
+   std::optional<std::string> default_sequence_name_;
+   std::map<std::string, SequenceIndex> indexes_;
+};
+
 }  // namespace storage::column
 
 }  // namespace silo

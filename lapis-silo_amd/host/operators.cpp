@@ -424,6 +424,25 @@ uint32_t Selection::lower(ProgramBuilder& builder) const {
    return acc;
 }
 
+// ---- BitmapProducer (bitmap_producer.cpp) -----------------------------------------------------------
+std::unique_ptr<Operator> BitmapProducer::copy() const {
+   return std::make_unique<BitmapProducer>(index, membership, rows);
+}
+std::unique_ptr<Operator> BitmapProducer::negate() const {
+   return std::make_unique<Complement>(this->copy(), rows);
+}
+uint32_t BitmapProducer::lower(ProgramBuilder& builder) const {
+   uint64_t* bitset = builder.temporaryBitset();
+   checkGpu(
+      silo_gpu_bitset_from_pairs(
+         rows.partition->store, bitset, index->device_rows, index->device_ids, static_cast<uint32_t>(index->pair_rows.size()),
+         membership.data(), static_cast<uint32_t>(membership.size()), queryStream()
+      ),
+      "silo_gpu_bitset_from_pairs"
+   );
+   return SILO_GPU_LEAF_OPERAND + builder.leaf(bitset);
+}
+
 // ---- BitmapSelection (bitmap_selection.cpp:33-71) -----------------------------------------------
 std::unique_ptr<Operator> BitmapSelection::copy() const {
    return std::make_unique<BitmapSelection>(missing_plane, rows, comparator, value);

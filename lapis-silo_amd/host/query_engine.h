@@ -301,6 +301,24 @@ class Selection : public Operator {
    std::vector<Predicate> predicates;
 };
 
+/// bitmap_producer.cpp: a bitmap computed at evaluation time.  The only producer on this path is the insertion
+/// search (insertion_contains.cpp:104-113): the rows that carry one of the distinct insertions the pattern matched,
+/// scattered into a bitset by k_bitset_from_pairs.
+class BitmapProducer : public Operator {
+  public:
+   BitmapProducer(const storage::column::InsertionColumnPartition::SequenceIndex* index, std::vector<uint8_t> membership, RowSpace rows)
+       : Operator(rows), index(index), membership(std::move(membership)) {}
+   Type type() const override { return BITMAP_PRODUCER; }
+   std::string toString() const override { return "BitmapProducer"; }
+   std::unique_ptr<Operator> copy() const override;
+   std::unique_ptr<Operator> negate() const override;
+   uint32_t lower(ProgramBuilder& builder) const override;
+   Cost cost() const override { return {1, 1}; }
+
+   const storage::column::InsertionColumnPartition::SequenceIndex* index;
+   std::vector<uint8_t> membership;  // per distinct insertion id of the index
+};
+
 class Threshold : public Operator {
   public:
    Threshold(OperatorVector&& non_negated_children, OperatorVector&& negated_children, uint32_t number_of_matchers, bool match_exactly, RowSpace rows);
@@ -466,6 +484,16 @@ struct FloatBetween : public Expression {  // float_between.cpp
    std::optional<double> from;
    std::optional<double> to;
 };
+template <typename SymbolType>
+struct InsertionContains : public Expression {  // insertion_contains.cpp
+   InsertionContains(std::vector<std::string>&& column_names, std::optional<std::string> sequence_name, uint32_t position, std::string value)
+       : column_names(std::move(column_names)), sequence_name(std::move(sequence_name)), position(position), value(std::move(value)) {}
+   SILO_DECLARE_EXPRESSION_METHODS
+   std::vector<std::string> column_names;
+   std::optional<std::string> sequence_name;
+   uint32_t position;
+   std::string value;
+};
 struct DateBetween : public Expression {  // date_between.cpp
    DateBetween(std::string column, std::optional<common::Date> date_from, std::optional<common::Date> date_to)
        : column(std::move(column)), date_from(date_from), date_to(date_to) {}
@@ -577,6 +605,19 @@ class Details : public Action {
    explicit Details(std::vector<std::string> fields) : fields(std::move(fields)) {}
    [[nodiscard]] QueryResult executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
    [[nodiscard]] QueryResult finish(const Database& database, Pending& pending) const override;
+};
+
+/// insertions.cpp: the distinct insertions of the selected rows with their counts (k_count_pairs per insertion index).
+template <typename SymbolType>
+class InsertionAggregation : public Action {
+   std::vector<std::string> column_names;
+   std::vector<std::string> sequence_names;
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   InsertionAggregation(std::vector<std::string>&& column_names, std::vector<std::string>&& sequence_names)
+       : column_names(std::move(column_names)), sequence_names(std::move(sequence_names)) {}
 };
 
 /// fasta_aligned.cpp: primary key + the aligned sequences of the selected rows, gathered from the planes on the

@@ -394,7 +394,10 @@ class DatabasePartition:  # database_partition.h:39-112
     int_columns: Dict[str, List[int]] = field(default_factory=dict)
     float_columns: Dict[str, List[float]] = field(default_factory=dict)
     date_columns: Dict[str, List[int]] = field(default_factory=dict)
-    insertion_columns: Dict[str, List[str]] = field(default_factory=dict)  # kept as text: only Details reads them here
+    insertion_columns: Dict[str, List[str]] = field(default_factory=dict)  # standardised text per row (lookupValue)
+    # insertion_column.cpp / insertion_index.cpp: column -> sequence name -> position -> insertion -> set of rows
+    nuc_insertion_indexes: Dict[str, Dict[str, Dict[int, Dict[str, set]]]] = field(default_factory=dict)
+    aa_insertion_indexes: Dict[str, Dict[str, Dict[int, Dict[str, set]]]] = field(default_factory=dict)
 
 
 INT32_MIN = -(1 << 31)
@@ -485,7 +488,29 @@ class Database:
             elif kind == "date":
                 partition.date_columns[name] = [string_to_date(value) for value in raw]
             elif kind in ("insertion", "aa_insertion"):
-                partition.insertion_columns[name] = raw
+                # InsertionColumnPartition::insert (insertion_column.cpp:76-113): "position:insertion" entries belong to
+                # the default sequence (the default nucleotide sequence; amino-acid columns have none), others name theirs
+                default_sequence = self.default_nucleotide_sequence if kind == "insertion" else None
+                index = {}
+                standardised = []
+                for row, value in enumerate(raw):
+                    parts_out = []
+                    for entry in (value.split(",") if value else []):
+                        parts = [part.replace('"', "") for part in entry.split(":")]
+                        if len(parts) == 2 and default_sequence is not None:
+                            sequence_name, position, insertion = default_sequence, int(parts[0]), parts[1]
+                        elif len(parts) == 3:
+                            sequence_name, position, insertion = parts[0], int(parts[1]), parts[2]
+                        else:
+                            raise ValueError("Failed to parse insertion due to invalid format: " + entry)
+                        index.setdefault(sequence_name, {}).setdefault(position, {}).setdefault(insertion, set()).add(row)
+                        if default_sequence is not None and default_sequence == sequence_name:
+                            parts_out.append(f"{position}:{insertion}")
+                        else:
+                            parts_out.append(f"{sequence_name}:{position}:{insertion}")
+                    standardised.append(",".join(parts_out))
+                partition.insertion_columns[name] = standardised
+                (partition.nuc_insertion_indexes if kind == "insertion" else partition.aa_insertion_indexes)[name] = index
             else:
                 raise ValueError(kind)
 
@@ -1236,6 +1261,10 @@ def parse_expression(node):  # expression.cpp:49-102
             string_to_date(node["from"]) if isinstance(node["from"], str) else None,
             string_to_date(node["to"]) if isinstance(node["to"], str) else None,
         )
+    if kind == "InsertionContains":
+        return parse_insertion_contains(node, Nucleotide)
+    if kind == "AminoAcidInsertionContains":
+        return parse_insertion_contains(node, AminoAcid)
     raise QueryParseException("Unknown object filter type '" + kind + "'")
 
 
@@ -1404,6 +1433,86 @@ class DateBetween(Expression):  # date_between.cpp:49-101
         low = self.date_from if self.date_from is not None else 1
         ids = [i for i, d in enumerate(values) if d >= low and (self.date_to is None or d <= self.date_to)]
         return IndexScan(bits_from_ids(ids), rows) if ids else RangeSelection([], rows)
+
+
+class InsertionContains(Expression):  # insertion_contains.cpp:65-131
+    def __init__(self, alphabet, column_names, sequence_name, position, value):
+        self.alphabet, self.column_names, self.sequence_name, self.position, self.value = alphabet, column_names, sequence_name, position, value
+
+    def compile(self, database, partition, mode):
+        import re
+
+        indexes = partition.nuc_insertion_indexes if self.alphabet is Nucleotide else partition.aa_insertion_indexes
+        for column_name in self.column_names:
+            check_silo_query(column_name in indexes, "The insertion column '" + column_name + "' does not exist.")
+        rows = partition.sequence_count
+        if not indexes:
+            return Empty(rows)
+        if self.sequence_name is not None:
+            sequence_name = self.sequence_name
+        else:
+            default = database.default_nucleotide_sequence if self.alphabet is Nucleotide else None
+            check_silo_query(default is not None, "The database has no default " + self.alphabet.NAME_LOWER + " sequence name")
+            sequence_name = default
+        operators = []
+        for column_name in sorted(indexes):
+            if self.column_names and column_name not in self.column_names:
+                continue
+            if sequence_name not in indexes[column_name]:
+                continue
+            # InsertionIndex::search (insertion_index.cpp:271-281): the 3-mer index only pre-selects candidates, the
+            # answer is regex_search of the pattern over the distinct insertions at the position
+            bits = 0
+            for insertion, row_set in indexes[column_name][sequence_name].get(self.position, {}).items():
+                if re.search(self.value, insertion):
+                    bits |= bits_from_ids(sorted(row_set))
+            operators.append(IndexScan(bits, rows))  # BitmapProducer: a computed bitmap
+        if not operators:
+            return Empty(rows)
+        if len(operators) == 1:
+            return operators[0]
+        return Union(operators, rows)
+
+
+def parse_insertion_contains(node, alphabet):  # insertion_contains.cpp:155-214
+    import re
+
+    check_silo_query(
+        "column" not in node or isinstance(node["column"], (str, list)),
+        "The InsertionsContains filter can have the field column of type string or an array of strings, but no other type",
+    )
+    column_names = []
+    if isinstance(node.get("column"), list):
+        for child in node["column"]:
+            check_silo_query(
+                isinstance(child, str),
+                "The field column of the InsertionsContains filter must have type string or an array, if present. Found:"
+                + json.dumps(child, separators=(",", ":")),
+            )
+            column_names.append(child)
+    elif isinstance(node.get("column"), str):
+        column_names.append(node["column"])
+    check_silo_query("position" in node, "The field 'position' is required in an InsertionContains expression")
+    check_silo_query(
+        _is_unsigned(node["position"]) and node["position"] > 0,
+        "The field 'position' in an InsertionContains expression needs to be a positive number (> 0)",
+    )
+    check_silo_query(
+        "sequenceName" not in node or isinstance(node["sequenceName"], str),
+        "The optional field 'sequenceName' in an InsertionContains expression needs to be a string",
+    )
+    check_silo_query("value" in node, "The field 'value' is required in an InsertionContains expression")
+    check_silo_query(isinstance(node["value"], str), "The field 'value' in an InsertionContains expression needs to be a string")
+    value = node["value"]
+    check_silo_query(value != "", "The field 'value' in an InsertionContains expression must not be an empty string")
+    symbols = "".join(alphabet.symbol_to_char(symbol) for symbol in alphabet.SYMBOLS)
+    valid = re.compile("^([" + re.escape(symbols).replace("\\-", "-") + "]|\\.\\*)*$")  # ^([symbols]|\.\*)*$
+    check_silo_query(
+        valid.search(value) is not None,
+        "The field 'value' in the InsertionContains expression does not contain a valid regex pattern: \"" + value
+        + "\". It must only consist of " + alphabet.NAME_LOWER + " symbols and the regex symbol '.*'.",
+    )
+    return InsertionContains(alphabet, column_names, node.get("sequenceName"), node["position"], value)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1745,6 +1854,90 @@ class Mutations(Action):
         return output
 
 
+class InsertionAggregation(Action):  # insertions.cpp
+    def __init__(self, alphabet, column_names, sequence_names):
+        super().__init__()
+        self.alphabet, self.column_names, self.sequence_names = alphabet, column_names, sequence_names
+
+    def validate_order_by_fields(self, database):  # :41-59
+        for f in self.order_by_fields:
+            check_silo_query(
+                f.name in ("position", "insertions", "sequenceName", "count"),
+                "OrderByField " + f.name + " is not contained in the result of this operation.",
+            )
+
+    def execute(self, database, filters):  # :126-258; rows come out of unordered_maps: the order is unspecified
+        symbol_name = "Nucleotide" if self.alphabet is Nucleotide else "Amino Acid"  # SymbolType::SYMBOL_NAME
+        wanted_kind = "insertion" if self.alphabet is Nucleotide else "aa_insertion"
+        for column_name in self.column_names:
+            check_silo_query(
+                database.column_type(column_name) == wanted_kind,
+                "The database does not contain the " + symbol_name + " column '" + column_name + "'",
+            )
+        references = database.sequence_store_names(self.alphabet)
+        for sequence_name in self.sequence_names:
+            check_silo_query(
+                sequence_name in references, "The database does not contain the " + symbol_name + " sequence '" + sequence_name + "'"
+            )
+        counts = {}  # sequence name -> (position, insertion) -> count
+        for partition, bitmap in zip(database.partitions, filters):
+            indexes = partition.nuc_insertion_indexes if self.alphabet is Nucleotide else partition.aa_insertion_indexes
+            if card(bitmap) == 0:
+                continue
+            selected = set(ids_from_bits(bitmap))
+            for column_name, index in indexes.items():
+                if self.column_names and column_name not in self.column_names:
+                    continue
+                for sequence_name, positions in index.items():
+                    if self.sequence_names and sequence_name not in self.sequence_names:
+                        continue
+                    per_sequence = counts.setdefault(sequence_name, {})
+                    for position, insertions in positions.items():
+                        for insertion, row_set in insertions.items():
+                            count = len(row_set & selected)
+                            if count > 0:
+                                per_sequence[(position, insertion)] = per_sequence.get((position, insertion), 0) + count
+        out = []
+        for sequence_name, per_sequence in counts.items():
+            for (position, insertion), count in per_sequence.items():
+                out.append({"position": position, "sequenceName": sequence_name, "insertions": insertion, "count": _to_int32(count)})
+        return out
+
+
+def parse_insertions(node, alphabet):  # insertions.cpp:260-302
+    check_silo_query(
+        "sequenceName" not in node or isinstance(node["sequenceName"], (str, list)),
+        "Insertions action can have the field sequenceName of type string or an array of strings, but no other type",
+    )
+    sequence_names = []
+    if isinstance(node.get("sequenceName"), list):
+        for child in node["sequenceName"]:
+            check_silo_query(
+                isinstance(child, str),
+                "The field sequenceName of the Insertions action must have type string or an array, if present. Found:"
+                + json.dumps(child, separators=(",", ":")),
+            )
+            sequence_names.append(child)
+    elif isinstance(node.get("sequenceName"), str):
+        sequence_names.append(node["sequenceName"])
+    check_silo_query(
+        "column" not in node or isinstance(node["column"], (str, list)),
+        "Insertions action can have the field column of type string or an array of strings, but no other type",
+    )
+    column_names = []
+    if isinstance(node.get("column"), list):
+        for child in node["column"]:
+            check_silo_query(
+                isinstance(child, str),
+                "The field column of the Insertions action must have type string or an array, if present. Found:"
+                + json.dumps(child, separators=(",", ":")),
+            )
+            column_names.append(child)
+    elif isinstance(node.get("column"), str):
+        column_names.append(node["column"])
+    return InsertionAggregation(alphabet, column_names, sequence_names)
+
+
 def parse_order_by_field(node):  # action.cpp:119-142
     if isinstance(node, str):
         return OrderByField(node, True)
@@ -1818,7 +2011,11 @@ def parse_action(node):  # action.cpp:144-187
         else:
             names.append(node["sequenceName"])
         action = FastaAligned(names)
-    elif kind in ("Fasta", "Insertions", "AminoAcidInsertions"):
+    elif kind == "Insertions":
+        action = parse_insertions(node, Nucleotide)
+    elif kind == "AminoAcidInsertions":
+        action = parse_insertions(node, AminoAcid)
+    elif kind == "Fasta":
         raise NotImplementedError(kind + " is outside the oracle's path")
     else:
         raise QueryParseException(kind + " is not a valid action")

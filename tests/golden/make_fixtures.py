@@ -24,9 +24,12 @@ HOT_FILTERS = {
 HOT_ACTIONS = {"Aggregated", "Mutations", "AminoAcidMutations"}
 # SURVEY.md §8(f) "next" rows: metadata predicates feeding the filter tree, Aggregated with groupByFields, Details,
 # FastaAligned.  Their fixtures go to queries_next/ and invalidQueries_next/.
-NEXT_FILTERS = HOT_FILTERS | {"StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "DateBetween"}
-NEXT_ACTIONS = HOT_ACTIONS | {"Details", "FastaAligned"}
-NEXT_INVALID = {"GroupByLineageInvalidOrderBy.json", "OffsetNegative.json"}
+NEXT_FILTERS = HOT_FILTERS | {"StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "DateBetween",
+                              "InsertionContains", "AminoAcidInsertionContains"}
+NEXT_ACTIONS = HOT_ACTIONS | {"Details", "FastaAligned", "Insertions", "AminoAcidInsertions"}
+NEXT_INVALID = {"GroupByLineageInvalidOrderBy.json", "OffsetNegative.json", "insertionContains_empty.json",
+                "insertionContains_invalidPattern.json", "insertionContains_invalidPattern2.json", "insertionsAAseparation.json",
+                "insertionsInvalidColumn.json", "insertionsInvalidSequence.json"}
 HOT_INVALID = {
     "sequencePos0Filter.json", "invalidMutationsMinProportion.json", "nuc_mutations_no_proportion.json",
     "aa_mutations_no_proportion.json", "invalidAction.json",

@@ -291,7 +291,18 @@ def test_reference_e2e_next_row_invalid_goldens(engines, case):
 
 
 def random_metadata_leaf(rng):
-    kind = rng.choice(["string", "indexed", "int_eq", "int_between", "float_eq", "float_between", "date", "unsorted_date"])
+    kind = rng.choice(["string", "indexed", "int_eq", "int_between", "float_eq", "float_between", "date", "unsorted_date", "insertion"])
+    if kind == "insertion":
+        if rng.random() < 0.5:
+            expr = {"type": "InsertionContains", "position": rng.choice([25701, 22339, 22204, 5959, 1]),
+                    "value": rng.choice(["CCC", "CC.*", ".*C.*G.*", "TAT", ".*", "G.*T", "AAAA"])}
+            if rng.random() < 0.5:
+                expr["column"] = "nucleotideInsertions"
+            if rng.random() < 0.3:
+                expr["sequenceName"] = rng.choice(["main", "testSecondSequence"])
+            return expr
+        return {"type": "AminoAcidInsertionContains", "position": rng.choice([214, 210, 247, 143]), "sequenceName": rng.choice(["S", "S", "N"]),
+                "value": rng.choice(["EPE", "E.*E", ".*", "IV", "T", "SGE.*"]), "column": "aminoAcidInsertions"}
     if kind == "string":
         return {"type": "StringEquals", "column": "gisaid_epi_isl", "value": rng.choice(["EPI_ISL_1749899", "EPI_ISL_1408408", "nope", None])}
     if kind == "indexed":
@@ -361,6 +372,30 @@ def test_random_group_by_and_details_match_oracle(engines):
         query = {"action": action, "filterExpression": expression}
         want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
         assert engine.execute_query(query) == want, json.dumps(query)
+
+
+def test_random_insertions_actions_match_oracle(engines):
+    engine, oracle_db = engines
+    rng = random.Random(808)
+    for trial in range(30):
+        if rng.random() < 0.5:
+            action = {"type": "Insertions"}
+            if rng.random() < 0.5:
+                action["column"] = rng.choice(["nucleotideInsertions", ["nucleotideInsertions"]])
+            if rng.random() < 0.4:
+                action["sequenceName"] = rng.choice(["main", ["main", "testSecondSequence"]])
+        else:
+            action = {"type": "AminoAcidInsertions"}
+            if rng.random() < 0.5:
+                action["column"] = "aminoAcidInsertions"
+            if rng.random() < 0.5:
+                action["sequenceName"] = rng.choice(["S", ["S", "N"], "ORF1a"])
+        query = {"action": action, "filterExpression": random_mixed_expression(rng, 2)}
+        want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+        assert as_multiset(engine.execute_query(query)) == as_multiset(want), json.dumps(query)
+        ordered = dict(action, orderByFields=["sequenceName", "position", "insertions"])
+        query = {"action": ordered, "filterExpression": query["filterExpression"]}
+        assert engine.execute_query(query) == json.loads(json.dumps(so.execute_query(oracle_db, query))), json.dumps(query)
 
 
 def test_fasta_aligned_matches_oracle(engines):
