@@ -49,7 +49,7 @@ constexpr uint32_t LEAF_BATCH = 8;
 
 // get(index): value of slot `index`, or of leaf (index - SILO_GPU_LEAF_OPERAND) for index >= SILO_GPU_LEAF_OPERAND
 // set(index, value): store into slot `index`        leaf(i): value of leaf i (a global load on the device)
-template <class T, class GetFn, class SetFn, class LeafFn>
+template <class T, uint32_t BATCH = LEAF_BATCH, class GetFn, class SetFn, class LeafFn>
 SILO_HD T bitprog_run(const uint32_t* code, uint32_t n_instructions, T valid, GetFn get, SetFn set, LeafFn leaf) {
    const T ones = ~zeroOf<T>();
    for (uint32_t pc = 0; pc < n_instructions; ++pc) {
@@ -90,15 +90,15 @@ SILO_HD T bitprog_run(const uint32_t* code, uint32_t n_instructions, T valid, Ge
             const uint32_t count = imm >> 16;
             const uint32_t last = first + count - 1;
             T acc = op == SILO_GPU_OP_OR_N ? zeroOf<T>() : ones;
-            for (uint32_t i = 0; i < count; i += LEAF_BATCH) {
-               T value[LEAF_BATCH];
+            for (uint32_t i = 0; i < count; i += BATCH) {
+               T value[BATCH];
 #pragma unroll
-               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {  // clamped: the last leaf is re-read, never a branch around a load
+               for (uint32_t k = 0; k < BATCH; ++k) {  // clamped: the last leaf is re-read, never a branch around a load
                   const uint32_t index = first + i + k;
                   value[k] = leaf(index < last ? index : last);
                }
 #pragma unroll
-               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {
+               for (uint32_t k = 0; k < BATCH; ++k) {
                   acc = op == SILO_GPU_OP_OR_N ? (acc | value[k]) : (acc & value[k]);
                }
             }
@@ -120,15 +120,15 @@ SILO_HD T bitprog_run(const uint32_t* code, uint32_t n_instructions, T valid, Ge
             // add every leaf of the run (or its complement within `valid`) to the counter dst .. dst+b-1
             const uint32_t first = imm & 0xFFFFu;
             const uint32_t count = imm >> 16;
-            for (uint32_t i = 0; i < count; i += LEAF_BATCH) {
-               T value[LEAF_BATCH];
+            for (uint32_t i = 0; i < count; i += BATCH) {
+               T value[BATCH];
 #pragma unroll
-               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {
+               for (uint32_t k = 0; k < BATCH; ++k) {
                   const uint32_t index = first + i + k;
                   value[k] = leaf(index < first + count ? index : first + count - 1);
                }
 #pragma unroll
-               for (uint32_t k = 0; k < LEAF_BATCH; ++k) {  // static index into value[]: stays in registers
+               for (uint32_t k = 0; k < BATCH; ++k) {  // static index into value[]: stays in registers
                   if (i + k < count) {
                      T carry = op == SILO_GPU_OP_CNT_ADD_N ? value[k] : (~value[k] & valid);
                      for (uint32_t bit = 0; bit < b; ++bit) {

@@ -33,6 +33,7 @@ thread_local const char* g_last_scan_kernel = "none";
 
 std::atomic<int> g_tune_rows_per_block{0};
 std::atomic<int> g_tune_scan_variant{0};
+std::atomic<int> g_tune_eval_leaf_batch{0};
 
 int fail(int code, const std::string& msg) {
    g_last_error = msg;
@@ -512,6 +513,7 @@ struct FilterEvalArgs {
    uint32_t code[2 * SILO_GPU_MAX_INSTRUCTIONS];
 };
 
+template <uint32_t BATCH>
 __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
    extern __shared__ ulonglong2 s_slots[];  // [n_slots][EVAL_THREADS]
    using silo_gpu::Word2;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalAr
    };
    const auto set = [&](uint32_t index, Word2 value) { s_slots[index * EVAL_THREADS + lane] = make_ulonglong2(value.x, value.y); };
 
-   Word2 result = silo_gpu::bitprog_run<Word2>(args.code, args.n_instructions, valid, get, set, leaf);
+   Word2 result = silo_gpu::bitprog_run<Word2, BATCH>(args.code, args.n_instructions, valid, get, set, leaf);
    result = result & valid;
    if (active && args.out != nullptr) {
       *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
@@ -936,6 +938,9 @@ int silo_gpu_tune(int knob, int value) {
    }
    if (knob == SILO_GPU_TUNE_SCAN_VARIANT) {
       return g_tune_scan_variant.exchange(value);
+   }
+   if (knob == SILO_GPU_TUNE_EVAL_LEAF_BATCH) {
+      return g_tune_eval_leaf_batch.exchange(value);
    }
    return -1;
 }
@@ -1749,7 +1754,11 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
    memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
    const uint32_t blocks = (store->row_words + EVAL_WORDS_PER_BLOCK - 1) / EVAL_WORDS_PER_BLOCK;
    const size_t lds_bytes = static_cast<size_t>(program->n_slots) * EVAL_THREADS * sizeof(ulonglong2);  // <= 32 KiB
-   k_filter_eval<<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
+   if (g_tune_eval_leaf_batch.load() == 16) {
+      k_filter_eval<16><<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
+   } else {
+      k_filter_eval<8><<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
+   }
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }

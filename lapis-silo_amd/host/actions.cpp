@@ -362,6 +362,7 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
 
    const PrefilteredBitmaps no_bitmaps{};
    std::vector<std::string> scanned;  // a store requested twice is scanned once
+   try {
    for (const auto& sequence_name : pending->sequence_names) {
       if (std::find(scanned.begin(), scanned.end(), sequence_name) != scanned.end()) {
          continue;
@@ -401,6 +402,11 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
    } else {
       allReduce(database, device_counts, n_counts);  // the whole query in one collective
       select_and_fetch();
+   }
+   } catch (...) {
+      // launches of this query may be in flight on the stream: let them finish before its buffers return to the pool
+      (void)silo_gpu_stream_synchronize(queryStream());
+      throw;
    }
    return pending;
 }

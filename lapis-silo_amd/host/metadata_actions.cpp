@@ -22,6 +22,14 @@ const MetadataColumnPartition& columnOf(const DatabasePartition& partition, cons
    return found->second;
 }
 
+/// Under position-range sharding every rank holds every row (and every metadata column), so row-wise actions simply
+/// run on each rank; a sequence-id shard sees only its own rows and would need a gather that is not built.
+void requireAllRowsLocal(const Database& database, const char* what) {
+   if (database.shard_world > 1 && !database.shard_by_position) {
+      throw std::runtime_error(std::string(what) + " is not supported on a database sharded by sequence id");
+   }
+}
+/// Needs every position of a sequence on this device.
 void requireUnsharded(const Database& database, const char* what) {
    if (database.shard_world > 1) {
       throw std::runtime_error(std::string(what) + " is not supported on a sharded (multi-GPU) database");
@@ -52,7 +60,7 @@ std::vector<uint32_t> selectedRows(const DatabasePartition& partition, const Ope
 
 // ---- Aggregated with groupByFields ---------------------------------------------------------------------
 QueryResult Aggregated::aggregateWithGrouping(const Database& database, std::vector<OperatorResult>& bitmap_filter) const {
-   requireUnsharded(database, "Aggregated with groupByFields");
+   requireAllRowsLocal(database, "Aggregated with groupByFields");
    struct Group {
       uint32_t count = 0;
       std::vector<JsonValue> values;
@@ -202,7 +210,7 @@ QueryResult Details::finish(const Database& database, Pending& pending) const {
 
 QueryResult Details::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // details.cpp:186-219
    validateOrderByFields(database);
-   requireUnsharded(database, "Details");
+   requireAllRowsLocal(database, "Details");
    const std::vector<storage::ColumnMetadata> field_metadata = parseFields(database, fields);
 
    struct Row {
@@ -308,7 +316,7 @@ QueryResult InsertionAggregation<SymbolType>::execute(const Database& database, 
          "The database does not contain the " + std::string(SymbolType::SYMBOL_NAME) + " sequence '" + sequence_name + "'"
       )
    }
-   requireUnsharded(database, "Insertions");
+   requireAllRowsLocal(database, "Insertions");
 
    // One k_count_pairs launch per (partition, column, sequence): the and_cardinality of the filter with the rows of
    // every distinct insertion at once (:196-206).  Launch all, then fetch.

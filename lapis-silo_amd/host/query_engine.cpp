@@ -79,6 +79,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
    std::vector<std::unique_ptr<actions::Action::Pending>> pending(queries.size());
    actions::ScanBatcher batcher;  // active on this thread until the end of the function
    for (size_t i = 0; i < queries.size(); ++i) {  // phase 1: parse, compile, evaluate filters, queue scans
+      const actions::ScanBatcher::Checkpoint mark = batcher.checkpoint();
       try {
          parsed[i] = std::make_unique<Query>(queries[i]);
          std::vector<OperatorResult> partition_filters(database.partitions.size());
@@ -90,6 +91,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
          }
          pending[i] = parsed[i]->action->begin(database, std::move(partition_filters));
       } catch (...) {
+         batcher.rollback(mark);  // scans recorded by the failed query point into buffers that are gone
          outcomes[i].error = std::current_exception();
       }
    }

@@ -534,6 +534,16 @@ class ScanBatcher {
    void addReduction(const Database& database, uint32_t* device_values, size_t n) { reductions.push_back({&database, device_values, n}); }
    /// Work that has to follow the launches (and reductions) of the batch on the stream, e.g. fetching the results.
    void afterFlush(std::function<void()> callback) { after_flush.push_back(std::move(callback)); }
+   /// What a query recorded can be dropped again when it fails before the flush (its buffers die with it).
+   struct Checkpoint {
+      size_t requests, reductions, after_flush;
+   };
+   [[nodiscard]] Checkpoint checkpoint() const { return {requests.size(), reductions.size(), after_flush.size()}; }
+   void rollback(const Checkpoint& mark) {
+      requests.resize(mark.requests);
+      reductions.resize(mark.reductions);
+      after_flush.resize(mark.after_flush);
+   }
    void flush();
 
   private:
