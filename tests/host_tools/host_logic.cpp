@@ -1,0 +1,58 @@
+// host_logic.cpp — test hooks into the pure host functions of libsilo_engine.so (no device is touched):
+// date parsing, lineage (un)aliasing, insertion standardisation.  Built by silo_amd/build.py for the CPU tests.
+#include <cstring>
+#include <string>
+
+#include "database.h"
+
+namespace {
+int copyOut(const std::string& text, char* out, size_t capacity) {
+   if (text.size() + 1 > capacity) {
+      return -2;
+   }
+   std::memcpy(out, text.c_str(), text.size() + 1);
+   return static_cast<int>(text.size());
+}
+}  // namespace
+
+extern "C" {
+
+uint32_t t_string_to_date(const char* text) {
+   return silo::common::stringToDate(text);
+}
+
+int t_date_to_string(uint32_t date, char* out, size_t capacity) {
+   const auto text = silo::common::dateToString(date);
+   return text.has_value() ? copyOut(*text, out, capacity) : -1;
+}
+
+/// mode 0: unalias, 1: alias (of an unaliased lineage), 2: alias(unalias(lineage)) — what a lineage column renders
+int t_lineage(const char* alias_json, const char* lineage, int mode, char* out, size_t capacity) {
+   try {
+      const auto lookup = silo::PangoLineageAliasLookup::fromJson(silo::json::parse(alias_json));
+      std::string value = lineage;
+      if (mode == 0 || mode == 2) {
+         value = lookup.unaliasPangoLineage(value);
+      }
+      if (mode == 1 || mode == 2) {
+         value = lookup.aliasPangoLineage(value);
+      }
+      return copyOut(value, out, capacity);
+   } catch (const std::exception&) {
+      return -1;
+   }
+}
+
+/// Standardised text of an insertion column value (default_sequence may be NULL); -1 for a malformed value.
+int t_insertion_standardise(const char* default_sequence, const char* value, char* out, size_t capacity) {
+   try {
+      silo::storage::column::InsertionColumnPartition column(
+         default_sequence != nullptr ? std::optional<std::string>(default_sequence) : std::nullopt
+      );
+      return copyOut(column.insert(value, 0), out, capacity);
+   } catch (const std::exception&) {
+      return -1;
+   }
+}
+
+}  // extern "C"

@@ -112,3 +112,67 @@ def test_bitprog_semantics(bitprog, n):
             code += b.encode(b.OP_LOAD, 0, imm=leaf) + b.encode(b.OP_CNT_ADD, 1, 0, 3)
         assert np.array_equal(bitprog(code + b.encode(b.OP_CNT_GE, 0, 1, 3, imm=k), masks, n), total >= k), k
         assert np.array_equal(bitprog(code + b.encode(b.OP_CNT_EQ, 0, 1, 3, imm=k), masks, n), total == k), k
+
+
+# ---- pure host functions of the engine against the oracle's restatement (no device) ---------------------------------
+@pytest.fixture(scope="module")
+def host_logic(built):
+    import json
+
+    path = os.path.join(ROOT, "lapis-silo_amd", "lib", "libhost_logic.so")
+    if not os.path.exists(path):
+        pytest.fail("libhost_logic.so has not been built")
+    lib = ctypes.CDLL(path)
+    lib.t_string_to_date.restype = ctypes.c_uint32
+    lib.t_string_to_date.argtypes = [ctypes.c_char_p]
+    lib.t_date_to_string.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    lib.t_lineage.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    lib.t_insertion_standardise.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.alias_json = open(os.path.join(ROOT, "tests", "golden", "exampleDataset", "pangolineage_alias.json")).read().encode()
+    lib.alias_dict = json.loads(lib.alias_json)
+    return lib
+
+
+def test_dates_match_oracle(host_logic):
+    from oracle import silo_oracle as so
+
+    buffer = ctypes.create_string_buffer(64)
+    texts = ["2021-03-18", "2020-1-1", "", "2021", "2021-13-01", "2021-00-10", "2021-02-31", "2021-02-32", "x-y-z", "2021-03-18T10:00",
+             "0001-01-01", "99999-12-31", "2021-3", " 2021-03-04", "2021-03-4x", "-5-03-04"]
+    for text in texts:
+        date = host_logic.t_string_to_date(text.encode())
+        assert date == so.string_to_date(text), text
+        n = host_logic.t_date_to_string(date, buffer, 64)
+        assert (buffer.value.decode() if n >= 0 else None) == so.date_to_string(date), text
+
+
+def test_lineage_aliases_match_oracle(host_logic):
+    from oracle import silo_oracle as so
+    from tests import dataset
+
+    lookup = so.PangoLineageAliasLookup(host_logic.alias_dict)
+    lineages = sorted({row["pango_lineage"] for row in dataset.load_example_dataset()["rows"]})
+    lineages += ["B.1.617.2.43", "B.1.617.2", "AY.43", "XA.1", "X", "Q.1", "BA.5.2.1.7", "B.1.1.529.5.2.1.7", "nonsense", "", "AY", "B.1.1.7.", "Q.3 . 4"]
+    buffer = ctypes.create_string_buffer(256)
+    for lineage in lineages:
+        unaliased = lookup.unalias(lineage)
+        assert host_logic.t_lineage(host_logic.alias_json, lineage.encode(), 0, buffer, 256) >= 0
+        assert buffer.value.decode() == unaliased, lineage
+        assert host_logic.t_lineage(host_logic.alias_json, unaliased.encode(), 1, buffer, 256) >= 0
+        assert buffer.value.decode() == lookup.alias(unaliased), lineage
+        assert host_logic.t_lineage(host_logic.alias_json, lineage.encode(), 2, buffer, 256) >= 0
+        assert buffer.value.decode() == lookup.alias(unaliased), lineage
+
+
+def test_insertion_values_are_standardised_like_the_reference(host_logic):
+    """insertion_column.cpp:31-113: entries without a sequence name belong to the default sequence and are written
+    back without it; quotes are dropped; malformed entries are errors."""
+    buffer = ctypes.create_string_buffer(512)
+    cases = [
+        (b"main", "22204:CAGAA", "22204:CAGAA"), (b"main", "main:22204:CAGAA", "22204:CAGAA"), (b"main", "other:5:AC,7:G", "other:5:AC,7:G"),
+        (b"main", '"25701:CCC"', "25701:CCC"), (None, "S:214:EPE,ORF1a:3:T", "S:214:EPE,ORF1a:3:T"), (b"main", "", ""),
+        (None, "214:EPE", None), (b"main", "a:b", None), (b"main", "1:2:3:4", None), (b"main", "S:x:EPE", None), (b"main", "99999999999:A", None),
+    ]
+    for default_sequence, value, expected in cases:
+        n = host_logic.t_insertion_standardise(default_sequence, value.encode(), buffer, 512)
+        assert (buffer.value.decode() if n >= 0 else None) == expected, (default_sequence, value)
