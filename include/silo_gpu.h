@@ -205,6 +205,19 @@ int silo_gpu_filter_eval(
 );
 
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
+/* Count slot: the cardinality of a filter without a copy or a stream synchronisation.  The last block of the K3
+ * launch sums the count shards, stores the total into page-locked host memory (system-scope store) and re-arms the
+ * slot; silo_gpu_count_slot_wait spins on that word (and checks the stream from time to time, so a failed launch is an
+ * error, not a hang).  One slot serves one launch at a time; a host thread keeps its own.  Replaces
+ * roaring::cardinality() at the end of Operator::evaluate for Aggregated (aggregated.cpp:61). */
+typedef struct silo_gpu_count_slot silo_gpu_count_slot;
+int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot);
+void silo_gpu_count_slot_destroy(silo_gpu_count_slot* slot);
+int silo_gpu_filter_eval_count(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev /* may be NULL */, silo_gpu_count_slot* slot,
+   void* stream
+);
+int silo_gpu_count_slot_wait(silo_gpu_count_slot* slot, uint64_t* out_count, void* stream);
 int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev /* shards, accumulated */, void* stream);
 
 /* ---- K5 / K6: metadata columns -------------------------------------------------

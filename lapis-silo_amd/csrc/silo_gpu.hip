@@ -509,6 +509,8 @@ struct FilterEvalArgs {
    uint32_t n_slots;
    uint64_t* out;
    unsigned long long* out_count;
+   uint32_t* ticket;                 // count slot: blocks done so far
+   unsigned long long* host_total;   // count slot: page-locked host word the last block stores the total into
    const uint64_t* leaves[SILO_GPU_MAX_LEAVES];
    uint32_t code[2 * SILO_GPU_MAX_INSTRUCTIONS];
 };
@@ -543,9 +545,47 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalAr
    if (active && args.out != nullptr) {
       *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
    }
-   if (args.out_count != nullptr) {
+   if (args.out_count != nullptr && args.ticket == nullptr) {
       const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
       addToCountShard(args.out_count, waveSumToLane63(bits));
+   }
+   if (args.ticket != nullptr) {
+      // Count slot: the last block to get here sums the shards, hands the total to the host through page-locked
+      // memory (no copy, no stream synchronisation on the host side) and re-arms shards and tickets for the next
+      // launch.  Atomics on one word serialise at ~12 ns each, so "last" is found in two levels: a ticket per shard
+      // class (blocks b with b % 64 == c), and a main ticket taken by the block that completes its class.
+      // Ordering uses only the atomics themselves (all performed at device scope, i.e. at the memory side): the shard
+      // add is a RETURNING atomic, so it has been performed when its result arrives, and the ticket is taken after
+      // that.  A __threadfence() here would be a release fence = an L2 write-back per block (the L2s of the 8 XCDs are
+      // not coherent with each other), which doubled the kernel time when tried.
+      const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
+      const uint32_t wave_total = waveSumToLane63(bits);
+      uint32_t last = 0;
+      if (lane == 63) {
+         const uint32_t shard_class = blockIdx.x % SILO_GPU_COUNT_SHARDS;
+         unsigned long long before = 0;
+         if (wave_total != 0) {
+            before = atomicAdd(args.out_count + shard_class, static_cast<unsigned long long>(wave_total));
+         }
+         // the ticket increment is made to depend on the value the shard add returned
+         const uint32_t one = 1u + static_cast<uint32_t>((before >> 63) & 1ull);  // a shard never reaches 2^63: always 1
+         const uint32_t blocks_in_class = (gridDim.x - 1 - shard_class) / SILO_GPU_COUNT_SHARDS + 1;
+         const uint32_t class_ticket = atomicAdd(args.ticket + 1 + shard_class, one);
+         if (class_ticket == blocks_in_class - 1) {
+            const uint32_t classes = min(gridDim.x, static_cast<uint32_t>(SILO_GPU_COUNT_SHARDS));
+            const uint32_t cleared = atomicExch(args.ticket + 1 + shard_class, 0u);
+            last = atomicAdd(args.ticket, 1u + (cleared >> 31)) == classes - 1 ? 1u : 0u;
+         }
+      }
+      last = __shfl(last, 63);
+      if (last != 0) {
+         const unsigned long long shard = atomicExch(args.out_count + lane, 0ull);  // EVAL_THREADS == SILO_GPU_COUNT_SHARDS
+         const uint32_t total = waveSumToLane63(static_cast<uint32_t>(shard));      // a cardinality fits 32 bits
+         if (lane == 63) {
+            atomicExch(args.ticket, 0u);
+            __hip_atomic_store(args.host_total, static_cast<unsigned long long>(total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+         }
+      }
    }
 }
 
@@ -1677,7 +1717,109 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
    return SILO_GPU_OK;
 }
 
+struct silo_gpu_count_slot {
+   unsigned long long* d_shards = nullptr;  // SILO_GPU_COUNT_SHARDS words + the tickets behind them
+   uint32_t* d_ticket = nullptr;
+   unsigned long long* host_total = nullptr;    // page-locked, written by the kernel
+   unsigned long long* host_total_dev = nullptr;  // its device address
+};
+
+namespace {
+constexpr unsigned long long COUNT_PENDING = ~0ull;
+int filterEvalLaunch(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
+   unsigned long long* host_total_dev, void* stream
+);
+}  // namespace
+
 int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream) {
+   return filterEvalLaunch(store, program, out_bitset_dev, out_count_dev, nullptr, nullptr, stream);
+}
+
+int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot) {
+   if (out_slot == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_count_slot_create: null out pointer");
+   }
+   auto* slot = new (std::nothrow) silo_gpu_count_slot;
+   if (slot == nullptr) {
+      return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of host memory");
+   }
+   // 64 count shards (64-bit), then the main ticket and one ticket per shard class (32-bit)
+   const size_t device_bytes = SILO_GPU_COUNT_SHARDS * sizeof(unsigned long long) + (1 + SILO_GPU_COUNT_SHARDS) * sizeof(uint32_t);
+   hipError_t err = hipMalloc(&slot->d_shards, device_bytes);
+   if (err == hipSuccess) {
+      err = hipMemset(slot->d_shards, 0, device_bytes);
+   }
+   if (err == hipSuccess) {
+      slot->d_ticket = reinterpret_cast<uint32_t*>(slot->d_shards + SILO_GPU_COUNT_SHARDS);
+      err = hipHostMalloc(&slot->host_total, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+   }
+   if (err == hipSuccess) {
+      *slot->host_total = COUNT_PENDING;
+      err = hipHostGetDevicePointer(reinterpret_cast<void**>(&slot->host_total_dev), slot->host_total, 0);
+   }
+   if (err != hipSuccess) {
+      silo_gpu_count_slot_destroy(slot);
+      HIP_TRY(err);
+   }
+   *out_slot = slot;
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_count_slot_destroy(silo_gpu_count_slot* slot) {
+   if (slot != nullptr) {
+      (void)hipFree(slot->d_shards);
+      if (slot->host_total != nullptr) {
+         (void)hipHostFree(slot->host_total);
+      }
+      delete slot;
+   }
+}
+
+int silo_gpu_filter_eval_count(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, silo_gpu_count_slot* slot, void* stream
+) {
+   if (slot == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval_count: null slot");
+   }
+   __atomic_store_n(slot->host_total, COUNT_PENDING, __ATOMIC_RELEASE);
+   return filterEvalLaunch(
+      store, program, out_bitset_dev, reinterpret_cast<uint64_t*>(slot->d_shards), slot->d_ticket, slot->host_total_dev, stream
+   );
+}
+
+int silo_gpu_count_slot_wait(silo_gpu_count_slot* slot, uint64_t* out_count, void* stream) {
+   if (slot == nullptr || out_count == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_count_slot_wait: null argument");
+   }
+   // the kernel's last block stores the total with system scope; a launch that never finishes shows up on the stream
+   for (uint64_t spin = 0;; ++spin) {
+      const unsigned long long value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
+      if (value != COUNT_PENDING) {
+         *out_count = value;
+         return SILO_GPU_OK;
+      }
+      if ((spin & 0xFFFFu) == 0xFFFFu) {
+         const hipError_t status = hipStreamQuery(static_cast<hipStream_t>(stream));
+         if (status != hipErrorNotReady) {
+            // the stream is idle (or broken): either the store has just landed or the kernel did not run to its end
+            const unsigned long long final_value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
+            if (status == hipSuccess && final_value != COUNT_PENDING) {
+               *out_count = final_value;
+               return SILO_GPU_OK;
+            }
+            HIP_TRY(status);
+            return fail(SILO_GPU_ERR_HIP, "count slot: the kernel finished without delivering its total");
+         }
+      }
+   }
+}
+
+namespace {
+int filterEvalLaunch(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
+   unsigned long long* host_total_dev, void* stream
+) {
    if (store == nullptr || program == nullptr || program->code == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
    }
@@ -1748,6 +1890,8 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
    args.n_slots = program->n_slots;
    args.out = out_bitset_dev;
    args.out_count = reinterpret_cast<unsigned long long*>(out_count_dev);
+   args.ticket = ticket_dev;
+   args.host_total = host_total_dev;
    for (uint32_t k = 0; k < program->n_leaves; ++k) {
       args.leaves[k] = program->leaves[k];
    }
@@ -1762,6 +1906,7 @@ int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* pr
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }
+}  // namespace
 
 int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev, void* stream) {
    if (store == nullptr || bitset_dev == nullptr || out_count_dev == nullptr) {

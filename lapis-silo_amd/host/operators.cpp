@@ -60,19 +60,19 @@ void OperatorResult::materialize() const {
    }
    const DatabasePartition& partition = *state->rows.partition;
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
-   DeviceBuffer counter = zeroedCounter(partition);
    const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
    if (scan != nullptr && !scan->sparse) {
+      DeviceBuffer counter = zeroedCounter(partition);
       state->borrowed = scan->bitmap;  // index_scan.cpp:28-30: borrow, no copy
       checkGpu(silo_gpu_popcount(partition.store, scan->bitmap, counter.as<uint64_t>(), queryStream()), "silo_gpu_popcount");
+      state->count = readCount(counter);
    } else {
       DeviceBuffer out = partition.pool.acquire(row_bytes);
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
-      builder.run(slot, out.as<uint64_t>(), counter.as<uint64_t>(), queryStream());
+      state->count = builder.runCounting(slot, out.as<uint64_t>(), queryStream());
       state->bitset = std::move(out);
    }
-   state->count = readCount(counter);
 }
 
 uint32_t OperatorResult::cardinality() const {
@@ -91,11 +91,9 @@ uint32_t OperatorResult::cardinality() const {
          state->count = state->rows.row_count;
          return *state->count;
       }
-      DeviceBuffer counter = zeroedCounter(partition);
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
-      builder.run(slot, nullptr, counter.as<uint64_t>(), queryStream());
-      state->count = readCount(counter);
+      state->count = builder.runCounting(slot, nullptr, queryStream());
       return *state->count;
    }
 }
@@ -244,7 +242,7 @@ uint32_t ProgramBuilder::lowerChild(const operators::Operator& child) {
    return operand;
 }
 
-void ProgramBuilder::run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream) {
+silo_gpu_bitprog ProgramBuilder::finishProgram(uint32_t result_slot) {
    if (result_slot != 0) {
       emit(SILO_GPU_OP_MOV, 0, result_slot);
       high_water = std::max(high_water, 1u);
@@ -258,11 +256,39 @@ void ProgramBuilder::run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* o
    program.n_leaves = static_cast<uint32_t>(leaves.size());
    program.leaves = leaves.data();
    program.n_slots = std::max(high_water, 1u);
+   return program;
+}
+
+void ProgramBuilder::run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream) {
+   const silo_gpu_bitprog program = finishProgram(result_slot);
    checkGpu(silo_gpu_filter_eval(rows.partition->store, &program, out_bitset, out_count, stream), "silo_gpu_filter_eval");
    if (!temporaries.empty() || !materialized_children.empty()) {
       // temporaries go back to the pool when the builder dies: make sure the kernel is done with them
       checkGpu(silo_gpu_stream_synchronize(stream), "silo_gpu_stream_synchronize");
    }
+}
+
+namespace {
+/// One count slot per host thread (a slot serves one launch at a time).  Never destroyed: thread exit may come
+/// after the HIP runtime has shut down.
+silo_gpu_count_slot* threadCountSlot() {
+   thread_local silo_gpu_count_slot* slot = nullptr;
+   if (slot == nullptr) {
+      checkGpu(silo_gpu_count_slot_create(&slot), "silo_gpu_count_slot_create");
+   }
+   return slot;
+}
+}  // namespace
+
+uint32_t ProgramBuilder::runCounting(uint32_t result_slot, uint64_t* out_bitset, void* stream) {
+   const silo_gpu_bitprog program = finishProgram(result_slot);
+   silo_gpu_count_slot* slot = threadCountSlot();
+   checkGpu(silo_gpu_filter_eval_count(rows.partition->store, &program, out_bitset, slot, stream), "silo_gpu_filter_eval_count");
+   uint64_t count = 0;
+   // the total arrives when the last block is done: every block has read its leaves by then, so the temporaries of
+   // this builder may go back to the pool without a stream synchronisation
+   checkGpu(silo_gpu_count_slot_wait(slot, &count, stream), "silo_gpu_count_slot_wait");
+   return static_cast<uint32_t>(count);
 }
 
 namespace operators {

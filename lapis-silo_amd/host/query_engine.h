@@ -122,6 +122,14 @@ class ProgramBuilder {
 
    /// Launches the program (result expected in `result_slot`).
    void run(uint32_t result_slot, uint64_t* out_bitset, uint64_t* out_count, void* stream);
+   /// Launches the program and returns the cardinality of its result, delivered by the kernel itself through this
+   /// thread's count slot (no counter memset, no device-to-host copy, no stream synchronisation).
+   uint32_t runCounting(uint32_t result_slot, uint64_t* out_bitset, void* stream);
+
+  private:
+   silo_gpu_bitprog finishProgram(uint32_t result_slot);
+
+  public:
 
    const RowSpace rows;
 
