@@ -515,6 +515,9 @@ struct FilterEvalArgs {
    uint32_t code[2 * SILO_GPU_MAX_INSTRUCTIONS];
 };
 
+// Tried and dropped (profiles/r01_k3_variants.md): 16 instead of 8 leaf loads in flight per n-ary instruction, and
+// fetching the first 24 leaves up front into LDS (register-staged: spilled to scratch; LDS-DMA global_load_lds_dwordx4:
+// no spill) — neither moved the kernel time of the 32-column program (19-21 us at 10 M sequences either way).
 template <uint32_t BATCH>
 __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
    extern __shared__ ulonglong2 s_slots[];  // [n_slots][EVAL_THREADS]

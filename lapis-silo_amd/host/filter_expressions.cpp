@@ -417,6 +417,52 @@ std::unique_ptr<Operator> NOf::compile(const Database& database, const DatabaseP
    );
 }
 
+namespace {
+
+/// "Symbol or any ambiguity code that may stand for it" (UPPER_BOUND, nucleotide_symbol_equals.cpp:137-149) is the
+/// OR of up to 8 planes, most of them nearly empty IUPAC planes.  The database is immutable, so the combined plane
+/// is built once (one fused launch) and kept in the partition's derived-plane cache next to the materialised sparse
+/// planes; later queries read ONE column instead of up to eight.  Beyond the cache budget the plain Or is returned.
+std::unique_ptr<Operator> cachedUpperBoundPlane(
+   const Database& database, const DatabasePartition& partition, uint32_t seqstore_id, uint32_t position, uint32_t symbol,
+   std::unique_ptr<Operator> expanded
+) {
+   const RowSpace rows = rowsOf(partition);
+   if (database.broadcast != nullptr || expanded->type() == operators::INDEX_SCAN || expanded->type() == operators::EMPTY ||
+       expanded->type() == operators::FULL) {
+      return expanded;  // leaf exchange between ranks is in play, or there is nothing to combine
+   }
+   const uint64_t key = (uint64_t{1} << 63) | (static_cast<uint64_t>(seqstore_id) << 40) | (static_cast<uint64_t>(position) << 8) | symbol;
+   const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
+   {
+      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const auto found = partition.sparse_cache.find(key);
+      if (found != partition.sparse_cache.end()) {
+         return std::make_unique<operators::IndexScan>(found->second.as<uint64_t>(), rows);
+      }
+      if ((partition.sparse_cache.size() + 1) * row_bytes > DatabasePartition::SPARSE_CACHE_BYTES) {
+         return expanded;
+      }
+   }
+   DeviceBuffer buffer = partition.pool.acquire(row_bytes);
+   {
+      ProgramBuilder builder(rows);
+      const uint32_t slot = expanded->lower(builder);
+      builder.run(slot, buffer.as<uint64_t>(), nullptr, queryStream());
+   }
+   // other threads (on their own streams) may pick the plane up from the cache at once: finish it first
+   checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");
+   const uint64_t* pointer = buffer.as<uint64_t>();
+   {
+      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const auto [entry, inserted] = partition.sparse_cache.try_emplace(key, std::move(buffer));
+      pointer = entry->second.as<uint64_t>();  // another thread may have been first: use its plane, ours returns to the pool
+   }
+   return std::make_unique<operators::IndexScan>(pointer, rows);
+}
+
+}  // namespace
+
 // ---- NucleotideSymbolEquals (nucleotide_symbol_equals.cpp:94-189) -----------------------------------
 std::string NucleotideSymbolEquals::toString(const Database& /*database*/) const {
    const std::string prefix = nuc_sequence_name ? nuc_sequence_name.value() + ":" : "";
@@ -446,7 +492,10 @@ std::unique_ptr<Operator> NucleotideSymbolEquals::compile(
       for (const auto symbol : symbols_to_match) {
          symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
       }
-      return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+      return cachedUpperBoundPlane(
+         database, database_partition, seq_store_partition.seqstore_id, position, static_cast<uint32_t>(nucleotide_symbol),
+         Or(std::move(symbol_filters)).compile(database, database_partition, NONE)
+      );
    }
    return symbolPlane<Nucleotide>(database, seq_store_partition, database_partition, position, nucleotide_symbol);
 }
