@@ -23,11 +23,34 @@ class ParseError : public std::runtime_error {
    using std::runtime_error::runtime_error;
 };
 
+class Value;
+
+/// Object members in key order (what nlohmann's std::map-based object_t gives), held in one flat vector: a query
+/// object has a handful of keys, and a map node per member was most of the parse time.
+class ObjectMembers {
+  public:
+   using Member = std::pair<std::string, Value>;
+   ObjectMembers();
+   ObjectMembers(const ObjectMembers&);
+   ObjectMembers(ObjectMembers&&) noexcept;
+   ObjectMembers& operator=(ObjectMembers);
+   ~ObjectMembers();
+   [[nodiscard]] const Value* find(const std::string& key) const;
+   /// Inserts or overwrites (later duplicates win, as in nlohmann).
+   Value& insertOrAssign(std::string key, Value value);
+   [[nodiscard]] const Member* begin() const;
+   [[nodiscard]] const Member* end() const;
+   [[nodiscard]] size_t size() const;
+
+  private:
+   std::vector<Member>* members_;  // pointer: Value is incomplete here
+};
+
 class Value {
   public:
    enum class Kind { Null, Bool, Unsigned, Integer, Float, String, Array, Object };
    using Array = std::vector<Value>;
-   using Object = std::map<std::string, Value>;
+   using Object = ObjectMembers;
 
    Value() = default;
    Value(std::nullptr_t) {}
@@ -56,20 +79,24 @@ class Value {
    [[nodiscard]] bool is_object() const { return kind_ == Kind::Object; }
 
    [[nodiscard]] bool contains(const std::string& key) const {
-      return kind_ == Kind::Object && object_->count(key) != 0;
+      return kind_ == Kind::Object && object_->find(key) != nullptr;
    }
    [[nodiscard]] const Value& at(const std::string& key) const {
       if (kind_ != Kind::Object) {
          throw std::out_of_range("json value is not an object");
       }
-      return object_->at(key);
+      const Value* found = object_->find(key);
+      if (found == nullptr) {
+         throw std::out_of_range("key '" + key + "' not found");
+      }
+      return *found;
    }
    [[nodiscard]] const Value& operator[](const std::string& key) const { return at(key); }
    Value& set(const std::string& key, Value value) {
       if (kind_ != Kind::Object) {
          *this = object();
       }
-      return (*object_)[key] = std::move(value);
+      return object_->insertOrAssign(key, std::move(value));
    }
    void push_back(Value value) {
       if (kind_ != Kind::Array) {
@@ -199,6 +226,47 @@ class Value {
    }
 };
 
+inline ObjectMembers::ObjectMembers() : members_(new std::vector<Member>()) {}
+inline ObjectMembers::ObjectMembers(const ObjectMembers& other) : members_(new std::vector<Member>(*other.members_)) {}
+inline ObjectMembers::ObjectMembers(ObjectMembers&& other) noexcept : members_(other.members_) {
+   other.members_ = nullptr;
+}
+inline ObjectMembers& ObjectMembers::operator=(ObjectMembers other) {
+   std::swap(members_, other.members_);
+   return *this;
+}
+inline ObjectMembers::~ObjectMembers() {
+   delete members_;
+}
+inline const Value* ObjectMembers::find(const std::string& key) const {
+   for (const Member& member : *members_) {
+      if (member.first == key) {
+         return &member.second;
+      }
+   }
+   return nullptr;
+}
+inline Value& ObjectMembers::insertOrAssign(std::string key, Value value) {
+   auto position = members_->begin();
+   while (position != members_->end() && position->first < key) {
+      ++position;
+   }
+   if (position != members_->end() && position->first == key) {
+      position->second = std::move(value);
+      return position->second;
+   }
+   return members_->emplace(position, std::move(key), std::move(value))->second;
+}
+inline const ObjectMembers::Member* ObjectMembers::begin() const {
+   return members_->data();
+}
+inline const ObjectMembers::Member* ObjectMembers::end() const {
+   return members_->data() + members_->size();
+}
+inline size_t ObjectMembers::size() const {
+   return members_->size();
+}
+
 class Parser {
   public:
    explicit Parser(const std::string& text) : text_(text) {}
@@ -286,7 +354,7 @@ class Parser {
          }
          ++pos_;
          skipWhitespace();
-         object[std::move(key)] = parseValue(depth + 1);  // later duplicates win, as in nlohmann
+         object.insertOrAssign(std::move(key), parseValue(depth + 1));  // later duplicates win, as in nlohmann
          skipWhitespace();
          if (pos_ < text_.size() && text_[pos_] == ',') {
             ++pos_;
@@ -303,6 +371,7 @@ class Parser {
    Value parseArray(int depth) {
       ++pos_;
       Value::Array array;
+      array.reserve(8);
       skipWhitespace();
       if (pos_ < text_.size() && text_[pos_] == ']') {
          ++pos_;

@@ -3,7 +3,10 @@
 #include <cstring>
 #include <string>
 
+#include <chrono>
+
 #include "database.h"
+#include "query_engine.h"
 
 namespace {
 int copyOut(const std::string& text, char* out, size_t capacity) {
@@ -50,6 +53,23 @@ int t_insertion_standardise(const char* default_sequence, const char* value, cha
          default_sequence != nullptr ? std::optional<std::string>(default_sequence) : std::nullopt
       );
       return copyOut(column.insert(value, 0), out, capacity);
+   } catch (const std::exception&) {
+      return -1;
+   }
+}
+
+/// Average microseconds to parse `query_json` into a Query (JSON -> Expression tree + Action), or -1 if it is invalid.
+double t_parse_query_us(const char* query_json, int repetitions) {
+   try {
+      const std::string text = query_json;
+      const auto start = std::chrono::steady_clock::now();
+      for (int i = 0; i < repetitions; ++i) {
+         const silo::query_engine::Query query(text);
+         if (query.filter == nullptr) {
+            return -1;
+         }
+      }
+      return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - start).count() / repetitions;
    } catch (const std::exception&) {
       return -1;
    }
