@@ -250,6 +250,14 @@ int silo_gpu_group_count(
    const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* const* group_ids_dev, const uint32_t* cardinalities,
    uint32_t n_columns, uint32_t* counts_dev, void* stream
 );
+/* The same group-by for tuple spaces beyond SILO_GPU_MAX_GROUP_BINS (up to 2^64 - 1 potential tuples): a hash table
+ * in HBM keyed by the 64-bit mixed-radix tuple id, then compacted.  max_rows bounds the number of selected rows (the
+ * filter's cardinality; the table gets twice as many slots).  On success *out_keys_dev / *out_counts_dev hold
+ * *out_n_groups (tuple id, count) pairs in no particular order; free both with silo_gpu_free.  Synchronises. */
+int silo_gpu_group_count_hashed(
+   const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* const* group_ids_dev, const uint32_t* cardinalities,
+   uint32_t n_columns, uint32_t max_rows, uint64_t** out_keys_dev, uint32_t** out_counts_dev, uint32_t* out_n_groups, void* stream
+);
 /* Insertion index on the device (insertion_index.cpp, insertions.cpp:186-221).  The occurrences of a column's
  * insertions in one sequence are n_pairs pairs (rows_dev[k], ids_dev[k]): row k carries the distinct insertion
  * ids_dev[k] (< n_ids).  silo_gpu_bitset_from_pairs: dst = rows of the pairs whose insertion is a member

@@ -169,6 +169,57 @@ __global__ __launch_bounds__(256) void k_group_count(
    }
 }
 
+// K6b: group-by for tuple spaces beyond SILO_GPU_MAX_GROUP_BINS: an open-addressing hash table in HBM keyed by the
+// 64-bit mixed-radix tuple id (linear probing, atomicCAS on the key, atomicAdd on the count), then a compaction of
+// the occupied slots.  The table has at least twice as many slots as rows, so probing terminates.
+struct GroupHashArgs {
+   const uint32_t* ids[SILO_GPU_MAX_GROUP_COLUMNS];
+   unsigned long long strides[SILO_GPU_MAX_GROUP_COLUMNS];
+   uint32_t n_columns;
+};
+
+constexpr unsigned long long GROUP_HASH_EMPTY = ~0ull;
+
+__global__ __launch_bounds__(256) void k_group_hash_insert(
+   const uint64_t* __restrict__ filter, uint32_t n_rows, const GroupHashArgs args, unsigned long long* __restrict__ table_keys,
+   uint32_t* __restrict__ table_counts, uint32_t capacity_mask
+) {
+   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+   if (row >= n_rows) {
+      return;
+   }
+   if (filter != nullptr && ((filter[row >> 6] >> (row & 63u)) & 1u) == 0) {
+      return;
+   }
+   unsigned long long key = 0;
+   for (uint32_t column = 0; column < args.n_columns; ++column) {
+      key += static_cast<unsigned long long>(args.ids[column][row]) * args.strides[column];
+   }
+   unsigned long long mixed = key * 0x9E3779B97F4A7C15ull;
+   mixed ^= mixed >> 29;
+   uint32_t slot = static_cast<uint32_t>(mixed) & capacity_mask;
+   while (true) {
+      const unsigned long long owner = atomicCAS(table_keys + slot, GROUP_HASH_EMPTY, key);
+      if (owner == GROUP_HASH_EMPTY || owner == key) {
+         atomicAdd(table_counts + slot, 1u);
+         return;
+      }
+      slot = (slot + 1) & capacity_mask;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_group_hash_compact(
+   const unsigned long long* __restrict__ table_keys, const uint32_t* __restrict__ table_counts, uint32_t capacity,
+   unsigned long long* __restrict__ out_keys, uint32_t* __restrict__ out_counts, uint32_t* __restrict__ n_out
+) {
+   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+   if (slot < capacity && table_keys[slot] != GROUP_HASH_EMPTY) {
+      const uint32_t index = atomicAdd(n_out, 1u);
+      out_keys[index] = table_keys[slot];
+      out_counts[index] = table_counts[slot];
+   }
+}
+
 // Insertion index (insertion_index.cpp): the occurrences of a column's insertions as pairs (row, distinct
 // insertion id).  K8 marks the rows of the pairs whose insertion matched the search pattern (the regex runs on the
 // host over the distinct insertions of one position, insertion_index.cpp:128-137); K9 counts, per distinct insertion,
@@ -286,6 +337,86 @@ int silo_gpu_group_count(
       k_group_count<false><<<grid, 256, 0, hip_stream>>>(filter_dev, n_rows, args, static_cast<uint32_t>(n_bins), 1, counts_dev);
    }
    SILO_HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_group_count_hashed(
+   const silo_gpu_store* store, const uint64_t* filter_dev, const uint32_t* const* group_ids_dev, const uint32_t* cardinalities,
+   uint32_t n_columns, uint32_t max_rows, uint64_t** out_keys_dev, uint32_t** out_counts_dev, uint32_t* out_n_groups, void* stream
+) {
+   if (store == nullptr || group_ids_dev == nullptr || cardinalities == nullptr || out_keys_dev == nullptr || out_counts_dev == nullptr ||
+       out_n_groups == nullptr || n_columns == 0 || n_columns > SILO_GPU_MAX_GROUP_COLUMNS) {
+      return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_group_count_hashed: bad arguments");
+   }
+   *out_keys_dev = nullptr;
+   *out_counts_dev = nullptr;
+   *out_n_groups = 0;
+   GroupHashArgs args{};
+   args.n_columns = n_columns;
+   unsigned long long stride = 1;
+   for (uint32_t column = n_columns; column-- > 0;) {  // mixed radix, first column most significant
+      if (group_ids_dev[column] == nullptr || cardinalities[column] == 0) {
+         return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_group_count_hashed: null column or empty dictionary");
+      }
+      args.ids[column] = group_ids_dev[column];
+      args.strides[column] = stride;
+      if (stride > (~0ull - 1) / cardinalities[column]) {
+         return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_group_count_hashed: the tuple space exceeds 64 bits");
+      }
+      stride *= cardinalities[column];
+   }
+   const uint32_t n_rows = silo_gpu_store_sequence_count(store);
+   const uint32_t rows_bound = std::min(max_rows, n_rows);
+   if (rows_bound == 0) {
+      return SILO_GPU_OK;
+   }
+   uint64_t capacity = 1024;
+   while (capacity < 2ull * rows_bound) {
+      capacity *= 2;
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   unsigned long long* table_keys = nullptr;
+   uint32_t* table_counts = nullptr;
+   unsigned long long* keys = nullptr;
+   uint32_t* counts = nullptr;
+   uint32_t* n_out = nullptr;
+   const auto release = [&](bool keep_outputs) {
+      (void)hipFree(table_keys);
+      (void)hipFree(table_counts);
+      (void)hipFree(n_out);
+      if (!keep_outputs) {
+         (void)hipFree(keys);
+         (void)hipFree(counts);
+      }
+   };
+   hipError_t err = hipMalloc(&table_keys, capacity * sizeof(unsigned long long));
+   if (err == hipSuccess) err = hipMalloc(&table_counts, capacity * sizeof(uint32_t));
+   if (err == hipSuccess) err = hipMalloc(&keys, static_cast<size_t>(rows_bound) * sizeof(unsigned long long));
+   if (err == hipSuccess) err = hipMalloc(&counts, static_cast<size_t>(rows_bound) * sizeof(uint32_t));
+   if (err == hipSuccess) err = hipMalloc(&n_out, sizeof(uint32_t));
+   if (err == hipSuccess) err = hipMemsetAsync(table_keys, 0xFF, capacity * sizeof(unsigned long long), hip_stream);
+   if (err == hipSuccess) err = hipMemsetAsync(table_counts, 0, capacity * sizeof(uint32_t), hip_stream);
+   if (err == hipSuccess) err = hipMemsetAsync(n_out, 0, sizeof(uint32_t), hip_stream);
+   if (err == hipSuccess) {
+      k_group_hash_insert<<<(n_rows + 255) / 256, 256, 0, hip_stream>>>(
+         filter_dev, n_rows, args, table_keys, table_counts, static_cast<uint32_t>(capacity - 1)
+      );
+      k_group_hash_compact<<<static_cast<uint32_t>((capacity + 255) / 256), 256, 0, hip_stream>>>(
+         table_keys, table_counts, static_cast<uint32_t>(capacity), keys, counts, n_out
+      );
+      err = hipGetLastError();
+   }
+   uint32_t n_groups = 0;
+   if (err == hipSuccess) err = hipMemcpyAsync(&n_groups, n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, hip_stream);
+   if (err == hipSuccess) err = hipStreamSynchronize(hip_stream);
+   if (err != hipSuccess) {
+      release(false);
+      SILO_HIP_TRY(err);
+   }
+   release(true);
+   *out_keys_dev = reinterpret_cast<uint64_t*>(keys);
+   *out_counts_dev = counts;
+   *out_n_groups = n_groups;
    return SILO_GPU_OK;
 }
 

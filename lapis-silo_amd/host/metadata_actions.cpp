@@ -117,19 +117,55 @@ QueryResult Aggregated::aggregateWithGrouping(const Database& database, std::vec
          launch.fetch = HostFetch(launch.device_counts.get(), launch.n_bins * sizeof(uint32_t), queryStream());
          continue;
       }
-      // more distinct tuples than the device histogram holds: tuple by tuple on the host, as the reference does
-      std::string key;
-      for (const uint32_t row : selectedRows(partition, filter)) {
-         key.clear();
-         for (const MetadataColumnPartition* column : columns) {
-            column->appendKeyOfRow(row, key);
+      // a tuple space beyond the dense histogram: hash table in HBM keyed by the 64-bit tuple id (K6b)
+      if (n_fields > SILO_GPU_MAX_GROUP_COLUMNS) {
+         throw QueryCompilationException("Compilation Error: more than " + std::to_string(SILO_GPU_MAX_GROUP_COLUMNS) + " groupByFields");
+      }
+      const uint32_t selected = filter.cardinality();
+      if (selected == 0) {
+         continue;
+      }
+      uint64_t* device_keys = nullptr;
+      uint32_t* device_group_counts = nullptr;
+      uint32_t n_groups = 0;
+      checkGpu(
+         silo_gpu_group_count_hashed(
+            partition.store, filter.bitset(), ids.data(), cardinalities.data(), static_cast<uint32_t>(n_fields), selected, &device_keys,
+            &device_group_counts, &n_groups, queryStream()
+         ),
+         "silo_gpu_group_count_hashed"
+      );
+      std::vector<uint64_t> tuple_ids(n_groups);
+      std::vector<uint32_t> tuple_counts(n_groups);
+      int status = 0;
+      if (n_groups != 0) {
+         status = silo_gpu_memcpy_d2h(tuple_ids.data(), device_keys, n_groups * sizeof(uint64_t), queryStream());
+         if (status == 0) {
+            status = silo_gpu_memcpy_d2h(tuple_counts.data(), device_group_counts, n_groups * sizeof(uint32_t), queryStream());
          }
-         Group& group = groups[key];
-         if (group.count++ == 0) {
-            for (const MetadataColumnPartition* column : columns) {
-               group.values.push_back(column->jsonOfRow(row));
+      }
+      silo_gpu_free(device_keys);
+      silo_gpu_free(device_group_counts);
+      checkGpu(status, "silo_gpu_memcpy_d2h");
+      std::vector<uint32_t> digits(n_fields);
+      std::string key;
+      for (uint32_t group = 0; group < n_groups; ++group) {
+         uint64_t rest = tuple_ids[group];  // first field most significant
+         for (size_t field = n_fields; field-- > 0;) {
+            digits[field] = static_cast<uint32_t>(rest % cardinalities[field]);
+            rest /= cardinalities[field];
+         }
+         key.clear();
+         for (size_t field = 0; field < n_fields; ++field) {
+            columns[field]->appendKeyOfGroup(digits[field], key);
+         }
+         Group& entry = groups[key];
+         if (entry.count == 0) {
+            for (size_t field = 0; field < n_fields; ++field) {
+               entry.values.push_back(columns[field]->jsonOfGroup(digits[field]));
             }
          }
+         entry.count += tuple_counts[group];
       }
    }
    Trace::mark("groups_launched");

@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
-    "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
+    "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
 ]
 
 _lib = None
@@ -140,6 +140,8 @@ def load_library():
     lib.silo_gpu_upload_column.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
     lib.silo_gpu_bitset_from_compare.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.silo_gpu_group_count.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_group_count_hashed.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_uint32,
+                                                ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), vp]
     lib.silo_gpu_reconstruct_sequences.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp]
     lib.silo_gpu_event_create.argtypes = [ctypes.POINTER(vp)]
     lib.silo_gpu_event_record.argtypes = [vp, vp]
@@ -464,6 +466,22 @@ class GpuStore:
         out = self.read(counts, np.uint32, n_bins, stream)
         self.free(counts)
         return out
+
+    def group_count_hashed(self, filter_ptr, id_ptrs, cardinalities, max_rows, stream=None):
+        """(tuple ids, counts) of the filtered rows through the HBM hash table (K6b), sorted by tuple id."""
+        ids = (ctypes.c_void_p * len(id_ptrs))(*[p.value for p in id_ptrs])
+        cards = (ctypes.c_uint32 * len(cardinalities))(*cardinalities)
+        keys, counts, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+        _check(self.lib.silo_gpu_group_count_hashed(self.handle, filter_ptr, ids, cards, len(id_ptrs), max_rows, ctypes.byref(keys),
+                                                    ctypes.byref(counts), ctypes.byref(n), stream))
+        if n.value == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+        tuple_ids = self.read(keys, np.uint64, n.value, stream)
+        tuple_counts = self.read(counts, np.uint32, n.value, stream)
+        self.free(keys)
+        self.free(counts)
+        order = np.argsort(tuple_ids)
+        return tuple_ids[order], tuple_counts[order]
 
     def reconstruct_sequences(self, seqstore_id, rows, stream=None):
         """The stored characters of the given rows: uint8 array [len(rows)][positions]."""

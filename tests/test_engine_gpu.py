@@ -374,6 +374,17 @@ def test_random_group_by_and_details_match_oracle(engines):
         assert engine.execute_query(query) == want, json.dumps(query)
 
 
+def test_group_by_with_a_huge_tuple_space_matches_oracle(engines):
+    """Five fields whose dictionary sizes multiply far past 2^24: the group-by goes through the HBM hash table (K6b)."""
+    engine, oracle_db = engines
+    fields = ["gisaid_epi_isl", "date", "age", "division", "qc_value", "pango_lineage"]
+    for expression in ({"type": "True"}, {"type": "IntBetween", "column": "age", "from": 40, "to": None},
+                       {"type": "StringEquals", "column": "country", "value": "nowhere"}):
+        query = {"action": {"type": "Aggregated", "groupByFields": fields, "orderByFields": ["gisaid_epi_isl"]}, "filterExpression": expression}
+        want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
+        assert engine.execute_query(query) == want
+
+
 def test_random_insertions_actions_match_oracle(engines):
     engine, oracle_db = engines
     rng = random.Random(808)

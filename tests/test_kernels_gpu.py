@@ -260,6 +260,33 @@ def test_group_count_matches_numpy(built, n):
                 store.free(pointer)
 
 
+@pytest.mark.parametrize("n", [5, 4097, 200003])
+def test_group_count_hashed_matches_numpy(built, n):
+    """K6b: tuple spaces far beyond the dense histogram (here up to 2^50 potential tuples)."""
+    rng = np.random.default_rng(n + 2)
+    ref = np.ones(4, dtype=np.uint8)
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        filt = rng.random(n) < 0.6
+        fptr = store.bitset_alloc()
+        store.bitset_upload(fptr, dense.pack_bits(filt))
+        for cardinalities in ([1 << 20, 1 << 20, 1 << 10], [n + 7, 3], [40000, 50000]):
+            columns = []
+            for cardinality in cardinalities:
+                ids = rng.integers(0, min(cardinality, 5000), size=n).astype(np.uint32) * (cardinality // min(cardinality, 5000))
+                ids[rng.random(n) < 0.3] = cardinality - 1
+                columns.append(ids.astype(np.uint32))
+            pointers = [store.upload_column(ids) for ids in columns]
+            key = np.zeros(n, dtype=np.uint64)
+            for ids, cardinality in zip(columns, cardinalities):
+                key = key * np.uint64(cardinality) + ids.astype(np.uint64)
+            for mask, pointer in ((filt, fptr), (np.ones(n, bool), None)):
+                want_ids, want_counts = np.unique(key[mask], return_counts=True)
+                got_ids, got_counts = store.group_count_hashed(pointer, pointers, cardinalities, int(mask.sum()))
+                assert np.array_equal(got_ids, want_ids) and np.array_equal(got_counts, want_counts.astype(np.uint32))
+            for pointer in pointers:
+                store.free(pointer)
+
+
 def test_reconstruct_sequences_matches_input(built):
     """FastaAligned gather: every stored character comes back, IUPAC codes (sparse planes) and null genomes included."""
     rng = np.random.default_rng(5)
