@@ -113,6 +113,12 @@ def main():
         chars = np.frombuffer(b"-ACGTRYSWKMBDHVN" if not is_aa else b"-ACDEFGHIKLMNPQRSTVWYBZ*X", dtype=np.uint8)[sym]
         engine.append_sequences(part, name, is_aa, 0, [bytes(row).decode("latin-1") for row in chars])
     engine.set_lineage_column_ids(part, "pango_lineage", tree.names, lineage[rows])
+    # metadata columns: every rank holds the values of its rows (all rows under position sharding)
+    metadata_rng = np.random.default_rng(3)
+    country = metadata_rng.integers(0, 7, size=N)
+    age = metadata_rng.integers(0, 90, size=N)
+    engine.append_metadata(part, "country", "indexed_string", [f"C{c}" for c in country[rows]])
+    engine.append_metadata(part, "age", "int", [str(a) if a % 11 else "" for a in age[rows]])
     engine.finalize()
     queries = [
         {"action": {"type": "Mutations", "minProportion": 0.02}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": True}},
@@ -129,7 +135,17 @@ def main():
         {"action": {"type": "Aggregated"}, "filterExpression": {"type": "Or", "children": [
             {"type": "NucleotideEquals", "position": 997, "symbol": "R"}, {"type": "NucleotideEquals", "position": 1, "symbol": "Y"},
             {"type": "HasAminoAcidMutation", "sequenceName": "S", "position": 100}]}},
+        # metadata predicates feed the same fused filter program on every rank
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "And", "children": [
+            {"type": "StringEquals", "column": "country", "value": "C3"}, {"type": "IntBetween", "column": "age", "from": 30, "to": None},
+            {"type": "Not", "child": {"type": "NucleotideEquals", "position": 700, "symbol": "-"}}]}},
+        {"action": {"type": "Mutations", "minProportion": 0.1}, "filterExpression": {"type": "IntEquals", "column": "age", "value": None}},
     ]
+    if by_position:  # row-wise actions need every row on the rank
+        queries.append({"action": {"type": "Aggregated", "groupByFields": ["country"], "orderByFields": ["country"]},
+                        "filterExpression": {"type": "NucleotideEquals", "position": 950, "symbol": "A"}})
+        queries.append({"action": {"type": "Details", "fields": ["age", "country"], "orderByFields": ["age", "country"], "limit": 7},
+                        "filterExpression": {"type": "NucleotideEquals", "position": 20, "symbol": "T"}})
     results = [engine.execute_raw(q) for q in queries]
     # the same queries as one batch: scans share plane passes, the count tables are reduced after the launches
     batched = engine.execute_batch(queries)
