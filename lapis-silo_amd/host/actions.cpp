@@ -8,26 +8,49 @@
 namespace silo::query_engine::actions {
 
 // ---- Action (action.cpp:37-117) ------------------------------------------------------------------
-void Action::applySort(QueryResult& result) const {
+void Action::applySort(QueryResult& result) const {  // action.cpp:37-66
    auto& result_vector = result.query_result;
-   auto cmp = [&](const QueryResultEntry& entry1, const QueryResultEntry& entry2) {
-      for (const OrderByField& field : order_by_fields) {
-         if (entry1.fields.at(field.name) == entry2.fields.at(field.name)) {
+   if (order_by_fields.empty()) {
+      return;
+   }
+   // The reference's comparator looks every field up in the row's std::map on every comparison; here the fields are
+   // looked up once per row and the sort runs over (row index, field pointers).  Same ordering, same (partial) sort.
+   using Field = std::optional<std::variant<std::string, int32_t, double>>;
+   const size_t n_fields = order_by_fields.size();
+   std::vector<const Field*> keys(result_vector.size() * n_fields);
+   for (size_t row = 0; row < result_vector.size(); ++row) {
+      for (size_t field = 0; field < n_fields; ++field) {
+         keys[row * n_fields + field] = &result_vector[row].fields.at(order_by_fields[field].name);
+      }
+   }
+   std::vector<uint32_t> order(result_vector.size());
+   for (size_t row = 0; row < order.size(); ++row) {
+      order[row] = static_cast<uint32_t>(row);
+   }
+   auto cmp = [&](uint32_t row1, uint32_t row2) {
+      for (size_t field = 0; field < n_fields; ++field) {
+         const Field& value1 = *keys[row1 * n_fields + field];
+         const Field& value2 = *keys[row2 * n_fields + field];
+         if (value1 == value2) {
             continue;
          }
-         return entry1.fields.at(field.name) < entry2.fields.at(field.name) ? field.ascending : !field.ascending;
+         return value1 < value2 ? order_by_fields[field].ascending : !order_by_fields[field].ascending;
       }
       return false;
    };
    const size_t end_of_sort =
       std::min(static_cast<size_t>(limit.value_or(result_vector.size()) + offset.value_or(0UL)), result_vector.size());
-   if (!order_by_fields.empty()) {
-      if (end_of_sort < result_vector.size()) {
-         std::partial_sort(result_vector.begin(), result_vector.begin() + static_cast<int64_t>(end_of_sort), result_vector.end(), cmp);
-      } else {
-         std::sort(result_vector.begin(), result_vector.end(), cmp);
-      }
+   if (end_of_sort < result_vector.size()) {
+      std::partial_sort(order.begin(), order.begin() + static_cast<int64_t>(end_of_sort), order.end(), cmp);
+   } else {
+      std::sort(order.begin(), order.end(), cmp);
    }
+   std::vector<QueryResultEntry> sorted;
+   sorted.reserve(result_vector.size());
+   for (const uint32_t row : order) {
+      sorted.push_back(std::move(result_vector[row]));
+   }
+   result_vector = std::move(sorted);
 }
 
 void Action::applyOffsetAndLimit(QueryResult& result) const {
