@@ -545,6 +545,20 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          const json::Value& metadata = record.at("metadata");
          for (size_t k = 0; k < metadata_writer.size(); ++k) {
             const std::string& column = metadata_writer.name(k);
+            if ((column == "nucleotideInsertions" || column == "aminoAcidInsertions") && record.contains(column) && record[column].is_object()) {
+               // metadata_info.cpp:61-94: the top-level maps {sequence: [entries]} become one column value
+               // "sequence:entry,sequence:entry,..." (list_string_agg of the flattened, prefixed lists)
+               std::string joined;
+               for (const auto& [sequence_name, entries] : record[column].members()) {
+                  for (const auto& entry : entries.items()) {
+                     if (entry.is_string()) {
+                        joined += (joined.empty() ? "" : ",") + sequence_name + ":" + entry.as_string();
+                     }
+                  }
+               }
+               metadata_writer.add(k, std::move(joined));
+               continue;
+            }
             if (!metadata.contains(column) || metadata[column].is_null()) {
                metadata_writer.add(k, "");
             } else if (metadata[column].is_string()) {

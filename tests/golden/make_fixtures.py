@@ -135,5 +135,35 @@ def main():
     print(f"kept {len(kept_next)} next-row query fixtures:", " ".join(kept_next))
 
 
+# The four scenarios of src/silo/preprocessing/preprocessor.test.cpp:31-88 (input directories of testBaseData plus the
+# expected sequence count, query and result, transcribed from the test as data).
+FASTA_ALIGNED_QUERY = {"action": {"type": "FastaAligned", "sequenceName": ["someShortGene", "secondSegment"], "orderByFields": ["accessionVersion"]},
+                       "filterExpression": {"type": "True"}}
+FASTA_ALIGNED_EXPECTED = [
+    {"accessionVersion": "1.1", "someShortGene": "MADS", "secondSegment": "NNNNNNNNNNNNNNNN"},
+    {"accessionVersion": "1.3", "someShortGene": "XXXX", "secondSegment": "NNNNNNNNNNNNNNNN"},
+]
+GROUP_QUERY = {"action": {"type": "Aggregated", "groupByFields": ["group"], "orderByFields": ["group"]}, "filterExpression": {"type": "True"}}
+GROUP_EXPECTED = [{"count": 1, "group": None}, {"count": 1, "group": "dummyValue"}]
+PREPROCESSING_SCENARIOS = {
+    "fastaFilesWithMissingSequences": (2, FASTA_ALIGNED_QUERY, FASTA_ALIGNED_EXPECTED),
+    "ndjsonWithNullSequences": (2, FASTA_ALIGNED_QUERY, FASTA_ALIGNED_EXPECTED),
+    "ndjsonWithSqlKeywordField": (2, GROUP_QUERY, GROUP_EXPECTED),
+    "tsvWithSqlKeywordField": (2, GROUP_QUERY, GROUP_EXPECTED),
+}
+
+
+def copy_preprocessing_scenarios():
+    for name, (count, query, expected) in PREPROCESSING_SCENARIOS.items():
+        src = os.path.join(REF, "testBaseData", name)
+        dst = os.path.join(HERE, "preprocessing", name)
+        os.makedirs(dst, exist_ok=True)
+        for file_name in sorted(os.listdir(src)):
+            shutil.copyfile(os.path.join(src, file_name), os.path.join(dst, file_name))
+        json.dump({"cite": "src/silo/preprocessing/preprocessor.test.cpp:31-88", "expectedSequenceCount": count, "query": query,
+                   "expectedQueryResult": expected}, open(os.path.join(dst, "expected.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    copy_preprocessing_scenarios()
     main()

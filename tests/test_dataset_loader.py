@@ -34,15 +34,27 @@ def write_ndjson_dataset(directory, compression):
     os.makedirs(directory, exist_ok=True)
     for name in ("reference_genomes.json", "pangolineage_alias.json", "database_config.yaml"):
         shutil.copyfile(os.path.join(EXAMPLE, name), os.path.join(directory, name))
+    def insertion_map(text, names, default):
+        """'25701:CCC,S:214:EPE' -> {sequence: ['position:insertion', ...]}: insertions travel as top-level maps in the
+        ndjson format (metadata_info.cpp:61-94), not as metadata fields."""
+        out = {name: [] for name in names}
+        for entry in (text.split(",") if text else []):
+            parts = entry.split(":")
+            if len(parts) == 2:
+                out[default].append(entry)
+            else:
+                out[parts[0]].append(":".join(parts[1:]))
+        return out
+
     lines = []
     for i, row in enumerate(data["rows"]):
         record = {
-            "metadata": {k: (v if v != "" else None) for k, v in row.items()},
+            "metadata": {k: (v if v != "" else None) for k, v in row.items() if k not in ("nucleotideInsertions", "aminoAcidInsertions")},
             "alignedNucleotideSequences": {name: seqs[i] for name, seqs in data["nuc"].items()},
             "alignedAminoAcidSequences": {name: seqs[i] for name, seqs in data["aa"].items()},
             "unalignedNucleotideSequences": {name: None for name in data["nuc"]},
-            "nucleotideInsertions": {name: [] for name in data["nuc"]},
-            "aminoAcidInsertions": {name: [] for name in data["aa"]},
+            "nucleotideInsertions": insertion_map(row["nucleotideInsertions"], data["nuc"], "main"),
+            "aminoAcidInsertions": insertion_map(row["aminoAcidInsertions"], data["aa"], None),
         }
         lines.append(json.dumps(record))
     text = ("\n".join(lines) + "\n").encode()
@@ -96,6 +108,22 @@ def test_ndjson_directory(built, tmp_path, compression):
     with Engine.from_directory(str(tmp_path)) as engine:
         assert engine.summary["sequenceCount"] == 100
         run_goldens(engine)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scenario", ["fastaFilesWithMissingSequences", "ndjsonWithNullSequences", "ndjsonWithSqlKeywordField", "tsvWithSqlKeywordField"])
+def test_reference_preprocessing_scenarios(built, scenario):
+    """src/silo/preprocessing/preprocessor.test.cpp:31-130: the reference's own input directories (missing segments and
+    genes, null sequences, a column named like an SQL keyword) with the sequence count and query result it expects."""
+    from silo_amd.engine import Engine
+
+    directory = os.path.join(dataset.GOLDEN, "preprocessing", scenario)
+    expected = json.load(open(os.path.join(directory, "expected.json")))
+    with Engine.from_directory(directory) as engine:
+        assert engine.summary["sequenceCount"] == expected["expectedSequenceCount"]
+        status, document = engine.execute_raw(expected["query"])
+        assert status == 200, document
+        assert document["queryResult"] == expected["expectedQueryResult"]
 
 
 @pytest.mark.gpu
