@@ -416,3 +416,28 @@ def test_fasta_aligned_matches_oracle(engines):
     want = json.loads(json.dumps(so.execute_query(oracle_db, query)))
     got = engine.execute_query(query)
     assert len(got) > 0 and got == want
+
+
+def test_insertion_search_unit_test_vectors(built):
+    """insertion_column.test.cpp:34-62 through InsertionContains on the device (K8), rows read back with Details."""
+    import os
+
+    from silo_amd.engine import Engine
+
+    vec = json.load(open(os.path.join(dataset.GOLDEN, "operators", "operator_vectors.json")))["insertion_search"]
+    genomes = {"nucleotideSequences": [{"name": "main", "sequence": "ACGT"}], "genes": []}
+    with Engine(genomes) as engine:
+        engine.set_schema("key")
+        n = len(vec["rows"])
+        part = engine.add_partition(n)
+        engine.append_sequences(part, "main", False, 0, [None] * n)
+        engine.append_metadata(part, "key", "string", [str(i) for i in range(n)])
+        engine.append_metadata(part, "insertions", "insertion", vec["rows"])
+        engine.finalize()
+        for search in vec["searches"]:
+            rows = engine.execute_query({"action": {"type": "Details", "fields": ["key"], "orderByFields": ["key"]},
+                                         "filterExpression": {"type": "InsertionContains", "column": "insertions",
+                                                              "position": search["position"], "value": search["pattern"]}})
+            assert [int(row["key"]) for row in rows] == search["expected"], search
+        assert engine.execute_query({"action": {"type": "Details", "fields": ["insertions"], "orderByFields": ["insertions"], "limit": 2},
+                                     "filterExpression": {"type": "True"}}) == [{"insertions": "25701:ACCA"}, {"insertions": "25701:ACCA"}]

@@ -176,3 +176,25 @@ def test_insertion_values_are_standardised_like_the_reference(host_logic):
     for default_sequence, value, expected in cases:
         n = host_logic.t_insertion_standardise(default_sequence, value.encode(), buffer, 512)
         assert (buffer.value.decode() if n >= 0 else None) == expected, (default_sequence, value)
+
+
+def test_reference_unit_test_vectors_on_the_host_functions(host_logic):
+    """date.test.cpp, pango_lineage_alias.test.cpp and insertion_column.test.cpp vectors against the C++ host code."""
+    import json
+
+    vectors = json.load(open(os.path.join(ROOT, "tests", "golden", "operators", "operator_vectors.json")))
+    buffer = ctypes.create_string_buffer(256)
+    for text, value in vectors["dates"]["parse"]:
+        assert host_logic.t_string_to_date(text.encode()) == value, text
+    for text, printed in vectors["dates"]["reprint"]:
+        n = host_logic.t_date_to_string(host_logic.t_string_to_date(text.encode()), buffer, 256)
+        assert (buffer.value.decode() if n >= 0 else None) == printed, text
+    alias = vectors["lineage_alias"]
+    for mode, block in ((0, alias["unalias"]), (1, alias["alias"])):
+        alias_json = json.dumps(block["alias_key"]).encode()
+        for text, expected in block["cases"]:
+            assert host_logic.t_lineage(alias_json, text.encode(), mode, buffer, 256) >= 0
+            assert buffer.value.decode() == expected, (mode, text)
+    for text, expected in alias["example_file"]:
+        assert host_logic.t_lineage(host_logic.alias_json, text.encode(), 0, buffer, 256) >= 0
+        assert buffer.value.decode() == expected, text

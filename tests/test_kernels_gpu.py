@@ -302,3 +302,21 @@ def test_reconstruct_sequences_matches_input(built):
             rows = np.concatenate([[0, n - 1], rng.choice(n, size=200, replace=False), np.nonzero(is_null)[0][:5]]).astype(np.uint32)
             got = store.reconstruct_sequences(0, rows)
             assert np.array_equal(got, expected[rows])
+
+
+def test_selection_unit_test_vectors_on_the_compare_kernel(built):
+    """selection.test.cpp:10-113 through K5, the negation as the negated comparator (selection.cpp:195-220)."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operators", "operator_vectors.json")
+    negated = {"==": "!=", "!=": "==", "<": ">=", ">=": "<", ">": "<=", "<=": ">"}
+    for vec in json.load(open(path))["selection"]:
+        column = np.array(vec["column"], dtype=np.int32)
+        with make_store(len(column), [dict(name="s", alphabet="nuc", reference=np.ones(4, dtype=np.uint8))]) as store:
+            pointer = store.upload_column(column)
+            got = dense.unpack_bits(store.bitset_from_compare(pointer, np.int32, vec["comparator"], vec["value"]), len(column))
+            assert np.nonzero(got)[0].tolist() == vec["expected"], vec["cite"]
+            got = dense.unpack_bits(store.bitset_from_compare(pointer, np.int32, negated[vec["comparator"]], vec["value"]), len(column))
+            assert np.nonzero(got)[0].tolist() == vec["negated"], vec["cite"]
+            store.free(pointer)

@@ -160,3 +160,52 @@ def test_position_vectors():
             for char, ids in vec["stored_after_flip"].items():
                 assert so.ids_from_bits(position.bitmaps[chars.index(char)]) == ids
             assert position.flip_most_numerous(vec["sequence_count"]) is None
+
+
+# ---- vectors of the reference's unit tests for the §8(f) row-3 pieces ------------------------------------------------
+@pytest.mark.parametrize("vec", VECTORS["range_selection"], ids=lambda v: v["cite"])
+def test_range_selection_vectors(vec):
+    op = so.RangeSelection([tuple(r) for r in vec["ranges"]], vec["row_count"])
+    assert so.ids_from_bits(op.evaluate()) == vec["expected"]
+    assert so.ids_from_bits(op.negate().evaluate()) == vec["negated"]
+    assert op.negate().type == so.RANGE_SELECTION
+
+
+@pytest.mark.parametrize("vec", VECTORS["selection"], ids=lambda v: v["cite"])
+def test_selection_vectors(vec):
+    op = so.Selection([so.Predicate(vec["column"], vec["comparator"], vec["value"])], len(vec["column"]))
+    assert op.type == so.SELECTION
+    assert so.ids_from_bits(op.evaluate()) == vec["expected"]
+    assert so.ids_from_bits(op.negate().evaluate()) == vec["negated"]
+
+
+def test_insertion_search_vectors():
+    vec = VECTORS["insertion_search"]
+    db = so.Database({"main": [1] * 4}, {}, default_nucleotide_sequence=vec["default_sequence"])
+    db.set_config([("insertions", "insertion")], "key")
+    partition = so.DatabasePartition(sequence_count=len(vec["rows"]))
+    db.partitions.append(partition)
+    db.add_metadata(partition, [{"insertions": value} for value in vec["rows"]])
+    for search in vec["searches"]:
+        expression = so.InsertionContains(so.Nucleotide, ["insertions"], None, search["position"], search["pattern"])
+        assert so.ids_from_bits(expression.compile(db, partition, so.NONE).evaluate()) == search["expected"], search
+
+
+def test_date_vectors():
+    for text, value in VECTORS["dates"]["parse"]:
+        assert so.string_to_date(text) == value, text
+    for text, printed in VECTORS["dates"]["reprint"]:
+        assert so.date_to_string(so.string_to_date(text)) == printed, text
+
+
+def test_lineage_alias_vectors(example_data):
+    vectors = VECTORS["lineage_alias"]
+    lookup = so.PangoLineageAliasLookup(vectors["unalias"]["alias_key"])
+    for text, expected in vectors["unalias"]["cases"]:
+        assert lookup.unalias(text) == expected, text
+    lookup = so.PangoLineageAliasLookup(vectors["alias"]["alias_key"])
+    for text, expected in vectors["alias"]["cases"]:
+        assert lookup.alias(text) == expected, text
+    lookup = so.PangoLineageAliasLookup(example_data["alias"])
+    for text, expected in vectors["example_file"]:
+        assert lookup.unalias(text) == expected, text
