@@ -135,15 +135,6 @@ void ProgramBuilder::freeSlot(uint32_t slot) {
    }
 }
 
-uint32_t ProgramBuilder::writable(uint32_t operand) {
-   if (!isLeafOperand(operand)) {
-      return operand;
-   }
-   const uint32_t slot = allocSlot();
-   emit(SILO_GPU_OP_MOV, slot, operand);
-   return slot;
-}
-
 void ProgramBuilder::emit(uint32_t op, uint32_t dst, uint32_t a, uint32_t b, uint32_t imm) {
    code.push_back(op | (dst << 8) | (a << 16) | (b << 24));
    code.push_back(imm);

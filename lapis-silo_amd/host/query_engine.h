@@ -99,8 +99,6 @@ class ProgramBuilder {
    uint32_t allocRun(uint32_t count);
    void freeSlot(uint32_t slot);
    void freeRun(uint32_t slot, uint32_t count);
-   /// Returns `operand` if it is a slot, else a fresh slot holding a copy of the leaf operand.
-   uint32_t writable(uint32_t operand);
    void emit(uint32_t op, uint32_t dst, uint32_t a = 0, uint32_t b = 0, uint32_t imm = 0);
    uint32_t leaf(const uint64_t* device_bitset);
    /// Leaf for a symbol that is stored sparsely: scattered into a cached / pooled bitset before launch.
