@@ -245,12 +245,12 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
 
 
 def batch_workload(engine, positions, n_sequences, sync, reps=5):
-    """4 concurrent Mutations queries with different lineage filters: one by one vs. one silo_engine_execute_batch
+    """8 concurrent Mutations queries with different lineage filters: one by one vs. one silo_engine_execute_batch
     call in which their scans share a single pass over the planes (K1c)."""
     queries = [json.dumps({
         "action": {"type": "Mutations", "minProportion": 0.05},
         "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": lineage, "includeSublineages": True},
-    }).encode() for lineage in ("B.1", "B.2", "B.3", "B.1.1")]
+    }).encode() for lineage in ("B.1", "B.2", "B.3", "B.1.1", "B.1.2", "B.1.3", "B.2.1", "B.2.2")]
     one_by_one = [engine.execute_text(q) for q in queries]
     batched = engine.execute_batch_text(queries)
     if batched != one_by_one:
@@ -268,10 +268,11 @@ def batch_workload(engine, positions, n_sequences, sync, reps=5):
     sync()
     together = (time.perf_counter() - t0) / reps
     return {
-        "workload": f"4 Mutations queries (PangoLineage B.1*, B.2*, B.3*, B.1.1*), {n_sequences} sequences; responses identical both ways",
+        "workload": f"{len(queries)} Mutations queries (PangoLineage B.1*, B.2*, B.3*, B.1.1*, B.1.2*, B.1.3*, B.2.1*, B.2.2*), {n_sequences} sequences; "
+                    "responses identical both ways",
         "ms_one_by_one": sequential * 1e3,
         "ms_one_batch": together * 1e3,
-        "value_one_batch": 4 * n_sequences * positions / together,
+        "value_one_batch": len(queries) * n_sequences * positions / together,
         "unit": "positions*sequences/s",
     }
 

@@ -312,7 +312,7 @@ int silo_gpu_mutations_scan(
 /* The same scan for a batch of filters over one sequence store: every plane row is read once for up to
  * SILO_GPU_MAX_SCAN_BATCH filters per pass (larger batches take several passes), counts_out_dev[q] is
  * accumulated with filters_dev[q].  This is how concurrent Mutations queries share the HBM stream. */
-enum { SILO_GPU_MAX_SCAN_BATCH = 4 };
+enum { SILO_GPU_MAX_SCAN_BATCH = 8 };
 int silo_gpu_mutations_scan_batch(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* const* filters_dev, uint32_t n_filters,
    uint32_t pos_begin, uint32_t pos_end, uint32_t* const* counts_out_dev, void* stream

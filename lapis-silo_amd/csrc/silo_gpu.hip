@@ -340,12 +340,19 @@ struct ScanBatchArgs {
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
 };
 
+// Words per thread: 8 up to four filters (Q * 16 filter registers), 4 beyond (5..8 filters: Q * 8 registers), so
+// that the filter tiles never push the kernel below 4 waves per SIMD.
+template <int Q>
+constexpr int batchWordsPerThread() {
+   return Q <= 4 ? 8 : 4;
+}
+
 template <int Q>
 __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tiled_batch(
    const uint64_t* __restrict__ planes, const ScanBatchArgs batch, uint32_t row_words, uint32_t n_rows, uint32_t rows_per_block,
    uint32_t n_tiles
 ) {
-   constexpr int WPT = 8;
+   constexpr int WPT = batchWordsPerThread<Q>();
    constexpr int CHUNKS = WPT / 2;
    constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
    __shared__ uint32_t s_partial[2][SCAN_WAVES][SCAN_ROWS_BATCH][Q];
@@ -1443,8 +1450,6 @@ int silo_gpu_mutations_scan_batch(
    const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
    const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
    const uint32_t rows_per_block = 64;
-   const uint32_t n_tiles = (row_words + TILE_WORDS - 1) / TILE_WORDS;
-   const dim3 grid(n_tiles * ((n_rows + rows_per_block - 1) / rows_per_block));
    for (uint32_t first = 0; first < n_filters; first += SILO_GPU_MAX_SCAN_BATCH) {
       const uint32_t q_count = std::min<uint32_t>(SILO_GPU_MAX_SCAN_BATCH, n_filters - first);
       ScanBatchArgs batch{};
@@ -1452,24 +1457,28 @@ int silo_gpu_mutations_scan_batch(
          batch.filters[q] = filters_dev[first + q];
          batch.counts[q] = counts_out_dev[first + q];
       }
-      switch (q_count) {
-         case 1: {  // the odd one out of a batch: the single-filter kernel
-            const int rc = silo_gpu_mutations_scan(store, seqstore_id, batch.filters[0], pos_begin, pos_end, batch.counts[0], stream);
-            if (rc != SILO_GPU_OK) {
-               return rc;
-            }
-            break;
+      if (q_count == 1) {  // the odd one out of a batch: the single-filter kernel
+         const int rc = silo_gpu_mutations_scan(store, seqstore_id, batch.filters[0], pos_begin, pos_end, batch.counts[0], stream);
+         if (rc != SILO_GPU_OK) {
+            return rc;
          }
-         case 2:
-            k_scan_tiled_batch<2><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
-            break;
-         case 3:
-            k_scan_tiled_batch<3><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
-            break;
-         default:
-            k_scan_tiled_batch<4><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles);
-            break;
+         continue;
       }
+      const uint32_t tile_words = SCAN_THREADS * (q_count <= 4 ? 8 : 4);
+      const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
+      const dim3 grid(n_tiles * ((n_rows + rows_per_block - 1) / rows_per_block));
+#define SILO_LAUNCH_BATCH(Q) \
+   case Q: k_scan_tiled_batch<Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles); break;
+      switch (q_count) {
+         SILO_LAUNCH_BATCH(2)
+         SILO_LAUNCH_BATCH(3)
+         SILO_LAUNCH_BATCH(4)
+         SILO_LAUNCH_BATCH(5)
+         SILO_LAUNCH_BATCH(6)
+         SILO_LAUNCH_BATCH(7)
+         default: k_scan_tiled_batch<8><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles); break;
+      }
+#undef SILO_LAUNCH_BATCH
       HIP_TRY(hipGetLastError());
    }
    g_last_scan_kernel = "k_scan_tiled_batch";

@@ -203,7 +203,7 @@ def test_batched_scan_matches_single_scans(built, n, alphabet):
             ptr = store.bitset_alloc()
             store.bitset_upload(ptr, dense.pack_bits(mask))
             ptrs.append(ptr)
-        for count in (1, 2, 3, 4, 5, 9):
+        for count in (1, 2, 3, 4, 5, 6, 7, 8, 9):
             tables = store.mutations_scan_batch(0, ptrs[:count], 2, 17)
             for mask, table in zip(masks, tables):
                 assert np.array_equal(table, dense.mutation_counts(sym, mask, scan_symbols, 2, 17)), count

@@ -31,7 +31,7 @@ lib = store.lib
 counts = [store.malloc(4 * positions * 5) for _ in filters]
 w8 = 8 * ((n + 63) // 64)
 start, stop = binding.GpuEvent(), binding.GpuEvent()
-for q in (1, 2, 3, 4, 8):
+for q in (1, 2, 4, 5, 6, 8):
     fa = (ctypes.c_void_p * q)(*[f.value for f in filters[:q]])
     ca = (ctypes.c_void_p * q)(*[c.value for c in counts[:q]])
     best = 1e9
@@ -42,5 +42,5 @@ for q in (1, 2, 3, 4, 8):
         ms = start.elapsed_ms(stop)
         if rep:
             best = min(best, ms)
-    print(f"Q={q}: {best:8.3f} ms per batch = {best / q:7.3f} ms per query; planes stream at {positions * 5 * w8 * -(-q // 4) / best / 1e6:7.1f} GB/s; "
+    print(f"Q={q}: {best:8.3f} ms per batch = {best / q:7.3f} ms per query; planes stream at {positions * 5 * w8 * -(-q // 8) / best / 1e6:7.1f} GB/s; "
           f"{q * n * positions / best / 1e9 * 1e3:.3e} pos*seq/s aggregate  [{store.last_scan_kernel()}]", flush=True)
