@@ -1,0 +1,34 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the host-side parsing code (CPU build only: the GPU pool has no
+sanitizer support).  Compiles the host sources with the sanitizers into a small driver and feeds it all golden queries and
+thousands of truncated / corrupted variants."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "lapis-silo_amd", "host")
+LIB = os.path.join(ROOT, "lapis-silo_amd", "lib")
+
+
+def test_query_parsing_is_clean_under_asan_and_ubsan(built, tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    sources = [os.path.join(HOST, name) for name in ("actions.cpp", "database.cpp", "filter_expressions.cpp", "operators.cpp", "query_engine.cpp",
+                                                      "metadata_columns.cpp", "metadata_actions.cpp")]
+    driver = str(tmp_path / "sanitizer_driver")
+    build = subprocess.run(
+        ["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+         "-I", os.path.join(ROOT, "include"), "-I", HOST, os.path.join(ROOT, "tests", "host_tools", "sanitizer_driver.cpp"), *sources,
+         "-o", driver, "-L", LIB, "-lsilo_gpu", "-Wl,-rpath," + LIB, "-pthread"],
+        capture_output=True, text=True, timeout=900)
+    if build.returncode != 0 and ("cannot find -lasan" in build.stderr or "libasan" in build.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-3000:]
+    golden = os.path.join(ROOT, "tests", "golden")
+    run = subprocess.run([driver] + [os.path.join(golden, name) for name in ("queries", "queries_next", "invalidQueries", "invalidQueries_next")],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    assert run.stdout.strip().startswith("parsed 95 rejected 9"), run.stdout
