@@ -72,6 +72,12 @@ int silo_engine_set_schema(silo_engine* engine, const char* primary_key, const c
 int silo_engine_append_metadata(
    silo_engine* engine, int partition, const char* column, const char* column_type, const char* const* values, uint32_t n_values
 );
+/* Unaligned nucleotide sequences for the Fasta action (fasta.cpp; the reference keeps them in zstd files next to the
+ * database, unaligned_sequence_store.h): n_sequences strings (NULL = none) appended to a nucleotide sequence of a
+ * partition.  Optional — rows without one answer null.  They stay in host memory. */
+int silo_engine_append_unaligned_sequences(
+   silo_engine* engine, int partition, const char* sequence_name, const char* const* sequences, uint32_t n_sequences
+);
 int silo_engine_finalize(silo_engine* engine);
 
 /* Multi-GPU (one process per GPU).  Call before silo_engine_add_partition.  shard_by_position != 0:

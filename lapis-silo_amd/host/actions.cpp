@@ -636,9 +636,26 @@ std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:14
       action = parseInsertions<Nucleotide>(json);
    } else if (expression_type == "AminoAcidInsertions") {
       action = parseInsertions<AminoAcid>(json);
-   } else if (expression_type == "Fasta") {
-      // unaligned sequences are not held by this engine (the reference reads them back from zstd files through DuckDB)
-      throw std::runtime_error("action '" + expression_type + "' is not supported by the MI355X filter engine");
+   } else if (expression_type == "Fasta") {  // fasta.cpp:247-270
+      CHECK_SILO_QUERY(
+         json.contains("sequenceName") && (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
+         "Fasta action must have the field sequenceName of type string or an array of strings"
+      )
+      std::vector<std::string> sequence_names;
+      if (json["sequenceName"].is_array()) {
+         for (const auto& child : json["sequenceName"].items()) {
+            CHECK_SILO_QUERY(
+               child.is_string(),
+               "Fasta action must have the field sequenceName of type string or an array of strings; while parsing array encountered the "
+               "element " +
+                  child.dump() + " which is not of type string"
+            )
+            sequence_names.emplace_back(child.as_string());
+         }
+      } else {
+         sequence_names.emplace_back(json["sequenceName"].as_string());
+      }
+      action = std::make_unique<Fasta>(std::move(sequence_names));
    } else {
       throw QueryParseException(expression_type + " is not a valid action");
    }

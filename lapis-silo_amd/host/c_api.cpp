@@ -251,6 +251,28 @@ int silo_engine_append_metadata(
    });
 }
 
+int silo_engine_append_unaligned_sequences(
+   silo_engine* engine, int partition, const char* sequence_name, const char* const* sequences, uint32_t n_sequences
+) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr || sequence_name == nullptr || (sequences == nullptr && n_sequences > 0)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_append_unaligned_sequences: bad arguments");
+   }
+   return guarded([&] {
+      std::vector<std::optional<std::string>> values;
+      values.reserve(n_sequences);
+      for (uint32_t row = 0; row < n_sequences; ++row) {
+         if (sequences[row] == nullptr) {
+            values.emplace_back(std::nullopt);
+         } else {
+            values.emplace_back(std::string(sequences[row]));
+         }
+      }
+      engine->database.appendUnalignedSequences(*part, sequence_name, std::move(values));
+      return 0;
+   });
+}
+
 int silo_engine_finalize(silo_engine* engine) {
    if (engine == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_finalize: null engine");

@@ -607,6 +607,21 @@ void Database::appendMetadata(
    }
 }
 
+void Database::appendUnalignedSequences(
+   DatabasePartition& partition, const std::string& sequence_name, std::vector<std::optional<std::string>> values
+) {
+   if (nuc_sequences.count(sequence_name) == 0) {
+      throw std::runtime_error("no nucleotide sequence named '" + sequence_name + "'");
+   }
+   auto& target = partition.unaligned_nuc_sequences[sequence_name];
+   if (target.size() + values.size() > partition.sequence_count) {
+      throw std::runtime_error("more unaligned sequences of '" + sequence_name + "' than the partition has rows");
+   }
+   for (auto& value : values) {
+      target.push_back(std::move(value));
+   }
+}
+
 void Database::finalize() {
    const bool device_in_use = !partitions.empty();
    nuc_mutation_layout = makeMutationTableLayout(nuc_sequences, device_in_use);

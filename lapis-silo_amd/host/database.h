@@ -231,6 +231,10 @@ class DatabasePartition {
    silo_gpu_store* store = nullptr;
    std::map<std::string, SequenceStorePartition<Nucleotide>> nuc_sequences;
    std::map<std::string, SequenceStorePartition<AminoAcid>> aa_sequences;
+   /// Unaligned nucleotide sequences by sequence name (unaligned_sequence_store.h), one optional string per row.  The
+   /// reference keeps them zstd-compressed on disk and reads them back through DuckDB (fasta.cpp:60-211); they never
+   /// touch the device, so here they simply stay on the host for the Fasta action.
+   std::map<std::string, std::vector<std::optional<std::string>>> unaligned_nuc_sequences;
    struct ColumnPartitionGroup {
       std::map<std::string, storage::column::PangoLineageColumnPartition> pango_lineage_columns;
       /// Every metadata column of database_config.metadata by name (column_group.h keeps one map per type; the
@@ -331,6 +335,8 @@ class Database {
    /// entry in database_config.metadata on first use.  A lineage column also feeds the PangoLineage filter index.
    /// Replaces the column inserts of Preprocessor::buildDatabase (preprocessor.cpp:447-503, column_group.cpp).
    void appendMetadata(DatabasePartition& partition, const std::string& name, config::ColumnType type, const std::vector<std::string>& values);
+   /// Appends unaligned nucleotide sequences (nullopt = none) of `sequence_name` to `partition`.
+   void appendUnalignedSequences(DatabasePartition& partition, const std::string& sequence_name, std::vector<std::optional<std::string>> values);
    void finalize();
 };
 

@@ -581,6 +581,16 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          };
          feed(nuc_writers, "alignedNucleotideSequences");
          feed(aa_writers, "alignedAminoAcidSequences");
+         if (record.contains("unalignedNucleotideSequences") && record["unalignedNucleotideSequences"].is_object()) {
+            const json::Value& unaligned = record["unalignedNucleotideSequences"];
+            for (const auto& [name, store] : partition.nuc_sequences) {
+               std::vector<std::optional<std::string>> value(1);
+               if (unaligned.contains(name) && unaligned[name].is_string()) {
+                  value[0] = unaligned[name].as_string();
+               }
+               database.appendUnalignedSequences(partition, name, std::move(value));
+            }
+         }
       }
    } else {  // preprocessor.cpp:255-334: metadata TSV, sequences joined by primary key from FASTA files
       std::vector<std::string> keys;
@@ -632,6 +642,21 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
       };
       feed(nuc_writers, setting("nucleotideSequencePrefix", "nuc_"));
       feed(aa_writers, setting("genePrefix", "gene_"));
+      // unaligned nucleotide sequences, where a file is present (preprocessor.cpp:355-401)
+      for (const auto& [name, store] : partition.nuc_sequences) {
+         const auto path = findWithCompression(root / (setting("unalignedNucleotideSequencePrefix", "unaligned_") + name + ".fasta"));
+         if (!path.has_value()) {
+            continue;
+         }
+         const auto records = readFasta(*path);
+         std::vector<std::optional<std::string>> values;
+         values.reserve(keys.size());
+         for (const std::string& key : keys) {
+            const auto found = records.find(key);
+            values.emplace_back(found == records.end() ? std::nullopt : std::optional<std::string>(found->second));
+         }
+         database.appendUnalignedSequences(partition, name, std::move(values));
+      }
    }
    for (auto& [name, writer] : nuc_writers) {
       writer.flush();

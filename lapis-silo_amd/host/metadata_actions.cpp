@@ -324,6 +324,64 @@ QueryResult Details::executeAndOrder(const Database& database, std::vector<Opera
    return results_in_format;
 }
 
+// ---- Fasta (fasta.cpp) ---------------------------------------------------------------------------------------
+void Fasta::validateOrderByFields(const Database& database) const {  // :42-57
+   const std::string& primary_key_field = database.database_config.primary_key;
+   for (const OrderByField& field : order_by_fields) {
+      std::string joined;
+      for (size_t i = 0; i < sequence_names.size(); ++i) {
+         joined += (i == 0 ? "" : ",") + sequence_names[i];
+      }
+      CHECK_SILO_QUERY(
+         field.name == primary_key_field || std::find(sequence_names.begin(), sequence_names.end(), field.name) != sequence_names.end(),
+         "The only fields returned by the Fasta action are " + joined + " and " + primary_key_field
+      )
+   }
+}
+
+QueryResult Fasta::execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // :214-245
+   for (const std::string& sequence_name : sequence_names) {
+      // every nucleotide sequence has an unaligned store (database.cpp:664-673)
+      CHECK_SILO_QUERY(
+         database.nuc_sequences.count(sequence_name) != 0, "Database does not contain an unaligned sequence with name: '" + sequence_name + "'"
+      )
+   }
+   const std::string& primary_key_column = database.database_config.primary_key;
+   size_t total_count = 0;
+   for (const auto& filter : bitmap_filter) {
+      total_count += filter.cardinality();
+   }
+   CHECK_SILO_QUERY(total_count <= SEQUENCE_LIMIT, "Fasta action currently limited to " + std::to_string(SEQUENCE_LIMIT) + " sequences")
+   requireAllRowsLocal(database, "Fasta");
+   QueryResult results;
+   results.query_result.reserve(total_count);
+   for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
+      const DatabasePartition& partition = database.partitions[partition_id];
+      const std::vector<uint32_t> rows = selectedRows(partition, bitmap_filter[partition_id]);
+      if (rows.empty()) {
+         continue;
+      }
+      const MetadataColumnPartition& primary_key = columnOf(partition, primary_key_column);
+      for (const uint32_t row : rows) {
+         QueryResultEntry& entry = results.query_result.emplace_back();
+         JsonValue key = primary_key.jsonOfRow(row);
+         if (!key.has_value()) {
+            throw std::runtime_error("Detected primary_key in column '" + primary_key_column + "' that is null.");
+         }
+         entry.fields.emplace(primary_key_column, std::move(key));
+         for (const std::string& sequence_name : sequence_names) {
+            const auto found = partition.unaligned_nuc_sequences.find(sequence_name);
+            if (found != partition.unaligned_nuc_sequences.end() && row < found->second.size() && found->second[row].has_value()) {
+               entry.fields.emplace(sequence_name, *found->second[row]);
+            } else {
+               entry.fields.emplace(sequence_name, std::nullopt);
+            }
+         }
+      }
+   }
+   return results;
+}
+
 // ---- Insertions / AminoAcidInsertions (insertions.cpp) ---------------------------------------------------
 template <typename SymbolType>
 void InsertionAggregation<SymbolType>::validateOrderByFields(const Database& /*database*/) const {  // :41-59

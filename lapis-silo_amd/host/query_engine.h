@@ -623,6 +623,17 @@ class Details : public Action {
    [[nodiscard]] QueryResult finish(const Database& database, Pending& pending) const override;
 };
 
+/// fasta.cpp: primary key + the unaligned nucleotide sequences of the selected rows (host data only).
+class Fasta : public Action {
+   std::vector<std::string> sequence_names;
+   void validateOrderByFields(const Database& database) const override;
+   [[nodiscard]] QueryResult execute(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
+
+  public:
+   static constexpr size_t SEQUENCE_LIMIT = 10'000;
+   explicit Fasta(std::vector<std::string>&& sequence_names) : sequence_names(std::move(sequence_names)) {}
+};
+
 /// insertions.cpp: the distinct insertions of the selected rows with their counts (k_count_pairs per insertion index).
 template <typename SymbolType>
 class InsertionAggregation : public Action {

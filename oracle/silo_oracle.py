@@ -394,6 +394,7 @@ class DatabasePartition:  # database_partition.h:39-112
     int_columns: Dict[str, List[int]] = field(default_factory=dict)
     float_columns: Dict[str, List[float]] = field(default_factory=dict)
     date_columns: Dict[str, List[int]] = field(default_factory=dict)
+    unaligned_nuc_sequences: Dict[str, List[Optional[str]]] = field(default_factory=dict)  # unaligned_sequence_store.h
     insertion_columns: Dict[str, List[str]] = field(default_factory=dict)  # standardised text per row (lookupValue)
     # insertion_column.cpp / insertion_index.cpp: column -> sequence name -> position -> insertion -> set of rows
     nuc_insertion_indexes: Dict[str, Dict[str, Dict[int, Dict[str, set]]]] = field(default_factory=dict)
@@ -1854,6 +1855,39 @@ class Mutations(Action):
         return output
 
 
+class Fasta(Action):  # fasta.cpp: primary key + unaligned nucleotide sequences of the selected rows
+    SEQUENCE_LIMIT = 10000
+
+    def __init__(self, sequence_names):
+        super().__init__()
+        self.sequence_names = sequence_names
+
+    def validate_order_by_fields(self, database):  # :42-57
+        for f in self.order_by_fields:
+            check_silo_query(
+                f.name == database.primary_key or f.name in self.sequence_names,
+                "The only fields returned by the Fasta action are " + ",".join(self.sequence_names) + " and " + database.primary_key,
+            )
+
+    def execute(self, database, filters):  # :214-245; every nucleotide sequence has an unaligned store (database.cpp:664-673)
+        for name in self.sequence_names:
+            check_silo_query(name in database.nuc_references, "Database does not contain an unaligned sequence with name: '" + name + "'")
+        total = sum(card(bitmap) for bitmap in filters)
+        check_silo_query(total <= self.SEQUENCE_LIMIT, "Fasta action currently limited to " + str(self.SEQUENCE_LIMIT) + " sequences")
+        out = []
+        for partition, bitmap in zip(database.partitions, filters):
+            for row in ids_from_bits(bitmap):
+                entry = {database.primary_key: json_tuple_value(
+                    database, database.primary_key, raw_tuple_value(database, partition, database.primary_key, row))}
+                if entry[database.primary_key] is None:
+                    raise RuntimeError("Detected primary_key in column '" + database.primary_key + "' that is null.")
+                for name in self.sequence_names:
+                    sequences = partition.unaligned_nuc_sequences.get(name)
+                    entry[name] = sequences[row] if sequences is not None else None
+                out.append(entry)
+        return out
+
+
 class InsertionAggregation(Action):  # insertions.cpp
     def __init__(self, alphabet, column_names, sequence_names):
         super().__init__()
@@ -2015,8 +2049,23 @@ def parse_action(node):  # action.cpp:144-187
         action = parse_insertions(node, Nucleotide)
     elif kind == "AminoAcidInsertions":
         action = parse_insertions(node, AminoAcid)
-    elif kind == "Fasta":
-        raise NotImplementedError(kind + " is outside the oracle's path")
+    elif kind == "Fasta":  # fasta.cpp:247-270
+        check_silo_query(
+            isinstance(node.get("sequenceName"), (str, list)),
+            "Fasta action must have the field sequenceName of type string or an array of strings",
+        )
+        names = []
+        if isinstance(node["sequenceName"], list):
+            for child in node["sequenceName"]:
+                check_silo_query(
+                    isinstance(child, str),
+                    "Fasta action must have the field sequenceName of type string or an array of strings; while parsing array "
+                    "encountered the element " + json.dumps(child, separators=(",", ":")) + " which is not of type string",
+                )
+                names.append(child)
+        else:
+            names.append(node["sequenceName"])
+        action = Fasta(names)
     else:
         raise QueryParseException(kind + " is not a valid action")
     order_by = [parse_order_by_field(f) for f in node.get("orderByFields", [])]

@@ -26,7 +26,7 @@ HOT_ACTIONS = {"Aggregated", "Mutations", "AminoAcidMutations"}
 # FastaAligned.  Their fixtures go to queries_next/ and invalidQueries_next/.
 NEXT_FILTERS = HOT_FILTERS | {"StringEquals", "IntEquals", "IntBetween", "FloatEquals", "FloatBetween", "DateBetween",
                               "InsertionContains", "AminoAcidInsertionContains"}
-NEXT_ACTIONS = HOT_ACTIONS | {"Details", "FastaAligned", "Insertions", "AminoAcidInsertions"}
+NEXT_ACTIONS = HOT_ACTIONS | {"Details", "FastaAligned", "Fasta", "Insertions", "AminoAcidInsertions"}
 NEXT_INVALID = {"GroupByLineageInvalidOrderBy.json", "OffsetNegative.json", "insertionContains_empty.json",
                 "insertionContains_invalidPattern.json", "insertionContains_invalidPattern2.json", "insertionsAAseparation.json",
                 "insertionsInvalidColumn.json", "insertionsInvalidSequence.json"}
@@ -73,8 +73,6 @@ def main():
         shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
     for name in sorted(os.listdir(src)):
         path = os.path.join(src, name)
-        if name.startswith("unaligned"):
-            continue
         if name.endswith(".fasta"):
             raw = open(path, "rb").read()
             base = name

@@ -52,7 +52,7 @@ def write_ndjson_dataset(directory, compression):
             "metadata": {k: (v if v != "" else None) for k, v in row.items() if k not in ("nucleotideInsertions", "aminoAcidInsertions")},
             "alignedNucleotideSequences": {name: seqs[i] for name, seqs in data["nuc"].items()},
             "alignedAminoAcidSequences": {name: seqs[i] for name, seqs in data["aa"].items()},
-            "unalignedNucleotideSequences": {name: None for name in data["nuc"]},
+            "unalignedNucleotideSequences": {name: data["unaligned"].get(name, [None] * len(data["rows"]))[i] for name in data["nuc"]},
             "nucleotideInsertions": insertion_map(row["nucleotideInsertions"], data["nuc"], "main"),
             "aminoAcidInsertions": insertion_map(row["aminoAcidInsertions"], data["aa"], None),
         }

@@ -30,6 +30,8 @@ def build_engine(data, partition_sizes=None):
             engine.append_sequences(part, name, False, 0, genomes_list[lo:hi])
         for name, genomes_list in data["aa"].items():
             engine.append_sequences(part, name, True, 0, genomes_list[lo:hi])
+        for name, sequences in data["unaligned"].items():
+            engine.append_unaligned_sequences(part, name, sequences[lo:hi])
         for column, kind in config["metadata"]:  # the lineage column also feeds the PangoLineage filter
             engine.append_metadata(part, column, column_types.get(kind, kind), [row.get(column) or "" for row in data["rows"][lo:hi]])
     engine.finalize()

@@ -29,6 +29,8 @@ def build_oracle_db(data, partition_sizes=None):
             data["lineages"][lo:hi],
         )
         db.add_metadata(partition, data["rows"][lo:hi])
+        for name, sequences in data["unaligned"].items():
+            partition.unaligned_nuc_sequences[name] = sequences[lo:hi]
     return db
 
 
