@@ -9,11 +9,13 @@
 //
 // Files understood, all relative to the data set directory:
 //   preprocessing_config.yaml   optional; metadataFilename | ndjsonInputFilename, pangoLineageDefinitionFilename,
-//                               referenceGenomeFilename, nucleotideSequencePrefix ("nuc_"), genePrefix ("gene_")
-//   database_config.yaml        schema.primaryKey, schema.metadata[] (name / type; `pango_lineage` columns are
-//                               loaded, the rest are outside the path), defaultNucleotideSequence
+//                               referenceGenomeFilename, nucleotideSequencePrefix ("nuc_"), genePrefix ("gene_"),
+//                               unalignedNucleotideSequencePrefix ("unaligned_")
+//   database_config.yaml        schema.primaryKey, schema.dateToSortBy, schema.metadata[] (name / type / generateIndex:
+//                               every column is loaded with its reference type), defaultNucleotideSequence
 //   reference_genomes.json, pangolineage_alias.json
-//   <metadata>.tsv + <prefix><name>.fasta[.zst|.xz]      or      <input>.ndjson[.zst|.xz]
+//   <metadata>.tsv + <prefix><name>.fasta[.zst|.xz] (+ unaligned_<name>.fasta[.zst|.xz])
+//   or <input>.ndjson[.zst|.xz] with metadata, aligned / unaligned sequences and the insertion maps per record
 #pragma once
 
 #include <string>
