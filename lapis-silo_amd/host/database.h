@@ -261,6 +261,10 @@ class DatabasePartition {
    static constexpr size_t SPARSE_CACHE_BYTES = size_t{2} << 30;
    mutable std::mutex sparse_cache_mutex;
    mutable std::map<uint64_t, DeviceBuffer> sparse_cache;
+   /// Row bitsets of the values of INDEXED string columns, built on first use (the reference builds one roaring bitmap
+   /// per value at insert time, indexed_string_column.cpp:24-36); same mutex, own budget.
+   static constexpr size_t INDEXED_VALUE_CACHE_BYTES = size_t{1} << 30;
+   mutable std::map<std::pair<const storage::column::MetadataColumnPartition*, uint32_t>, DeviceBuffer> indexed_value_cache;
 
    [[nodiscard]] uint32_t rowWords() const { return silo_gpu_store_row_words(store); }
 

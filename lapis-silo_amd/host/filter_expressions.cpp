@@ -646,6 +646,35 @@ std::unique_ptr<Operator> StringEquals::compile(
    if (!value_id.has_value()) {
       return std::make_unique<operators::Empty>(rows);
    }
+   if (indexed != nullptr) {
+      // an indexed column answers with a stored bitmap (IndexScan, string_equals.cpp:45-55): the bitset of a value is
+      // built by one compare pass on first use and kept
+      const auto key = std::make_pair(indexed, *value_id);
+      const size_t row_bytes = static_cast<size_t>(database_partition.rowWords()) * sizeof(uint64_t);
+      bool room = false;
+      {
+         const std::lock_guard<std::mutex> lock(database_partition.sparse_cache_mutex);
+         const auto found = database_partition.indexed_value_cache.find(key);
+         if (found != database_partition.indexed_value_cache.end()) {
+            return std::make_unique<operators::IndexScan>(found->second.as<uint64_t>(), rows);
+         }
+         room = (database_partition.indexed_value_cache.size() + 1) * row_bytes <= DatabasePartition::INDEXED_VALUE_CACHE_BYTES;
+      }
+      if (room) {
+         DeviceBuffer buffer = database_partition.pool.acquire(row_bytes);
+         const uint32_t id = *value_id;
+         checkGpu(
+            silo_gpu_bitset_from_compare(
+               database_partition.store, buffer.as<uint64_t>(), indexed->deviceValues(), SILO_GPU_VALUE_U32, SILO_GPU_CMP_EQUALS, &id, queryStream()
+            ),
+            "silo_gpu_bitset_from_compare"
+         );
+         checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");  // other streams may read it at once
+         const std::lock_guard<std::mutex> lock(database_partition.sparse_cache_mutex);
+         const auto [entry, inserted] = database_partition.indexed_value_cache.try_emplace(key, std::move(buffer));
+         return std::make_unique<operators::IndexScan>(entry->second.as<uint64_t>(), rows);
+      }
+   }
    return selectionOf({wordPredicate(*string_column, SILO_GPU_CMP_EQUALS, *value_id)}, rows);
 }
 
