@@ -382,8 +382,12 @@ def main():
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
+        aliases = {}  # (device pointer, length) -> tensor aliasing it: the engine's pool hands the same buffer out every step
+
         def all_reduce(device_ptr, n, _stream):
-            tensor = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
+            tensor = aliases.get((device_ptr, n))
+            if tensor is None:
+                tensor = aliases[(device_ptr, n)] = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI; ordered after the scan on the null stream
 
         class DeviceBytes:
