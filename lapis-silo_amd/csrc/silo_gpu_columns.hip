@@ -182,7 +182,7 @@ constexpr unsigned long long GROUP_HASH_EMPTY = ~0ull;
 
 __global__ __launch_bounds__(256) void k_group_hash_insert(
    const uint64_t* __restrict__ filter, uint32_t n_rows, const GroupHashArgs args, unsigned long long* __restrict__ table_keys,
-   uint32_t* __restrict__ table_counts, uint32_t capacity_mask
+   uint32_t* __restrict__ table_counts, uint32_t capacity_mask, uint32_t* __restrict__ overflow
 ) {
    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
    if (row >= n_rows) {
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void k_group_hash_insert(
    unsigned long long mixed = key * 0x9E3779B97F4A7C15ull;
    mixed ^= mixed >> 29;
    uint32_t slot = static_cast<uint32_t>(mixed) & capacity_mask;
-   while (true) {
+   // bounded probing: a table that is too small for the rows it gets (max_rows understated) is reported, never a hang
+   for (uint32_t probe = 0; probe <= capacity_mask; ++probe) {
       const unsigned long long owner = atomicCAS(table_keys + slot, GROUP_HASH_EMPTY, key);
       if (owner == GROUP_HASH_EMPTY || owner == key) {
          atomicAdd(table_counts + slot, 1u);
@@ -206,17 +207,20 @@ __global__ __launch_bounds__(256) void k_group_hash_insert(
       }
       slot = (slot + 1) & capacity_mask;
    }
+   atomicExch(overflow, 1u);
 }
 
 __global__ __launch_bounds__(256) void k_group_hash_compact(
    const unsigned long long* __restrict__ table_keys, const uint32_t* __restrict__ table_counts, uint32_t capacity,
-   unsigned long long* __restrict__ out_keys, uint32_t* __restrict__ out_counts, uint32_t* __restrict__ n_out
+   unsigned long long* __restrict__ out_keys, uint32_t* __restrict__ out_counts, uint32_t max_out, uint32_t* __restrict__ n_out
 ) {
    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
    if (slot < capacity && table_keys[slot] != GROUP_HASH_EMPTY) {
       const uint32_t index = atomicAdd(n_out, 1u);
-      out_keys[index] = table_keys[slot];
-      out_counts[index] = table_counts[slot];
+      if (index < max_out) {  // more groups than rows promised by the caller: counted, not stored
+         out_keys[index] = table_keys[slot];
+         out_counts[index] = table_counts[slot];
+      }
    }
 }
 
@@ -393,25 +397,30 @@ int silo_gpu_group_count_hashed(
    if (err == hipSuccess) err = hipMalloc(&table_counts, capacity * sizeof(uint32_t));
    if (err == hipSuccess) err = hipMalloc(&keys, static_cast<size_t>(rows_bound) * sizeof(unsigned long long));
    if (err == hipSuccess) err = hipMalloc(&counts, static_cast<size_t>(rows_bound) * sizeof(uint32_t));
-   if (err == hipSuccess) err = hipMalloc(&n_out, sizeof(uint32_t));
+   if (err == hipSuccess) err = hipMalloc(&n_out, 2 * sizeof(uint32_t));  // [0] groups, [1] overflow flag
    if (err == hipSuccess) err = hipMemsetAsync(table_keys, 0xFF, capacity * sizeof(unsigned long long), hip_stream);
    if (err == hipSuccess) err = hipMemsetAsync(table_counts, 0, capacity * sizeof(uint32_t), hip_stream);
-   if (err == hipSuccess) err = hipMemsetAsync(n_out, 0, sizeof(uint32_t), hip_stream);
+   if (err == hipSuccess) err = hipMemsetAsync(n_out, 0, 2 * sizeof(uint32_t), hip_stream);
    if (err == hipSuccess) {
       k_group_hash_insert<<<(n_rows + 255) / 256, 256, 0, hip_stream>>>(
-         filter_dev, n_rows, args, table_keys, table_counts, static_cast<uint32_t>(capacity - 1)
+         filter_dev, n_rows, args, table_keys, table_counts, static_cast<uint32_t>(capacity - 1), n_out + 1
       );
       k_group_hash_compact<<<static_cast<uint32_t>((capacity + 255) / 256), 256, 0, hip_stream>>>(
-         table_keys, table_counts, static_cast<uint32_t>(capacity), keys, counts, n_out
+         table_keys, table_counts, static_cast<uint32_t>(capacity), keys, counts, rows_bound, n_out
       );
       err = hipGetLastError();
    }
-   uint32_t n_groups = 0;
-   if (err == hipSuccess) err = hipMemcpyAsync(&n_groups, n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, hip_stream);
+   uint32_t result[2] = {0, 0};
+   if (err == hipSuccess) err = hipMemcpyAsync(result, n_out, sizeof(result), hipMemcpyDeviceToHost, hip_stream);
    if (err == hipSuccess) err = hipStreamSynchronize(hip_stream);
    if (err != hipSuccess) {
       release(false);
       SILO_HIP_TRY(err);
+   }
+   const uint32_t n_groups = result[0];
+   if (result[1] != 0 || n_groups > rows_bound) {
+      release(false);
+      return silo_gpu_internal_fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_group_count_hashed: more selected rows than max_rows");
    }
    release(true);
    *out_keys_dev = reinterpret_cast<uint64_t*>(keys);

@@ -320,3 +320,19 @@ def test_selection_unit_test_vectors_on_the_compare_kernel(built):
             got = dense.unpack_bits(store.bitset_from_compare(pointer, np.int32, negated[vec["comparator"]], vec["value"]), len(column))
             assert np.nonzero(got)[0].tolist() == vec["negated"], vec["cite"]
             store.free(pointer)
+
+
+def test_group_count_hashed_reports_an_understated_row_bound(built):
+    """max_rows smaller than the rows the filter selects: an error status, not a hang or an out-of-bounds write."""
+    from silo_amd.binding import SiloGpuError
+
+    n = 50000
+    rng = np.random.default_rng(9)
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=np.ones(4, dtype=np.uint8))]) as store:
+        ids = np.arange(n, dtype=np.uint32)  # every row its own group
+        pointer = store.upload_column(ids)
+        with pytest.raises(SiloGpuError):
+            store.group_count_hashed(None, [pointer, pointer], [n, n], 100)
+        got_ids, got_counts = store.group_count_hashed(None, [pointer, pointer], [n, n], n)
+        assert len(got_ids) == n and int(got_counts.sum()) == n
+        store.free(pointer)
