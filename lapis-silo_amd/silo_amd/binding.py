@@ -140,6 +140,8 @@ def load_library():
     lib.silo_gpu_upload_column.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
     lib.silo_gpu_bitset_from_compare.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.silo_gpu_group_count.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_mutations_select.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, vp, vp]
+    lib.silo_gpu_upload_bytes.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.silo_gpu_group_count_hashed.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_uint32,
                                                 ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), vp]
     lib.silo_gpu_reconstruct_sequences.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp]
@@ -494,6 +496,22 @@ class GpuStore:
         self.free(out)
         self.free(rows_dev)
         return chars
+
+    def mutations_select(self, counts, reference_index, min_proportion, capacity, stream=None):
+        """K4 on a host-made count table [positions][symbols]: (n_selected, rows[min(n, capacity)] as (position, symbol, count, total))."""
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        positions, n_symbols = counts.shape
+        counts_dev = self.upload_column(counts.reshape(-1))
+        ref = np.ascontiguousarray(reference_index, dtype=np.uint8)
+        ref_dev = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_upload_bytes(ref.ctypes.data_as(ctypes.c_void_p), ref.nbytes, ctypes.byref(ref_dev)))
+        out = self.malloc(16 + 16 * max(capacity, 1))
+        _check(self.lib.silo_gpu_mutations_select(counts_dev, ref_dev, positions, n_symbols, ctypes.c_double(min_proportion), capacity, out, stream))
+        words = self.read(out, np.uint32, 4 + 4 * max(capacity, 1), stream)
+        for pointer in (counts_dev, ref_dev, out):
+            self.free(pointer)
+        n = int(words[0])
+        return n, words[4:4 + 4 * min(n, capacity)].reshape(-1, 4)
 
     def last_scan_kernel(self):
         return self.lib.silo_gpu_last_scan_kernel().decode()

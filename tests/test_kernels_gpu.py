@@ -336,3 +336,36 @@ def test_group_count_hashed_reports_an_understated_row_bound(built):
         got_ids, got_counts = store.group_count_hashed(None, [pointer, pointer], [n, n], n)
         assert len(got_ids) == n and int(got_counts.sum()) == n
         store.free(pointer)
+
+
+@pytest.mark.parametrize("n_symbols", [5, 22])
+def test_mutations_select_threshold_arithmetic_matches_host_doubles(built, n_symbols):
+    """K4: ceil((double)total * minProportion) - 1 on the device is the host's IEEE arithmetic bit for bit, for totals up
+    to tens of millions and proportions that sit on rounding edges (mutations.cpp:197-211)."""
+    rng = np.random.default_rng(n_symbols)
+    positions = 20000
+    counts = np.zeros((positions, n_symbols), dtype=np.uint32)
+    scale = rng.choice([1, 10, 1000, 100000, 10_000_000], size=positions)
+    for s in range(n_symbols):
+        counts[:, s] = (rng.random(positions) ** 4 * scale).astype(np.uint32)
+    counts[rng.random(positions) < 0.05] = 0                       # positions nobody covers
+    reference = rng.integers(0, n_symbols, size=positions).astype(np.uint8)
+    reference[rng.random(positions) < 0.02] = 0xFF                 # reference symbol not among the valid ones
+    totals = counts.sum(axis=1, dtype=np.uint64)
+    with make_store(64, [dict(name="s", alphabet="nuc", reference=np.ones(4, dtype=np.uint8))]) as store:
+        for proportion in (0.0, 0.05, 1.0 / 3.0, 0.1, 0.3, 1e-9, 0.9999999, 1.0, 0.07, 2.0 / 7.0):
+            if proportion == 0:
+                threshold = np.zeros(positions, dtype=np.uint64)
+            else:
+                threshold = (np.ceil(totals.astype(np.float64) * proportion) - 1).astype(np.int64).astype(np.uint64) & 0xFFFFFFFF
+            want = set()
+            for position in np.nonzero(totals)[0]:
+                for s in range(n_symbols):
+                    if s != reference[position] and counts[position, s] > threshold[position]:
+                        want.add((int(position), s, int(counts[position, s]), int(totals[position])))
+            n, rows = store.mutations_select(counts, reference, proportion, positions * n_symbols)
+            assert n == len(want), proportion
+            assert {tuple(int(v) for v in row) for row in rows} == want, proportion
+            # a list that is too short still reports the true number of selected cells
+            n_short, rows_short = store.mutations_select(counts, reference, proportion, 7)
+            assert n_short == n and len(rows_short) == min(n, 7)
