@@ -128,7 +128,10 @@ def test_reference_preprocessing_scenarios(built, scenario):
 
 @pytest.mark.gpu
 def test_cli_answers_queries(built):
-    cases = dataset.load_query_fixtures("queries")[:6] + dataset.load_query_fixtures("invalidQueries")[:2]
+    next_rows = [case for case in dataset.load_query_fixtures("queries_next")
+                 if case["file"] in ("GroupByDivision.json", "dateBetween.json", "insertionsAction.json", "fastaAligned_multiple.json", "DetailsOrderBy.json")]
+    assert len(next_rows) == 5
+    cases = dataset.load_query_fixtures("queries")[:6] + next_rows + dataset.load_query_fixtures("invalidQueries")[:2]
     stdin = "".join(json.dumps(case["query"]) + "\n" for case in cases)
     proc = subprocess.run([os.path.join(ROOT, "lapis-silo_amd", "lib", "silo_query"), EXAMPLE], input=stdin, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
