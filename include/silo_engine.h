@@ -123,6 +123,10 @@ void silo_engine_free_string(char* text);
 /* The reference's two per-query timings (query_engine.cpp:63-65) of the last query on this thread. */
 void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_microseconds);
 
+/* The value of the `data-version` response header (query_handler.cpp:38, data_version.cpp:9-13): the unix time at which
+ * silo_engine_finalize built the data, as decimal text; *out_text is malloc'ed (free with silo_engine_free_string). */
+int silo_engine_data_version(const silo_engine* engine, char** out_text);
+
 /* Phase marks of the last query on this thread as JSON {"phase": microseconds since the query began, ...};
  * *out_json is malloc'ed (free with silo_engine_free_string). */
 int silo_engine_last_trace(char** out_json);

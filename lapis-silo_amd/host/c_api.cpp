@@ -413,6 +413,14 @@ void silo_engine_last_timings(int64_t* filter_microseconds, int64_t* action_micr
    }
 }
 
+int silo_engine_data_version(const silo_engine* engine, char** out_text) {
+   if (engine == nullptr || out_text == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_data_version: null argument");
+   }
+   *out_text = duplicate(engine->database.data_version);
+   return *out_text != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+}
+
 int silo_engine_last_trace(char** out_json) {
    if (out_json == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_last_trace: null argument");

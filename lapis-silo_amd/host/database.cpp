@@ -623,6 +623,7 @@ void Database::appendUnalignedSequences(
 }
 
 void Database::finalize() {
+   data_version = std::to_string(std::chrono::system_clock::to_time_t(std::chrono::system_clock::now()));  // DataVersion::mineDataVersion
    const bool device_in_use = !partitions.empty();
    nuc_mutation_layout = makeMutationTableLayout(nuc_sequences, device_in_use);
    aa_mutation_layout = makeMutationTableLayout(aa_sequences, device_in_use);

@@ -289,6 +289,9 @@ class Database {
    std::deque<DatabasePartition> partitions;
    std::map<std::string, SequenceStore<Nucleotide>> nuc_sequences;
    std::map<std::string, SequenceStore<AminoAcid>> aa_sequences;
+   /// data_version.cpp:9-13: the moment the data was built, as a decimal unix time; silo_api sends it as the
+   /// `data-version` header of every query response (query_handler.cpp:38).  Set by finalize().
+   std::string data_version;
    /// database_config.yaml: default nucleotide sequence; metadata columns in file order, primary key, dateToSortBy
    config::DatabaseConfig database_config;
    PangoLineageAliasLookup alias_key;

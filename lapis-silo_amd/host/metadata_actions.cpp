@@ -99,7 +99,11 @@ QueryResult Aggregated::aggregateWithGrouping(const Database& database, std::vec
          cardinalities.push_back(column_groups.cardinality);
          n_bins = std::min<uint64_t>(n_bins * std::max<uint32_t>(column_groups.cardinality, 1), uint64_t{1} << 40);
       }
-      if (n_fields <= SILO_GPU_MAX_GROUP_COLUMNS && n_bins <= SILO_GPU_MAX_GROUP_BINS) {
+      // the dense histogram comes back whole (4 bytes per potential tuple): beyond a million potential tuples the hash
+      // table path, which returns only the tuples that occur, moves less data
+      constexpr uint64_t DENSE_HISTOGRAM_LIMIT = uint64_t{1} << 20;
+      static_assert(DENSE_HISTOGRAM_LIMIT <= SILO_GPU_MAX_GROUP_BINS);
+      if (n_fields <= SILO_GPU_MAX_GROUP_COLUMNS && n_bins <= DENSE_HISTOGRAM_LIMIT) {
          InFlight& launch = in_flight.emplace_back();
          launch.partition = &partition;
          launch.columns = columns;

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string",
+    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
@@ -52,6 +52,7 @@ def load_library():
     lib.silo_engine_set_schema.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
     lib.silo_engine_append_metadata.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
     lib.silo_engine_append_unaligned_sequences.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
+    lib.silo_engine_data_version.argtypes = [vp, ctypes.POINTER(vp)]
     lib.silo_engine_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_execute_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
@@ -237,6 +238,14 @@ class Engine:
         """Unaligned nucleotide sequences (None = none) for the Fasta action."""
         array = (ctypes.c_char_p * max(len(sequences), 1))(*[None if s is None else s.encode() for s in sequences])
         _check(self.lib.silo_engine_append_unaligned_sequences(self.handle, partition, sequence_name.encode(), array, len(sequences)))
+
+    def data_version(self):
+        out = ctypes.c_void_p()
+        _check(self.lib.silo_engine_data_version(self.handle, ctypes.byref(out)))
+        try:
+            return ctypes.string_at(out).decode()
+        finally:
+            self.lib.silo_engine_free_string(out)
 
     def set_option(self, name, value):
         _check(self.lib.silo_engine_set_option(self.handle, name.encode(), int(value)))

@@ -69,6 +69,7 @@ def test_reference_e2e_invalid_goldens(engines, case):
 
 def test_inline_error_cases(engines):  # endToEndTests/test/query.test.js:64-113
     engine, _ = engines
+    assert engine.data_version().isdigit() and int(engine.data_version()) > 1_600_000_000  # headerToHaveDataVersion, common.js
     status, document = engine.execute_raw({"someJson": "but missing expected properties"})
     assert (status, document) == (400, {"error": "Bad request", "message": "Query json must contain filterExpression and action."})
     status, document = engine.execute_raw({"action": {"type": "invalid action"}, "filterExpression": {"type": "invalid filter type"}})
