@@ -96,11 +96,16 @@ uint32_t missingSymbol(uint32_t alphabet) {
 enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
 
 struct SeqStoreDev {
-   uint64_t* scan;   // [P][n_scan][Wp]
+   // Bit-sliced scan planes [P][n_bits][Wp]: bit b of the CODE of every row's symbol at the position, where the code of
+   // the k-th valid mutation symbol is k + 1 and 0 stands for "none of them" (missing, ambiguity code, row padding).
+   // n_bits = 3 for the 5 nucleotide symbols, 5 for the 22 amino-acid symbols: the Mutations scan streams
+   // 3 (5) planes per position instead of 5 (22) one-hot planes.
+   uint64_t* scan;
    uint64_t* extra;  // [n_extra][P][Wp]
    uint32_t positions;
    uint32_t n_symbols;  // alphabet size
    uint32_t n_scan;
+   uint32_t n_bits;
    uint32_t n_extra;
    uint32_t row_words;  // Wp
    uint32_t missing_symbol;
@@ -108,15 +113,30 @@ struct SeqStoreDev {
    uint8_t index[SILO_GPU_MAX_SYMBOLS];
 };
 
+/// One-hot plane of a symbol that has one: the extra symbols.  Valid mutation symbols live in the bit-sliced scan planes
+/// (decodeScanWord / silo_gpu_store_sparse_plane materialise their one-hot plane on demand).
 __host__ __device__ inline uint64_t* planePtr(const SeqStoreDev& s, uint32_t position, uint32_t symbol) {
    const uint8_t kind = s.kind[symbol];
-   if (kind == PLANE_SCAN) {
-      return s.scan + (static_cast<size_t>(position) * s.n_scan + s.index[symbol]) * s.row_words;
-   }
    if (kind == PLANE_EXTRA) {
       return s.extra + (static_cast<size_t>(s.index[symbol]) * s.positions + position) * s.row_words;
    }
    return nullptr;
+}
+
+__host__ __device__ inline const uint64_t* scanPlanes(const SeqStoreDev& s, uint32_t position) {
+   return s.scan + static_cast<size_t>(position) * s.n_bits * s.row_words;
+}
+
+/// Word `word` of the one-hot plane of valid mutation symbol `symbol` at `position`, decoded from the bit planes.
+__device__ __forceinline__ uint64_t decodeScanWord(const SeqStoreDev& s, uint32_t position, uint32_t symbol, uint32_t word) {
+   const uint32_t code = static_cast<uint32_t>(s.index[symbol]) + 1u;
+   const uint64_t* base = scanPlanes(s, position) + word;
+   uint64_t match = ~0ull;
+   for (uint32_t bit = 0; bit < s.n_bits; ++bit) {
+      const uint64_t plane_word = base[static_cast<size_t>(bit) * s.row_words];
+      match &= ((code >> bit) & 1u) != 0 ? plane_word : ~plane_word;
+   }
+   return match;  // padding bits have code 0, every valid symbol has a code >= 1
 }
 
 struct SeqStoreHost {
@@ -180,18 +200,22 @@ __device__ __forceinline__ uint32_t popc128(const ulonglong2& v, const ulonglong
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1a: tiled Mutations scan for long rows.
+// K1: Mutations scan over the bit-sliced planes.
 //
-// Grid: blockIdx.x = row_group * n_tiles + tile.  A block owns a column tile of
-// TILE_WORDS = 256 threads * WPT words of the filter, held in registers for the whole block lifetime
-// (the "filter staged once and reused across all position columns" of the north star: registers
-// are the first-level staging, LDS only carries the per-row partial counts), and streams that
-// tile's slice of `rows_per_block` consecutive plane rows.  Every load instruction is a fully
-// coalesced 16 B/lane access (4 KiB per block, 1 KiB per wave).
+// counts[q][p][k] += popcount(filter_q & {rows whose code at position p is k + 1}) for the NSYM valid mutation symbols,
+// reading BITS = ceil(log2(NSYM + 1)) planes per position (3 for nucleotides, 5 for amino acids) instead of NSYM
+// one-hot planes: 0.375 instead of 0.625 bytes per position x sequence (nuc), 0.625 instead of 2.75 (aa).
+//
+// Grid: blockIdx.x = position_group * n_tiles + tile.  A block owns a column tile of TILE_WORDS = 256 threads * WPT
+// words of the Q filters, held in registers for the whole block lifetime (registers are the first-level staging of
+// the filter, LDS only carries per-wave partial counts), and streams that tile's slice of the BITS plane rows of
+// `positions_per_block` consecutive positions.  Every load is a fully coalesced, non-temporal 16 B/lane access; the
+// planes of position p+1 are in flight while position p is decoded (two register buffers, unconditional clamped
+// loads so that s_waitcnt keeps counting).  Decoding is pure VALU: per symbol BITS and/andn per word (constant-folded
+// code bits, shared sub-terms), an AND with each filter, v_bcnt; then a 6-instruction DPP wave reduction per
+// (symbol, filter).  Out-of-row chunks of the ragged last tile read word 0 against zero filters.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ROWS_BATCH = 64;
-
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -209,163 +233,45 @@ __device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
    }
 }
 
-template <int WPT, bool GUARDED, bool NT>
-__device__ __forceinline__ void scanTile(
-   const uint64_t* __restrict__ planes,
-   const uint64_t* __restrict__ filter,
-   uint32_t* __restrict__ counts,
-   uint32_t row_words,
-   uint32_t n_rows,
-   uint32_t rows_per_block,
-   uint32_t tile,
-   uint32_t row_group,
-   uint32_t (&s_partial)[2][SCAN_WAVES][SCAN_ROWS_BATCH]
-) {
-   constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread
-   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
-   constexpr int WAVES = SCAN_WAVES;
-
-   const uint32_t tid = threadIdx.x;
-   const uint32_t wave = tid >> 6;
-   const bool writer = (tid & 63u) == 63u;  // waveSumToLane63 leaves the total in lane 63
-   const uint32_t row_begin = row_group * rows_per_block;
-   const uint32_t row_end = min(n_rows, row_begin + rows_per_block);
-   const uint32_t last_row = row_end - 1;
-
-   // this thread's 16-byte chunks of the tile; the filter words stay in registers for all rows
-   uint32_t word[CHUNKS];
-   ulonglong2 f[CHUNKS];
-#pragma unroll
-   for (int j = 0; j < CHUNKS; ++j) {
-      word[j] = tile * TILE_WORDS + (j * SCAN_THREADS + tid) * 2;
-      if (GUARDED && word[j] >= row_words) {
-         // out-of-row chunks read word 0 (always valid) against a zero filter: no branch in the loop
-         word[j] = 0;
-         f[j] = make_ulonglong2(0, 0);
-      } else {
-         f[j] = *reinterpret_cast<const ulonglong2*>(filter + word[j]);
-      }
-   }
-
-   auto load_row = [&](uint32_t row, ulonglong2 (&dst)[CHUNKS]) {
-      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
-#pragma unroll
-      for (int j = 0; j < CHUNKS; ++j) {
-         dst[j] = loadPlane16<NT>(row_ptr + word[j]);
-      }
-   };
-   auto reduce_row = [&](const ulonglong2 (&src)[CHUNKS]) {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int j = 0; j < CHUNKS; ++j) {
-         acc += popc128(src[j], f[j]);
-      }
-      return waveSumToLane63(acc);
-   };
-   auto flush = [&](uint32_t batch_first_row, uint32_t n_batch, uint32_t buffer) {
-      __syncthreads();
-      if (tid < n_batch) {
-         uint32_t total = 0;
-#pragma unroll
-         for (int w = 0; w < WAVES; ++w) {
-            total += s_partial[buffer][w][tid];
-         }
-         if (total != 0) {
-            atomicAdd(&counts[batch_first_row + tid], total);
-         }
-      }
-   };
-
-   // Software pipeline over rows with two register buffers: while row r is reduced, the loads of
-   // row r+1 are in flight.  Loads past the block's last row are clamped to it (an L2 hit, result
-   // unused) so that the loop body has no load under a branch and s_waitcnt can stay at vmcnt(4).
-   ulonglong2 buf_a[CHUNKS];
-   ulonglong2 buf_b[CHUNKS];
-   load_row(row_begin, buf_a);
-   uint32_t buffer = 0;
-   uint32_t batch_first_row = row_begin;
-   for (uint32_t row = row_begin; row < row_end; row += 2) {
-      load_row(min(row + 1, last_row), buf_b);
-      const uint32_t sum_a = reduce_row(buf_a);
-      if (writer) {
-         s_partial[buffer][wave][row - batch_first_row] = sum_a;
-      }
-      load_row(min(row + 2, last_row), buf_a);
-      const uint32_t sum_b = reduce_row(buf_b);
-      if (writer && row + 1 < row_end) {
-         s_partial[buffer][wave][row + 1 - batch_first_row] = sum_b;
-      }
-      const uint32_t done = min(row + 2, row_end) - batch_first_row;
-      if (done >= SCAN_ROWS_BATCH || row + 2 >= row_end) {  // SCAN_ROWS_BATCH is even
-         flush(batch_first_row, done, buffer);
-         batch_first_row += done;
-         buffer ^= 1u;
-      }
-   }
-}
-
-// One launch covers the whole (rows x row_words) rectangle: blockIdx.x = row_group * n_tiles + tile.
-// Only the last column tile can be ragged (row_words is a multiple of 32 words, a tile is 2048); it
-// takes the guarded instantiation through a block-uniform branch, every other block the unguarded one.
-template <int WPT, bool NT>
-__global__ __launch_bounds__(SCAN_THREADS, (WPT <= 8 ? 8 : 4)) void k_scan_tiled(
-   const uint64_t* __restrict__ planes,
-   const uint64_t* __restrict__ filter,
-   uint32_t* __restrict__ counts,
-   uint32_t row_words,
-   uint32_t n_rows,
-   uint32_t rows_per_block,
-   uint32_t n_tiles
-) {
-   // per-wave partial counts of one batch of rows, double-buffered so one barrier per batch suffices
-   __shared__ uint32_t s_partial[2][SCAN_WAVES][SCAN_ROWS_BATCH];
-   constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
-   const uint32_t tile = blockIdx.x % n_tiles;
-   const uint32_t row_group = blockIdx.x / n_tiles;
-   if ((tile + 1) * TILE_WORDS <= row_words) {
-      scanTile<WPT, false, NT>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
-   } else {
-      scanTile<WPT, true, NT>(planes, filter, counts, row_words, n_rows, rows_per_block, tile, row_group, s_partial);
-   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1c: the same scan for Q filters at once (a batch of concurrent Mutations queries over one store).
-// Every plane row is loaded ONCE and ANDed with the Q filter tiles held in registers, so Q queries cost
-// one pass over the planes; at Q = 4 the extra AND / popcount / DPP work still fits under the HBM time.
-// 8 words per thread (Q * 16 filter registers), out-of-row chunks read word 0 against zero filters.
-// ------------------------------------------------------------------------------------------------
 struct ScanBatchArgs {
    const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
 };
 
-// Words per thread: 8 up to four filters (Q * 16 filter registers), 4 beyond (5..8 filters: Q * 8 registers), so
-// that the filter tiles never push the kernel below 4 waves per SIMD.
-template <int Q>
-constexpr int batchWordsPerThread() {
-   return Q <= 4 ? 8 : 4;
+// positions whose partial counts sit in LDS between two flushes: ~16 KiB of LDS whatever NSYM * Q is
+template <int NSYM, int Q>
+constexpr int scanPositionsBatch() {
+   int batch = 512 / (NSYM * Q);
+   batch -= batch & 1;
+   return batch < 2 ? 2 : (batch > 64 ? 64 : batch);
 }
 
-template <int Q>
-__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tiled_batch(
-   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, uint32_t row_words, uint32_t n_rows, uint32_t rows_per_block,
+// blocks per CU the register budget has to allow: plane buffers 2 * BITS * WPT * 2 VGPRs, filters Q * WPT * 2
+template <int BITS, int WPT, int Q>
+constexpr int scanMinBlocks() {
+   return Q == 1 ? (BITS * WPT <= 12 ? 6 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2)) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
+}
+
+template <int BITS, int NSYM, int WPT, int Q>
+__global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void k_scan_sliced(
+   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, uint32_t row_words, uint32_t n_positions, uint32_t positions_per_block,
    uint32_t n_tiles
 ) {
-   constexpr int WPT = batchWordsPerThread<Q>();
-   constexpr int CHUNKS = WPT / 2;
+   constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread and plane
    constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
-   __shared__ uint32_t s_partial[2][SCAN_WAVES][SCAN_ROWS_BATCH][Q];
+   constexpr int POS_BATCH = scanPositionsBatch<NSYM, Q>();
+   __shared__ uint32_t s_partial[2][SCAN_WAVES][POS_BATCH][NSYM * Q];
 
    const uint32_t tid = threadIdx.x;
    const uint32_t wave = tid >> 6;
-   const bool writer = (tid & 63u) == 63u;
+   const bool writer = (tid & 63u) == 63u;  // waveSumToLane63 leaves the total in lane 63
    const uint32_t tile = blockIdx.x % n_tiles;
-   const uint32_t row_group = blockIdx.x / n_tiles;
-   const uint32_t row_begin = row_group * rows_per_block;
-   const uint32_t row_end = min(n_rows, row_begin + rows_per_block);
-   const uint32_t last_row = row_end - 1;
+   const uint32_t position_group = blockIdx.x / n_tiles;
+   const uint32_t pos_begin = position_group * positions_per_block;
+   const uint32_t pos_end = min(n_positions, pos_begin + positions_per_block);
+   const uint32_t last_pos = pos_end - 1;
 
+   // this thread's 16-byte chunks of the tile; the filter words stay in registers for all positions
    uint32_t word[CHUNKS];
    ulonglong2 f[Q][CHUNKS];
 #pragma unroll
@@ -373,102 +279,133 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tiled_batch(
       word[j] = tile * TILE_WORDS + (j * SCAN_THREADS + tid) * 2;
       const bool inside = word[j] < row_words;
       if (!inside) {
-         word[j] = 0;
+         word[j] = 0;  // out-of-row chunks read word 0 (always valid) against zero filters: no branch in the loop
       }
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
          f[q][j] = inside ? *reinterpret_cast<const ulonglong2*>(batch.filters[q] + word[j]) : make_ulonglong2(0, 0);
       }
    }
-   auto load_row = [&](uint32_t row, ulonglong2 (&dst)[CHUNKS]) {
-      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
+
+   auto load_position = [&](uint32_t position, ulonglong2 (&dst)[BITS][CHUNKS]) {
+      const uint64_t* base = planes + static_cast<size_t>(position) * BITS * row_words;
 #pragma unroll
-      for (int j = 0; j < CHUNKS; ++j) {
-         dst[j] = loadPlane16<true>(row_ptr + word[j]);
-      }
-   };
-   auto reduce_row = [&](const ulonglong2 (&src)[CHUNKS], uint32_t buffer, uint32_t slot, bool store) {
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-         uint32_t acc = 0;
+      for (int bit = 0; bit < BITS; ++bit) {
 #pragma unroll
          for (int j = 0; j < CHUNKS; ++j) {
-            acc += popc128(src[j], f[q][j]);
-         }
-         acc = waveSumToLane63(acc);
-         if (writer && store) {
-            s_partial[buffer][wave][slot][q] = acc;
+            dst[bit][j] = loadPlane16<true>(base + static_cast<size_t>(bit) * row_words + word[j]);
          }
       }
    };
-   auto flush = [&](uint32_t batch_first_row, uint32_t n_batch, uint32_t buffer) {
+   auto reduce_position = [&](const ulonglong2 (&src)[BITS][CHUNKS], uint32_t buffer, uint32_t slot, bool store) {
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
+         constexpr uint64_t ONES = ~0ull;
+         const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
+         uint32_t acc[Q];
+#pragma unroll
+         for (int q = 0; q < Q; ++q) {
+            acc[q] = 0;
+         }
+#pragma unroll
+         for (int j = 0; j < CHUNKS; ++j) {
+            uint64_t match_x = ONES, match_y = ONES;
+#pragma unroll
+            for (int bit = 0; bit < BITS; ++bit) {
+               match_x &= ((code >> bit) & 1u) != 0 ? src[bit][j].x : ~src[bit][j].x;
+               match_y &= ((code >> bit) & 1u) != 0 ? src[bit][j].y : ~src[bit][j].y;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+               acc[q] += static_cast<uint32_t>(__popcll(match_x & f[q][j].x)) + static_cast<uint32_t>(__popcll(match_y & f[q][j].y));
+            }
+         }
+#pragma unroll
+         for (int q = 0; q < Q; ++q) {
+            const uint32_t total = waveSumToLane63(acc[q]);
+            if (writer && store) {
+               s_partial[buffer][wave][slot][q * NSYM + symbol] = total;
+            }
+         }
+      }
+   };
+   auto flush = [&](uint32_t batch_first_position, uint32_t n_batch, uint32_t buffer) {
       __syncthreads();
-      for (uint32_t item = tid; item < n_batch * Q; item += SCAN_THREADS) {
-         const uint32_t row = item / Q;
-         const uint32_t q = item % Q;
+      for (uint32_t item = tid; item < n_batch * (NSYM * Q); item += SCAN_THREADS) {
+         const uint32_t position = item / (NSYM * Q);
+         const uint32_t rest = item % (NSYM * Q);
          uint32_t total = 0;
 #pragma unroll
          for (int w = 0; w < SCAN_WAVES; ++w) {
-            total += s_partial[buffer][w][row][q];
+            total += s_partial[buffer][w][position][rest];
          }
          if (total != 0) {
-            atomicAdd(&batch.counts[q][batch_first_row + row], total);
+            atomicAdd(&batch.counts[rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
          }
       }
    };
 
-   ulonglong2 buf_a[CHUNKS];
-   ulonglong2 buf_b[CHUNKS];
-   load_row(row_begin, buf_a);
+   ulonglong2 buf_a[BITS][CHUNKS];
+   ulonglong2 buf_b[BITS][CHUNKS];
+   load_position(pos_begin, buf_a);
    uint32_t buffer = 0;
-   uint32_t batch_first_row = row_begin;
-   for (uint32_t row = row_begin; row < row_end; row += 2) {
-      load_row(min(row + 1, last_row), buf_b);
-      reduce_row(buf_a, buffer, row - batch_first_row, true);
-      load_row(min(row + 2, last_row), buf_a);
-      reduce_row(buf_b, buffer, row + 1 - batch_first_row, row + 1 < row_end);
-      const uint32_t done = min(row + 2, row_end) - batch_first_row;
-      if (done >= SCAN_ROWS_BATCH || row + 2 >= row_end) {
-         flush(batch_first_row, done, buffer);
-         batch_first_row += done;
+   uint32_t batch_first_position = pos_begin;
+   for (uint32_t position = pos_begin; position < pos_end; position += 2) {
+      load_position(min(position + 1, last_pos), buf_b);
+      reduce_position(buf_a, buffer, position - batch_first_position, true);
+      load_position(min(position + 2, last_pos), buf_a);
+      reduce_position(buf_b, buffer, position + 1 - batch_first_position, position + 1 < pos_end);
+      const uint32_t done = min(position + 2, pos_end) - batch_first_position;
+      if (done >= static_cast<uint32_t>(POS_BATCH) || position + 2 >= pos_end) {  // POS_BATCH is even
+         flush(batch_first_position, done, buffer);
+         batch_first_position += done;
          buffer ^= 1u;
       }
    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1b: one wave per row, for short rows (small N) where a 256-thread column tile would be empty.
+// K1b: one wave per position, for short rows (small N) where a 256-thread column tile would be mostly empty.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan_rowwave(
-   const uint64_t* __restrict__ planes,
-   const uint64_t* __restrict__ filter,
-   uint32_t* __restrict__ counts,
-   uint32_t row_words,
-   uint32_t n_rows
+template <int BITS, int NSYM>
+__global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
+   const uint64_t* __restrict__ planes, const uint64_t* __restrict__ filter, uint32_t* __restrict__ counts, uint32_t row_words,
+   uint32_t n_positions
 ) {
    const uint32_t lane = threadIdx.x & 63u;
    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-   const uint32_t n_chunks = row_words / 2;
-
-   // the first chunk of the filter stays in registers across rows (covers N <= 8192 entirely)
-   const ulonglong2 f0 =
-      lane < n_chunks ? *reinterpret_cast<const ulonglong2*>(filter + 2 * lane) : make_ulonglong2(0, 0);
-
-   for (uint32_t row = wave; row < n_rows; row += n_waves) {
-      const uint64_t* row_ptr = planes + static_cast<size_t>(row) * row_words;
-      uint32_t acc = 0;
-      if (lane < n_chunks) {
-         acc = popc128(*reinterpret_cast<const ulonglong2*>(row_ptr + 2 * lane), f0);
+   for (uint32_t position = wave; position < n_positions; position += n_waves) {
+      const uint64_t* base = planes + static_cast<size_t>(position) * BITS * row_words;
+      uint32_t acc[NSYM];
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
+         acc[symbol] = 0;
       }
-      for (uint32_t chunk = lane + 64; chunk < n_chunks; chunk += 64) {
-         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(row_ptr + 2 * chunk);
-         const ulonglong2 f = *reinterpret_cast<const ulonglong2*>(filter + 2 * chunk);
-         acc += popc128(v, f);
+      for (uint32_t w = lane; w < row_words; w += 64) {
+         const uint64_t filter_word = filter[w];
+         uint64_t bits[BITS];
+#pragma unroll
+         for (int bit = 0; bit < BITS; ++bit) {
+            bits[bit] = base[static_cast<size_t>(bit) * row_words + w];
+         }
+#pragma unroll
+         for (int symbol = 0; symbol < NSYM; ++symbol) {
+            const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
+            uint64_t match = filter_word;
+#pragma unroll
+            for (int bit = 0; bit < BITS; ++bit) {
+               match &= ((code >> bit) & 1u) != 0 ? bits[bit] : ~bits[bit];
+            }
+            acc[symbol] += static_cast<uint32_t>(__popcll(match));
+         }
       }
-      acc = waveSumToLane63(acc);
-      if (lane == 63u && acc != 0) {
-         atomicAdd(&counts[row], acc);
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
+         const uint32_t total = waveSumToLane63(acc[symbol]);
+         if (lane == 63u && total != 0) {
+            atomicAdd(&counts[static_cast<size_t>(position) * NSYM + symbol], total);
+         }
       }
    }
 }
@@ -483,6 +420,7 @@ __device__ __forceinline__ void addToCountShard(unsigned long long* shards, uint
       atomicAdd(shards + (blockIdx.x % SILO_GPU_COUNT_SHARDS), static_cast<unsigned long long>(wave_total_lane63));
    }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // K2: popcount of one row-sized bitset
@@ -608,13 +546,32 @@ __device__ __forceinline__ void emitWord(
    uint64_t* sparse, uint32_t* sparse_count, uint32_t sparse_capacity
 ) {
    const uint32_t lane = threadIdx.x & 63u;
+   // valid mutation symbols: the bits of their code go to the bit-sliced scan planes
+   const bool is_scan = symbol < store.n_symbols && store.kind[symbol] == PLANE_SCAN;
+   const uint32_t code = is_scan ? static_cast<uint32_t>(store.index[symbol]) + 1u : 0u;
+   uint64_t* scan_word = store.scan + static_cast<size_t>(position) * store.n_bits * store.row_words + word;
+   for (uint32_t bit = 0; bit < store.n_bits; ++bit) {
+      const uint64_t mask = __ballot(((code >> bit) & 1u) != 0);
+      if (mask != 0 && lane == 0) {
+         uint64_t* dst = scan_word + static_cast<size_t>(bit) * store.row_words;
+         if (whole_word) {
+            *dst = mask;
+         } else {
+            atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(mask));
+         }
+      }
+   }
+   // every other symbol: its own plane (extra) or the sorted key list (sparse)
    for (uint32_t s = 0; s < store.n_symbols; ++s) {
+      const uint8_t kind = store.kind[s];
+      if (kind == PLANE_SCAN) {
+         continue;
+      }
       const uint64_t mask = __ballot(symbol == s);
       if (mask == 0) {
          continue;
       }
-      const uint8_t kind = store.kind[s];
-      if (kind != PLANE_SPARSE) {
+      if (kind == PLANE_EXTRA) {
          if (lane == 0) {
             uint64_t* dst = planePtr(store, position, s) + word;
             if (whole_word) {
@@ -891,7 +848,17 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
    const uint32_t word = sequence >> 6;
    const uint32_t bit = sequence & 63u;
    uint32_t found = 0xFFu;
+   uint32_t code = 0;  // the row's code in the bit-sliced scan planes: valid mutation symbol index + 1, or 0
+   for (uint32_t plane_bit = 0; plane_bit < store.n_bits; ++plane_bit) {
+      code |= static_cast<uint32_t>((scanPlanes(store, position)[static_cast<size_t>(plane_bit) * store.row_words + word] >> bit) & 1u) << plane_bit;
+   }
    for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
+      if (store.kind[symbol] == PLANE_SCAN) {
+         if (code != 0 && store.index[symbol] + 1u == code) {
+            found = symbol;
+         }
+         continue;
+      }
       const uint64_t* plane = planePtr(store, position, symbol);
       if (plane != nullptr && ((plane[word] >> bit) & 1u) != 0) {
          found = symbol;
@@ -918,6 +885,14 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
       }
    }
    out[static_cast<size_t>(blockIdx.y) * store.positions + position] = found == 0xFFu ? '?' : symbol_chars[found];
+}
+
+// One-hot plane of a valid mutation symbol out of the bit-sliced scan planes (n_bits reads per word).
+__global__ __launch_bounds__(256) void k_decode_plane(const SeqStoreDev store, uint32_t position, uint32_t symbol, uint64_t* __restrict__ out) {
+   const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
+   if (word < store.row_words) {
+      out[word] = decodeScanWord(store, position, symbol, word);
+   }
 }
 
 __global__ void k_scatter_sparse(const uint64_t* __restrict__ keys, uint32_t begin, uint32_t end, uint64_t* out) {
@@ -1031,6 +1006,10 @@ int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out)
       dev.positions = in.positions;
       dev.n_symbols = alphabetSize(in.alphabet);
       dev.n_scan = in.n_scan_symbols;
+      dev.n_bits = 0;
+      while ((1u << dev.n_bits) < dev.n_scan + 1u) {
+         ++dev.n_bits;
+      }
       dev.n_extra = in.n_extra_symbols;
       dev.row_words = row_words;
       dev.missing_symbol = missingSymbol(in.alphabet);
@@ -1052,7 +1031,7 @@ int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out)
          dev.kind[in.extra_symbols[s]] = PLANE_EXTRA;
          dev.index[in.extra_symbols[s]] = static_cast<uint8_t>(s);
       }
-      const size_t scan_bytes = static_cast<size_t>(in.positions) * dev.n_scan * row_words * sizeof(uint64_t);
+      const size_t scan_bytes = static_cast<size_t>(in.positions) * dev.n_bits * row_words * sizeof(uint64_t);
       const size_t extra_bytes = static_cast<size_t>(in.positions) * dev.n_extra * row_words * sizeof(uint64_t);
       hipError_t err = hipSuccess;
       if (scan_bytes > 0) {
@@ -1414,6 +1393,116 @@ void silo_gpu_free(void* dev_ptr) {
    (void)hipFree(dev_ptr);
 }
 
+}  // extern "C"
+
+namespace {
+
+/// Launches k_scan_sliced for `q_count` filters (1..SILO_GPU_MAX_SCAN_BATCH) over positions [pos_begin, pos_end).
+template <int BITS, int NSYM>
+int launchSlicedScan(
+   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
+   hipStream_t hip_stream
+) {
+   const uint32_t row_words = dev.row_words;
+   const uint32_t n_positions = pos_end - pos_begin;
+   const uint64_t* planes = scanPlanes(dev, pos_begin);
+   (void)store;
+   // words per thread: 8 for one nucleotide filter (3 planes x 4 chunks per position and buffer), 4 otherwise (amino
+   // acids: 5 planes; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
+   const int variant = g_tune_scan_variant.load();
+   bool wide = BITS <= 3 && q_count == 1 && row_words >= SCAN_THREADS * 8;
+   if (variant == 10) {
+      wide = false;
+   } else if (variant == 12 && BITS <= 3 && q_count == 1) {
+      wide = true;
+   }
+   const uint32_t tile_words = SCAN_THREADS * (wide ? 8 : 4);
+   int positions_per_block = g_tune_rows_per_block.load();
+   if (positions_per_block <= 0) {
+      positions_per_block = BITS <= 3 ? 32 : 12;  // ~100 / ~60 plane rows per block (profiles/r01_scan_variants.md)
+   }
+   positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
+   const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
+   const dim3 grid(n_tiles * ((n_positions + positions_per_block - 1) / positions_per_block));
+#define SILO_LAUNCH_SLICED(WPT, Q) \
+   k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_positions, positions_per_block, n_tiles)
+   if (wide) {
+      if constexpr (BITS <= 3) {
+         SILO_LAUNCH_SLICED(8, 1);
+      }
+   } else {
+      switch (q_count) {
+         case 1: SILO_LAUNCH_SLICED(4, 1); break;
+         case 2: SILO_LAUNCH_SLICED(4, 2); break;
+         case 3: SILO_LAUNCH_SLICED(4, 3); break;
+         case 4: SILO_LAUNCH_SLICED(4, 4); break;
+         default:
+            if constexpr (BITS <= 3) {  // 5..8 filters: nucleotides only (amino-acid batches go in groups of 4)
+               switch (q_count) {
+                  case 5: SILO_LAUNCH_SLICED(4, 5); break;
+                  case 6: SILO_LAUNCH_SLICED(4, 6); break;
+                  case 7: SILO_LAUNCH_SLICED(4, 7); break;
+                  default: SILO_LAUNCH_SLICED(4, 8); break;
+               }
+            } else {
+               return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "launchSlicedScan: more than 4 amino-acid filters in one pass");
+            }
+      }
+   }
+#undef SILO_LAUNCH_SLICED
+   HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+/// Scan for up to SILO_GPU_MAX_SCAN_BATCH filters in one pass; dispatches on the layout of the sequence store.
+int slicedScan(
+   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
+   hipStream_t hip_stream
+) {
+   if (dev.row_words < SCAN_THREADS * 4) {
+      // short rows: one wave per position, one filter at a time
+      const uint32_t n_positions = pos_end - pos_begin;
+      const uint32_t waves = std::min<uint32_t>(n_positions, 256u * 32u);
+      const uint32_t blocks = (waves + 3) / 4;
+      for (uint32_t q = 0; q < q_count; ++q) {
+         if (dev.n_bits == 3 && dev.n_scan == 5) {
+            k_scan_sliced_rowwave<3, 5><<<blocks, 256, 0, hip_stream>>>(scanPlanes(dev, pos_begin), batch.filters[q], batch.counts[q], dev.row_words, n_positions);
+         } else if (dev.n_bits == 5 && dev.n_scan == 22) {
+            k_scan_sliced_rowwave<5, 22><<<blocks, 256, 0, hip_stream>>>(scanPlanes(dev, pos_begin), batch.filters[q], batch.counts[q], dev.row_words, n_positions);
+         } else {
+            return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
+         }
+      }
+      HIP_TRY(hipGetLastError());
+      g_last_scan_kernel = "k_scan_sliced_rowwave";
+      return SILO_GPU_OK;
+   }
+   g_last_scan_kernel = q_count == 1 ? "k_scan_sliced" : "k_scan_sliced_batch";
+   if (dev.n_bits == 3 && dev.n_scan == 5) {
+      return launchSlicedScan<3, 5>(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
+   }
+   if (dev.n_bits == 5 && dev.n_scan == 22) {
+      for (uint32_t first = 0; first < q_count; first += 4) {  // amino acids: at most 4 filters per pass
+         ScanBatchArgs part{};
+         const uint32_t n = std::min<uint32_t>(4, q_count - first);
+         for (uint32_t q = 0; q < n; ++q) {
+            part.filters[q] = batch.filters[first + q];
+            part.counts[q] = batch.counts[first + q];
+         }
+         const int rc = launchSlicedScan<5, 22>(store, dev, part, n, pos_begin, pos_end, hip_stream);
+         if (rc != SILO_GPU_OK) {
+            return rc;
+         }
+      }
+      return SILO_GPU_OK;
+   }
+   return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
+}
+
+}  // namespace
+
+extern "C" {
+
 int silo_gpu_mutations_scan_batch(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* const* filters_dev, uint32_t n_filters, uint32_t pos_begin,
    uint32_t pos_end, uint32_t* const* counts_out_dev, void* stream
@@ -1430,26 +1519,11 @@ int silo_gpu_mutations_scan_batch(
    if (pos_begin > pos_end || pos_end > dev.positions) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");
    }
-   constexpr uint32_t TILE_WORDS = SCAN_THREADS * 8;
-   // short rows (one wave per row kernel) and single filters take the one-filter path
-   if (n_filters == 1 || dev.row_words < TILE_WORDS) {
-      for (uint32_t q = 0; q < n_filters; ++q) {
-         const int rc = silo_gpu_mutations_scan(store, seqstore_id, filters_dev[q], pos_begin, pos_end, counts_out_dev[q], stream);
-         if (rc != SILO_GPU_OK) {
-            return rc;
-         }
-      }
-      return SILO_GPU_OK;
-   }
    if (pos_begin == pos_end || dev.n_scan == 0 || n_filters == 0) {
       return SILO_GPU_OK;
    }
    HIP_TRY(hipSetDevice(store->device));
    auto hip_stream = static_cast<hipStream_t>(stream);
-   const uint32_t row_words = dev.row_words;
-   const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
-   const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
-   const uint32_t rows_per_block = 64;
    for (uint32_t first = 0; first < n_filters; first += SILO_GPU_MAX_SCAN_BATCH) {
       const uint32_t q_count = std::min<uint32_t>(SILO_GPU_MAX_SCAN_BATCH, n_filters - first);
       ScanBatchArgs batch{};
@@ -1457,31 +1531,11 @@ int silo_gpu_mutations_scan_batch(
          batch.filters[q] = filters_dev[first + q];
          batch.counts[q] = counts_out_dev[first + q];
       }
-      if (q_count == 1) {  // the odd one out of a batch: the single-filter kernel
-         const int rc = silo_gpu_mutations_scan(store, seqstore_id, batch.filters[0], pos_begin, pos_end, batch.counts[0], stream);
-         if (rc != SILO_GPU_OK) {
-            return rc;
-         }
-         continue;
+      const int rc = slicedScan(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
+      if (rc != SILO_GPU_OK) {
+         return rc;
       }
-      const uint32_t tile_words = SCAN_THREADS * (q_count <= 4 ? 8 : 4);
-      const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
-      const dim3 grid(n_tiles * ((n_rows + rows_per_block - 1) / rows_per_block));
-#define SILO_LAUNCH_BATCH(Q) \
-   case Q: k_scan_tiled_batch<Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles); break;
-      switch (q_count) {
-         SILO_LAUNCH_BATCH(2)
-         SILO_LAUNCH_BATCH(3)
-         SILO_LAUNCH_BATCH(4)
-         SILO_LAUNCH_BATCH(5)
-         SILO_LAUNCH_BATCH(6)
-         SILO_LAUNCH_BATCH(7)
-         default: k_scan_tiled_batch<8><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_rows, rows_per_block, n_tiles); break;
-      }
-#undef SILO_LAUNCH_BATCH
-      HIP_TRY(hipGetLastError());
    }
-   g_last_scan_kernel = "k_scan_tiled_batch";
    return SILO_GPU_OK;
 }
 
@@ -1715,6 +1769,18 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
    }
    HIP_TRY(hipSetDevice(store->device));
    auto hip_stream = static_cast<hipStream_t>(stream);
+   if (seqstore.dev.kind[symbol] == PLANE_SCAN) {  // a valid mutation symbol: decode its one-hot plane from the bit planes
+      k_decode_plane<<<(store->row_words + 255) / 256, 256, 0, hip_stream>>>(seqstore.dev, position, symbol, dst_dev);
+      HIP_TRY(hipGetLastError());
+      return SILO_GPU_OK;
+   }
+   if (seqstore.dev.kind[symbol] == PLANE_EXTRA) {  // already a plane: copy it
+      HIP_TRY(hipMemcpyAsync(
+         dst_dev, planePtr(seqstore.dev, position, symbol), static_cast<size_t>(store->row_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+         hip_stream
+      ));
+      return SILO_GPU_OK;
+   }
    HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(store->row_words) * sizeof(uint64_t), hip_stream));
    const uint64_t key_begin = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32);
    const uint64_t key_end = key_begin + (1ull << 32);
@@ -1978,53 +2044,10 @@ int silo_gpu_mutations_scan(
       g_last_scan_kernel = "k_add_u32 (cached totals)";
       return SILO_GPU_OK;
    }
-   const uint64_t* filter = filter_dev;
-   const uint32_t row_words = dev.row_words;
-   const uint32_t n_rows = (pos_end - pos_begin) * dev.n_scan;
-   const uint64_t* planes = dev.scan + static_cast<size_t>(pos_begin) * dev.n_scan * row_words;
-   auto hip_stream = static_cast<hipStream_t>(stream);
-
-   // Kernel selection (measured on MI355X, profiles/r01_scan_variants.md):
-   //   rows shorter than one 2048-word tile      -> k_scan_rowwave (one wave per row, cacheable loads)
-   //   otherwise k_scan_tiled with non-temporal plane loads; 16 words per thread when rows are long and that
-   //   tiling pads the row no worse than the 8-word one (a ragged last tile idles lanes), else 8.
-   // SILO_GPU_TUNE_SCAN_VARIANT: 0 auto, 1 force tiled, 2 force rowwave, 10 tiled 8 words, 12 tiled 16 words.
-   const int variant = g_tune_scan_variant.load();
-   constexpr uint32_t TILE8 = SCAN_THREADS * 8, TILE16 = SCAN_THREADS * 16;
-   const bool tiled = variant == 1 || variant >= 10 || (variant == 0 && row_words >= TILE8);
-   if (!tiled) {
-      const uint32_t waves = std::min<uint32_t>(n_rows, 256u * 32u);
-      const uint32_t blocks = (waves + 3) / 4;
-      k_scan_rowwave<<<blocks, 256, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows);
-      g_last_scan_kernel = "k_scan_rowwave";
-      HIP_TRY(hipGetLastError());
-      return SILO_GPU_OK;
-   }
-   const double pad8 = static_cast<double>((row_words + TILE8 - 1) / TILE8 * TILE8) / row_words;
-   const double pad16 = static_cast<double>((row_words + TILE16 - 1) / TILE16 * TILE16) / row_words;
-   bool wide = row_words >= 8192 && pad16 <= pad8 + 0.02;
-   if (variant == 10) {
-      wide = false;
-   } else if (variant == 12) {
-      wide = true;
-   }
-   const uint32_t tile_words = wide ? TILE16 : TILE8;
-   int rows_per_block = g_tune_rows_per_block.load();
-   if (rows_per_block <= 0) {
-      rows_per_block = 64;
-   }
-   rows_per_block += rows_per_block & 1;  // the row pipeline works on pairs
-   const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
-   const uint32_t row_groups = (n_rows + rows_per_block - 1) / rows_per_block;
-   const dim3 grid(n_tiles * row_groups);
-   if (wide) {
-      k_scan_tiled<16, true><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles);
-   } else {
-      k_scan_tiled<8, true><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, filter, counts_out_dev, row_words, n_rows, rows_per_block, n_tiles);
-   }
-   HIP_TRY(hipGetLastError());
-   g_last_scan_kernel = "k_scan_tiled";
-   return SILO_GPU_OK;
+   ScanBatchArgs batch{};
+   batch.filters[0] = filter_dev;
+   batch.counts[0] = counts_out_dev;
+   return slicedScan(store, dev, batch, 1, pos_begin, pos_end, static_cast<hipStream_t>(stream));
 }
 
 int silo_gpu_reconstruct_sequences(

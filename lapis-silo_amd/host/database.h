@@ -258,7 +258,7 @@ class DatabasePartition {
 
    /// Materialised bitsets of sparsely stored symbols (IUPAC ambiguity codes), keyed by
    /// seqstore << 40 | local position << 8 | symbol; filled on first use by ProgramBuilder::sparseLeaf.
-   static constexpr size_t SPARSE_CACHE_BYTES = size_t{2} << 30;
+   static constexpr size_t SPARSE_CACHE_BYTES = size_t{32} << 30;
    mutable std::mutex sparse_cache_mutex;
    mutable std::map<uint64_t, DeviceBuffer> sparse_cache;
    /// Row bitsets of the values of INDEXED string columns, built on first use (the reference builds one roaring bitmap

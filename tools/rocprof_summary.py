@@ -1,7 +1,7 @@
 """Summarises rocprofv3 CSV output (kernel trace / PMC counter collection) into profiles/.
 
 usage: python tools/rocprof_summary.py <round-tag> <kernel_trace.csv> [<fetch_counter_collection.csv> <write_counter_collection.csv> [sequences rows]]
-(sequences / rows = the workload of the profiled k_scan_tiled launches, recorded so that bench.py can match them)
+(sequences / rows = the workload of the profiled k_scan_sliced launches, recorded so that bench.py can match them)
 Writes profiles/<tag>_kernel_summary.md and, with counters, profiles/pmc_traffic.json — the file bench.py
 reads for roofline.traffic.  Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM:
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
@@ -57,7 +57,7 @@ def main():
                 }
         if len(sys.argv) >= 7:
             for key, entry in traffic.items():
-                if key.startswith("k_scan_tiled"):
+                if key.startswith("k_scan_sliced"):
                     entry["sequences"], entry["rows"] = int(sys.argv[5]), int(sys.argv[6])
         doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {tag}",
                "correction": "bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (MI355X_MICROARCH.md §HBM)",
