@@ -146,12 +146,15 @@ int silo_gpu_stream_synchronize(void* stream);
 int silo_gpu_stream_create(void** out_stream);
 void silo_gpu_stream_destroy(void* stream);
 
-/* Device pointer of the dense plane of (seqstore, position, symbol), or NULL when that symbol is
- * sparse / not stored.  Replaces SequenceStorePartition::getBitmap (sequence_store.cpp:92-98);
- * positions are 0-based as there. */
+/* Device pointer of the one-hot plane of (seqstore, position, symbol) when the store holds one: the extra symbols
+ * (the missing symbol N / X).  NULL for the valid mutation symbols — they live in the bit-sliced scan planes
+ * ([position][code bit][Wp], code = index among the scan symbols + 1; 3 planes for 5 nucleotide symbols, 5 for 22
+ * amino-acid symbols) — and for sparsely stored symbols; silo_gpu_store_sparse_plane materialises either.
+ * Replaces SequenceStorePartition::getBitmap (sequence_store.cpp:92-98); positions are 0-based as there. */
 const uint64_t* silo_gpu_store_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol);
 
-/* Materialises the bitset of a sparse symbol at a position into dst_dev (Wp words, overwritten). */
+/* Materialises the one-hot bitset of any symbol at a position into dst_dev (Wp words, overwritten): decoded from the
+ * code planes (valid mutation symbols), copied (extra symbols) or scattered from the sorted keys (sparse symbols). */
 int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, uint32_t symbol, uint64_t* dst_dev, void* stream);
 
 /* ---- K3: fused filter-expression evaluator --------------------------------------------------------
@@ -299,8 +302,9 @@ int silo_gpu_mutations_select(
 int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev);
 
 /* ---- K1: Mutations scan (mutations.cpp:64-164) ---------------------------------------------------
- * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & plane[p][scan_symbols[s]])
- * for p in [pos_begin, pos_end).  The buffer is ACCUMULATED into (the reference sums partitions into
+ * counts_out_dev[(p - pos_begin) * n_scan_symbols + s] += popcount(filter & {rows whose symbol at p is scan_symbols[s]})
+ * for p in [pos_begin, pos_end), decoded from the bit-sliced scan planes (3 planes per nucleotide position, 5 per
+ * amino-acid position; the scan symbols must be the 5 / 22 valid mutation symbols).  The buffer is ACCUMULATED into (the reference sums partitions into
  * one table, mutations.cpp:71,108); zero it with silo_gpu_memset_async before the first partition.
  * filter_dev == NULL means the full filter: like the reference, which then reads stored cardinalities
  * instead of intersecting (mutations.cpp:98-136), the totals of the unfiltered store are computed by one
