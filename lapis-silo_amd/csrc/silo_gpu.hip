@@ -249,7 +249,7 @@ constexpr int scanPositionsBatch() {
 // blocks per CU the register budget has to allow: plane buffers 2 * BITS * WPT * 2 VGPRs, filters Q * WPT * 2
 template <int BITS, int WPT, int Q>
 constexpr int scanMinBlocks() {
-   return Q == 1 ? (BITS * WPT <= 12 ? 6 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2)) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
+   return Q == 1 ? (BITS * WPT <= 12 ? 4 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2)) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
 }
 
 template <int BITS, int NSYM, int WPT, int Q>
@@ -298,31 +298,68 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
       }
    };
    auto reduce_position = [&](const ulonglong2 (&src)[BITS][CHUNKS], uint32_t buffer, uint32_t slot, bool store) {
+      uint32_t acc[NSYM][Q];
 #pragma unroll
       for (int symbol = 0; symbol < NSYM; ++symbol) {
-         constexpr uint64_t ONES = ~0ull;
-         const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
-         uint32_t acc[Q];
 #pragma unroll
          for (int q = 0; q < Q; ++q) {
-            acc[q] = 0;
+            acc[symbol][q] = 0;
          }
+      }
 #pragma unroll
-         for (int j = 0; j < CHUNKS; ++j) {
-            uint64_t match_x = ONES, match_y = ONES;
+      for (int j = 0; j < CHUNKS; ++j) {
+#pragma unroll
+         for (int half = 0; half < 2; ++half) {
+            uint64_t bits[BITS];
 #pragma unroll
             for (int bit = 0; bit < BITS; ++bit) {
-               match_x &= ((code >> bit) & 1u) != 0 ? src[bit][j].x : ~src[bit][j].x;
-               match_y &= ((code >> bit) & 1u) != 0 ? src[bit][j].y : ~src[bit][j].y;
+               bits[bit] = half == 0 ? src[bit][j].x : src[bit][j].y;
+            }
+            // Decode tree: the four combinations of the two low code bits, of the next two, and the top bit — a symbol
+            // is then two ANDs (22 symbols from 5 planes: ~55 logic ops per word instead of 110).  With one filter the
+            // filter is folded into the low pair, so the per-symbol AND with it disappears as well.
+            const uint64_t filter0 = half == 0 ? f[0][j].x : f[0][j].y;
+            uint64_t low[4];
+            low[0] = ~bits[1] & ~bits[0];
+            low[1] = ~bits[1] & bits[0];
+            low[2] = bits[1] & ~bits[0];
+            low[3] = bits[1] & bits[0];
+            if constexpr (Q == 1) {
+#pragma unroll
+               for (int k = 0; k < 4; ++k) {
+                  low[k] &= filter0;
+               }
+            }
+            uint64_t high[BITS <= 3 ? 2 : 8];
+            if constexpr (BITS == 3) {
+               high[0] = ~bits[2];
+               high[1] = bits[2];
+            } else {
+               static_assert(BITS == 5, "decode tree written for 3 or 5 code bits");
+#pragma unroll
+               for (int k = 0; k < 8; ++k) {
+                  high[k] = ((k & 1) != 0 ? bits[2] : ~bits[2]) & ((k & 2) != 0 ? bits[3] : ~bits[3]) & ((k & 4) != 0 ? bits[4] : ~bits[4]);
+               }
             }
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-               acc[q] += static_cast<uint32_t>(__popcll(match_x & f[q][j].x)) + static_cast<uint32_t>(__popcll(match_y & f[q][j].y));
+            for (int symbol = 0; symbol < NSYM; ++symbol) {
+               constexpr int dummy = 0;
+               (void)dummy;
+               const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
+               const uint64_t match = low[code & 3u] & high[code >> 2];
+#pragma unroll
+               for (int q = 0; q < Q; ++q) {
+                  const uint64_t filter_word = half == 0 ? f[q][j].x : f[q][j].y;
+                  acc[symbol][q] += static_cast<uint32_t>(__popcll(Q == 1 ? match : (match & filter_word)));
+               }
             }
          }
+      }
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
 #pragma unroll
          for (int q = 0; q < Q; ++q) {
-            const uint32_t total = waveSumToLane63(acc[q]);
+            const uint32_t total = waveSumToLane63(acc[symbol][q]);
             if (writer && store) {
                s_partial[buffer][wave][slot][q * NSYM + symbol] = total;
             }
