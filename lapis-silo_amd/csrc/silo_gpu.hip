@@ -249,7 +249,7 @@ constexpr int scanPositionsBatch() {
 // blocks per CU the register budget has to allow: plane buffers 2 * BITS * WPT * 2 VGPRs, filters Q * WPT * 2
 template <int BITS, int WPT, int Q>
 constexpr int scanMinBlocks() {
-   return Q == 1 ? (BITS * WPT <= 12 ? 4 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2)) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
+   return Q == 1 ? (BITS * WPT <= 12 ? 4 : (BITS * WPT <= 18 ? 4 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2))) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
 }
 
 template <int BITS, int NSYM, int WPT, int Q>
@@ -1453,17 +1453,24 @@ int launchSlicedScan(
    } else if (variant == 12 && BITS <= 3 && q_count == 1) {
       wide = true;
    }
-   const uint32_t tile_words = SCAN_THREADS * (wide ? 8 : 4);
+   const bool medium = variant == 14 && BITS <= 3 && q_count == 1;  // experiment: 6 words per thread
+   const uint32_t tile_words = SCAN_THREADS * (medium ? 6 : (wide ? 8 : 4));
    int positions_per_block = g_tune_rows_per_block.load();
+   const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    if (positions_per_block <= 0) {
-      positions_per_block = BITS <= 3 ? 32 : 12;  // ~100 / ~60 plane rows per block (profiles/r01_scan_variants.md)
+      // nucleotides: 128 positions (384 plane rows) per block while that still leaves >= 4096 blocks, else 64; amino
+      // acids 12 (60 plane rows) — profiles/r01_scan_variants.md
+      positions_per_block = BITS <= 3 ? (static_cast<uint64_t>(n_tiles) * ((n_positions + 127) / 128) >= 4096 ? 128 : 64) : 12;
    }
    positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
-   const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    const dim3 grid(n_tiles * ((n_positions + positions_per_block - 1) / positions_per_block));
 #define SILO_LAUNCH_SLICED(WPT, Q) \
    k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_positions, positions_per_block, n_tiles)
-   if (wide) {
+   if (medium) {
+      if constexpr (BITS <= 3) {
+         SILO_LAUNCH_SLICED(6, 1);
+      }
+   } else if (wide) {
       if constexpr (BITS <= 3) {
          SILO_LAUNCH_SLICED(8, 1);
       }
