@@ -277,6 +277,38 @@ def batch_workload(engine, positions, n_sequences, sync, reps=5):
     }
 
 
+def selective_workload(engine, lib, tree, lineage, positions, n_sequences, sync, reps=20):
+    """Mutations under SELECTIVE filters (one exact lineage: a few thousand rows scattered over the store): the dense
+    scan would cost the same 16 ms whatever the filter selects; K1s gathers only the 64-byte sectors of the planes
+    that hold selected rows.  Timed with the routing on (default) and off; responses must be identical."""
+    sizes = np.bincount(lineage, minlength=len(tree.names))
+    order = [int(i) for i in np.argsort(sizes) if sizes[i] > 0]
+    picks = {"smallest lineage": order[0], "median lineage": order[len(order) // 2]}
+    out = {}
+    for label, index in picks.items():
+        query = json.dumps({
+            "action": {"type": "Mutations", "minProportion": 0.05},
+            "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": tree.names[index], "includeSublineages": False},
+        }).encode()
+        timings = {}
+        responses = {}
+        for mode, divisor in (("gather", 0), ("dense", -1)):
+            lib.silo_gpu_tune(3, divisor)
+            responses[mode] = engine.execute_text(query)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                engine.execute_text(query)
+            sync()
+            timings[mode] = (time.perf_counter() - t0) / reps * 1e3
+        lib.silo_gpu_tune(3, 0)
+        if responses["gather"] != responses["dense"] or responses["gather"][0] != 200:
+            raise AssertionError("sparse-filter routing changed a response")
+        out[label] = {"lineage": tree.names[index], "rows_selected": int(sizes[index]), "ms_per_query": timings["gather"],
+                      "ms_per_query_dense_scan": timings["dense"], "mutation_rows": len(json.loads(responses["gather"][1].decode())["queryResult"])}
+    return {"workload": f"Mutations under one exact PangoLineage (no sublineages), {n_sequences} sequences", "queries": out}
+
+
 def metadata_workload(engine, n_sequences, sync, seconds=1.0):
     """SURVEY.md §8(f) row 3 on the 1 M-sequence engine: metadata predicates feeding the filter program (K5) and
     Aggregated with groupByFields (K6); latency per query through executeQuery."""
@@ -498,6 +530,7 @@ def main():
     if rank == 0 and world == 1 and not use_dist and not args.no_also:
         result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
         result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)
+        result["selective_queries"] = selective_workload(engine, lib, tree, lineage, positions, args.sequences, sync)
     lib.silo_gpu_free(filt)
     lib.silo_gpu_free(counts_dev)
     engine.close()

@@ -324,7 +324,8 @@ int silo_gpu_mutations_scan_batch(
 int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream);
 
 /* Tuning knobs of K1 (0 = default); returns the previous value.  For benchmarks only. */
-enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SILO_GPU_TUNE_EVAL_LEAF_BATCH = 2 /* 8 (default) or 16 leaf loads in flight per lane in K3 */ };
+enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SILO_GPU_TUNE_EVAL_LEAF_BATCH = 2 /* 8 (default) or 16 leaf loads in flight per lane in K3 */,
+       SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };
 int silo_gpu_tune(int knob, int value);
 
 /* HIP events on the caller's stream, so a host without the HIP headers can time the kernels

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -34,6 +35,7 @@ thread_local const char* g_last_scan_kernel = "none";
 std::atomic<int> g_tune_rows_per_block{0};
 std::atomic<int> g_tune_scan_variant{0};
 std::atomic<int> g_tune_eval_leaf_batch{0};
+std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
 int fail(int code, const std::string& msg) {
    g_last_error = msg;
@@ -236,6 +238,11 @@ __device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
 struct ScanBatchArgs {
    const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
+   // sparse-filter routing (K1s): sparse_sectors[q] = number of 64-byte sectors of filter q with a set bit, written by
+   // k_compact_filter earlier on the same stream; a filter with at most sparse_capacity of them is served by
+   // k_scan_gather and is treated as empty by k_scan_sliced.  nullptr = no routing.
+   const uint32_t* sparse_sectors;
+   uint32_t sparse_capacity;
 };
 
 // positions whose partial counts sit in LDS between two flushes: ~16 KiB of LDS whatever NSYM * Q is
@@ -271,6 +278,21 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
    const uint32_t pos_end = min(n_positions, pos_begin + positions_per_block);
    const uint32_t last_pos = pos_end - 1;
 
+   // filters routed to the gather kernel count as empty here; a block with nothing left to do leaves at once
+   bool dense[Q];
+#pragma unroll
+   for (int q = 0; q < Q; ++q) {
+      dense[q] = batch.sparse_sectors == nullptr || batch.sparse_sectors[q] > batch.sparse_capacity;
+   }
+   bool any_dense = false;
+#pragma unroll
+   for (int q = 0; q < Q; ++q) {
+      any_dense |= dense[q];
+   }
+   if (!any_dense) {
+      return;
+   }
+
    // this thread's 16-byte chunks of the tile; the filter words stay in registers for all positions
    uint32_t word[CHUNKS];
    ulonglong2 f[Q][CHUNKS];
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
       }
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-         f[q][j] = inside ? *reinterpret_cast<const ulonglong2*>(batch.filters[q] + word[j]) : make_ulonglong2(0, 0);
+         f[q][j] = inside && dense[q] ? *reinterpret_cast<const ulonglong2*>(batch.filters[q] + word[j]) : make_ulonglong2(0, 0);
       }
    }
 
@@ -442,6 +464,133 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
          const uint32_t total = waveSumToLane63(acc[symbol]);
          if (lane == 63u && total != 0) {
             atomicAdd(&counts[static_cast<size_t>(position) * NSYM + symbol], total);
+         }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1s: Mutations scan under a SPARSE filter.  The dense scan costs the same whatever the filter selects; the reference's
+// roaring and_cardinality gets cheaper with the filter (mutations.cpp:139-164 over a small filter bitmap), so a query
+// for a few hundred rows must not pay for 112 GB.  k_compact_filter lists the 64-byte SECTORS (8 consecutive words —
+// the unit HBM delivers) of the filter that hold a set bit, at most `capacity` of them (the total is counted
+// regardless); when they fit, k_scan_gather reads only those sectors of every plane and k_scan_sliced skips the
+// filter.  The decision is taken on the device from the counter: no host round trip.  Measured at 10 M sequences
+// (profiles/r01_sparse_filters.md): ~1 µs per listed sector against 16.5 ms for the dense scan, hence the default
+// capacity of row_words / 16 sectors.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SECTOR_WORDS = 8;
+
+__global__ __launch_bounds__(256) void k_compact_filter(
+   const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index
+) {
+   const uint32_t q = blockIdx.y;
+   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // row_words is a multiple of 32: sectors never straddle the row end
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint64_t value = w < row_words ? batch.filters[q][w] : 0;
+   const uint64_t ballot = __ballot(value != 0);
+   if (ballot == 0) {
+      return;
+   }
+   // one bit per sector of this wave (at the sector's first lane): does any of its 8 words have a set bit?
+   uint64_t leaders = 0;
+#pragma unroll
+   for (uint32_t sector = 0; sector < 64 / SECTOR_WORDS; ++sector) {
+      if (((ballot >> (sector * SECTOR_WORDS)) & 0xFFull) != 0) {
+         leaders |= 1ull << (sector * SECTOR_WORDS);
+      }
+   }
+   uint32_t base = 0;
+   if (lane == 0) {
+      base = atomicAdd(sparse_sectors + q, static_cast<uint32_t>(__popcll(leaders)));
+   }
+   base = __shfl(base, 0);
+   if (((leaders >> lane) & 1ull) != 0) {
+      const uint32_t slot = base + static_cast<uint32_t>(__popcll(leaders & ((1ull << lane) - 1ull)));
+      if (slot < capacity) {
+         sector_index[static_cast<size_t>(q) * capacity + slot] = w / SECTOR_WORDS;
+      }
+   }
+}
+
+// One WAVE per group of POSG consecutive positions (no LDS, no block-level reduction: a sparse filter may have fewer
+// non-zero words than a block has lanes); lanes stride over the words of the listed sectors, POSG * BITS gathers in flight each.
+template <int BITS, int NSYM, int POSG>
+__global__ __launch_bounds__(256) void k_scan_gather(
+   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity,
+   uint32_t row_words, uint32_t n_positions
+) {
+   const uint32_t q = blockIdx.y;
+   const uint32_t n_sectors = batch.sparse_sectors[q];
+   if (n_sectors == 0 || n_sectors > batch.sparse_capacity) {
+      return;  // empty filter, or a dense one (k_scan_sliced has it); `capacity` is the stride of the lists
+   }
+   const uint32_t n_words = n_sectors * SECTOR_WORDS;
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const uint32_t pos_begin = group * POSG;
+   if (pos_begin >= n_positions) {
+      return;
+   }
+   const uint32_t last_pos = n_positions - 1;
+   const uint32_t* index = sector_index + static_cast<size_t>(q) * capacity;
+   const uint64_t* filter = batch.filters[q];
+   const size_t position_stride = static_cast<size_t>(BITS) * row_words;
+
+   uint32_t acc[POSG][NSYM];
+#pragma unroll
+   for (int g = 0; g < POSG; ++g) {
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
+         acc[g][symbol] = 0;
+      }
+   }
+   for (uint32_t i = lane; i < n_words; i += 64) {
+      const uint32_t w = index[i / SECTOR_WORDS] * SECTOR_WORDS + i % SECTOR_WORDS;  // 8 lanes share a 64-byte sector
+      const uint64_t filter_word = filter[w];
+      uint64_t bits[POSG][BITS];
+#pragma unroll
+      for (int g = 0; g < POSG; ++g) {
+         // positions past the end are clamped (an in-bounds re-read) and not stored below
+         const uint64_t* base = planes + static_cast<size_t>(min(pos_begin + g, last_pos)) * position_stride + w;
+#pragma unroll
+         for (int bit = 0; bit < BITS; ++bit) {
+            bits[g][bit] = base[static_cast<size_t>(bit) * row_words];
+         }
+      }
+#pragma unroll
+      for (int g = 0; g < POSG; ++g) {
+         uint64_t low[4];
+         low[0] = ~bits[g][1] & ~bits[g][0] & filter_word;
+         low[1] = ~bits[g][1] & bits[g][0] & filter_word;
+         low[2] = bits[g][1] & ~bits[g][0] & filter_word;
+         low[3] = bits[g][1] & bits[g][0] & filter_word;
+         uint64_t high[BITS <= 3 ? 2 : 8];
+         if constexpr (BITS == 3) {
+            high[0] = ~bits[g][2];
+            high[1] = bits[g][2];
+         } else {
+            static_assert(BITS == 5, "decode tree written for 3 or 5 code bits");
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+               high[k] = ((k & 1) != 0 ? bits[g][2] : ~bits[g][2]) & ((k & 2) != 0 ? bits[g][3] : ~bits[g][3]) &
+                         ((k & 4) != 0 ? bits[g][4] : ~bits[g][4]);
+            }
+         }
+#pragma unroll
+         for (int symbol = 0; symbol < NSYM; ++symbol) {
+            const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
+            acc[g][symbol] += static_cast<uint32_t>(__popcll(low[code & 3u] & high[code >> 2]));
+         }
+      }
+   }
+#pragma unroll
+   for (int g = 0; g < POSG; ++g) {
+#pragma unroll
+      for (int symbol = 0; symbol < NSYM; ++symbol) {
+         const uint32_t total = waveSumToLane63(acc[g][symbol]);
+         if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
+            atomicAdd(&batch.counts[q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
          }
       }
    }
@@ -1004,6 +1153,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_EVAL_LEAF_BATCH) {
       return g_tune_eval_leaf_batch.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR) {
+      return g_tune_sparse_divisor.exchange(value);
+   }
    return -1;
 }
 
@@ -1498,8 +1650,60 @@ int launchSlicedScan(
    return SILO_GPU_OK;
 }
 
+/// Device scratch of the sparse-filter routing: per filter a counter and the list of sector indexes.  Blocks are
+/// pooled; a block is handed out again only once the event recorded after its last use has completed, whatever
+/// stream that use was on.
+struct SparseScratch {
+   int device = 0;
+   uint32_t capacity = 0;  // sectors per filter
+   uint32_t* sparse_sectors = nullptr;  // [SILO_GPU_MAX_SCAN_BATCH]
+   uint32_t* sector_index = nullptr;    // [SILO_GPU_MAX_SCAN_BATCH][capacity]
+   hipEvent_t last_use = nullptr;
+   bool in_flight = false;  // handed out and not yet released
+};
+
+std::mutex g_sparse_scratch_mutex;
+std::vector<SparseScratch*> g_sparse_scratch;
+
+int acquireSparseScratch(int device, uint32_t capacity, SparseScratch** out) {
+   {
+      std::lock_guard<std::mutex> lock(g_sparse_scratch_mutex);
+      for (SparseScratch* block : g_sparse_scratch) {
+         if (!block->in_flight && block->device == device && block->capacity >= capacity && hipEventQuery(block->last_use) == hipSuccess) {
+            block->in_flight = true;
+            *out = block;
+            return SILO_GPU_OK;
+         }
+      }
+   }
+   auto block = std::make_unique<SparseScratch>();
+   block->device = device;
+   block->capacity = capacity;
+   void* memory = nullptr;
+   // one allocation: the index lists, then the counters
+   const size_t bytes = (static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity + SILO_GPU_MAX_SCAN_BATCH) * sizeof(uint32_t);
+   HIP_TRY(hipMalloc(&memory, bytes));
+   block->sector_index = static_cast<uint32_t*>(memory);
+   block->sparse_sectors = block->sector_index + static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity;
+   if (hipEventCreateWithFlags(&block->last_use, hipEventDisableTiming) != hipSuccess) {
+      (void)hipFree(memory);
+      return fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipEventCreate failed");
+   }
+   block->in_flight = true;
+   std::lock_guard<std::mutex> lock(g_sparse_scratch_mutex);
+   g_sparse_scratch.push_back(block.get());
+   *out = block.release();
+   return SILO_GPU_OK;
+}
+
+void releaseSparseScratch(SparseScratch* block, hipStream_t stream) {
+   (void)hipEventRecord(block->last_use, stream);
+   std::lock_guard<std::mutex> lock(g_sparse_scratch_mutex);
+   block->in_flight = false;
+}
+
 /// Scan for up to SILO_GPU_MAX_SCAN_BATCH filters in one pass; dispatches on the layout of the sequence store.
-int slicedScan(
+int slicedScanDense(
    const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
    hipStream_t hip_stream
 ) {
@@ -1533,6 +1737,8 @@ int slicedScan(
             part.filters[q] = batch.filters[first + q];
             part.counts[q] = batch.counts[first + q];
          }
+         part.sparse_sectors = batch.sparse_sectors != nullptr ? batch.sparse_sectors + first : nullptr;
+         part.sparse_capacity = batch.sparse_capacity;
          const int rc = launchSlicedScan<5, 22>(store, dev, part, n, pos_begin, pos_end, hip_stream);
          if (rc != SILO_GPU_OK) {
             return rc;
@@ -1541,6 +1747,60 @@ int slicedScan(
       return SILO_GPU_OK;
    }
    return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
+}
+
+/// The scan with sparse-filter routing (K1s) around the dense kernels: compact every filter, let the dense kernels
+/// skip the sparse ones, and serve those with the gather kernel.  All decisions are taken on the device.
+int slicedScan(
+   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch_in, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
+   hipStream_t hip_stream
+) {
+   const int divisor = g_tune_sparse_divisor.load();
+   const bool layout_known = (dev.n_bits == 3 && dev.n_scan == 5) || (dev.n_bits == 5 && dev.n_scan == 22);
+   if (divisor < 0 || dev.row_words < SCAN_THREADS * 4 || !layout_known) {
+      return slicedScanDense(store, dev, batch_in, q_count, pos_begin, pos_end, hip_stream);
+   }
+   const uint32_t capacity = std::max<uint32_t>(4, dev.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
+   SparseScratch* scratch = nullptr;
+   const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
+   if (acquired != SILO_GPU_OK) {
+      return acquired;
+   }
+   ScanBatchArgs batch = batch_in;
+   batch.sparse_sectors = scratch->sparse_sectors;
+   batch.sparse_capacity = capacity;
+   int rc = SILO_GPU_OK;
+   const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
+   if (hipMemsetAsync(scratch->sparse_sectors, 0, SILO_GPU_MAX_SCAN_BATCH * sizeof(uint32_t), hip_stream) != hipSuccess) {
+      rc = fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipMemsetAsync failed");
+   } else {
+      k_compact_filter<<<dim3((dev.row_words + 255) / 256, q_count), 256, 0, hip_stream>>>(
+         batch, dev.row_words, stride, scratch->sparse_sectors, scratch->sector_index
+      );
+      rc = slicedScanDense(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
+   }
+   if (rc == SILO_GPU_OK) {
+      const uint32_t n_positions = pos_end - pos_begin;
+      const ScanBatchArgs& gather = batch;
+      if (dev.n_bits == 3) {
+         constexpr int POSG = 4;
+         const uint32_t waves = (n_positions + POSG - 1) / POSG;
+         k_scan_gather<3, 5, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(
+            scanPlanes(dev, pos_begin), gather, scratch->sector_index, stride, dev.row_words, n_positions
+         );
+      } else {
+         constexpr int POSG = 2;
+         const uint32_t waves = (n_positions + POSG - 1) / POSG;
+         k_scan_gather<5, 22, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(
+            scanPlanes(dev, pos_begin), gather, scratch->sector_index, stride, dev.row_words, n_positions
+         );
+      }
+      if (hipGetLastError() != hipSuccess) {
+         rc = fail(SILO_GPU_ERR_HIP, "k_scan_gather: launch failed");
+      }
+   }
+   releaseSparseScratch(scratch, hip_stream);
+   return rc;
 }
 
 }  // namespace

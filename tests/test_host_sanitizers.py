@@ -31,4 +31,4 @@ def test_query_parsing_is_clean_under_asan_and_ubsan(built, tmp_path):
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
-    assert run.stdout.strip().startswith("parsed 95 rejected 9"), run.stdout
+    assert run.stdout.strip().startswith("parsed 98 rejected 9"), run.stdout

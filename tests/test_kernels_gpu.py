@@ -209,6 +209,51 @@ def test_batched_scan_matches_single_scans(built, n, alphabet):
                 assert np.array_equal(table, dense.mutation_counts(sym, mask, scan_symbols, 2, 17)), count
 
 
+@pytest.mark.parametrize("n,alphabet", [(70000, "aa"), (140000, "nuc"), (300001, "nuc")])
+def test_sparse_filters_take_the_gather_scan_and_give_the_same_tables(built, n, alphabet):
+    """K1s: filters with set bits in few 64-byte sectors are routed on the device to k_scan_gather; dense ones, and the filters just
+    past the capacity, stay with k_scan_sliced — same tables either way, alone and mixed in one batch."""
+    rng = np.random.default_rng(n + 11)
+    positions = 23
+    sym = random_symbols(rng, n, positions, alphabet)
+    chars = (NUC_CHARS if alphabet == "nuc" else AA_CHARS)[sym]
+    with make_store(n, [dict(name="s", alphabet=alphabet, reference=sym[0].copy())]) as store:
+        store.append_sequences(0, 0, chars)
+        store.finalize()
+        scan_symbols = list(store.scan_symbols[0])
+        capacity = max(4, store.row_words // 16)  # 64-byte sectors (8 words) of the filter with a set bit
+
+        def rows_in_sectors(n_sectors):
+            mask = np.zeros(n, bool)
+            sectors = rng.choice(n // 512, size=n_sectors, replace=False)
+            mask[sectors * 512 + rng.integers(0, 512, size=n_sectors)] = True
+            return mask
+
+        masks = [np.zeros(n, bool), rows_in_sectors(1), rows_in_sectors(7), rows_in_sectors(capacity), rows_in_sectors(capacity + 1),
+                 rng.random(n) < 0.4]
+        last = np.zeros(n, bool)
+        last[n - 1] = True  # the last row, in the ragged last word
+        masks.append(last)
+        clustered = np.zeros(n, bool)
+        clustered[n // 3: n // 3 + 500] = True
+        masks.append(clustered)
+        ptrs = []
+        for mask in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            ptrs.append(ptr)
+        want = [dense.mutation_counts(sym, mask, scan_symbols) for mask in masks]
+        for divisor in (0, -1):  # default routing, then the dense kernels alone
+            store.tune(3, divisor)
+            for ptr, table in zip(ptrs, want):
+                assert np.array_equal(store.mutations_scan(0, ptr), table), divisor
+            for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
+                assert np.array_equal(got, table), divisor
+            got = store.mutations_scan(0, ptrs[2], 2, 17)
+            assert np.array_equal(got, dense.mutation_counts(sym, masks[2], scan_symbols, 2, 17))
+        store.tune(3, 0)
+
+
 @pytest.mark.parametrize("n", [1, 64, 1000, 250007])
 def test_column_compare_matches_numpy(built, n):
     """K5: every comparator on int32 / uint32 / float64 columns, NULL markers and NaN included."""
