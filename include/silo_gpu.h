@@ -308,7 +308,10 @@ int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev);
  * one table, mutations.cpp:71,108); zero it with silo_gpu_memset_async before the first partition.
  * filter_dev == NULL means the full filter: like the reference, which then reads stored cardinalities
  * instead of intersecting (mutations.cpp:98-136), the totals of the unfiltered store are computed by one
- * scan on first use, kept on the device and added from then on (invalidated by append / generate). */
+ * scan on first use, kept on the device and added from then on (invalidated by append / generate).
+ * A filter whose set bits fall into few 64-byte sectors (<= row_words / 16 by default, SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR)
+ * is served by a gather over just those sectors of the planes (K1s) — decided on the device, same counts, so that the
+ * scan gets cheaper with the filter as roaring's and_cardinality does (mutations.cpp:139-164). */
 int silo_gpu_mutations_scan(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev,
    uint32_t pos_begin, uint32_t pos_end, uint32_t* counts_out_dev, void* stream
