@@ -316,6 +316,22 @@ int silo_gpu_mutations_scan(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev,
    uint32_t pos_begin, uint32_t pos_end, uint32_t* counts_out_dev, void* stream
 );
+/* K1 over several position ranges at once — the 12 genes of an AminoAcidMutations query, the segments of a segmented
+ * genome, the sequence stores of several batched queries: every filter is applied to every range;
+ * counts_out_dev[r * n_filters + q] is the table of filter q on range r, indexed from the range's first position and
+ * ACCUMULATED into.  Ranges over stores of the same alphabet share launches (blocks are dealt to the ranges), and the
+ * sparse-filter routing (K1s) looks at each filter once for all ranges.  Replaces the reference's loop over sequence
+ * names in Mutations::execute (mutations.cpp:258-271). */
+typedef struct silo_gpu_scan_range {
+   uint32_t seqstore_id;
+   uint32_t pos_begin;
+   uint32_t pos_end;
+} silo_gpu_scan_range;
+int silo_gpu_mutations_scan_ranges(
+   const silo_gpu_store* store, const silo_gpu_scan_range* ranges, uint32_t n_ranges, const uint64_t* const* filters_dev, uint32_t n_filters,
+   uint32_t* const* counts_out_dev, void* stream
+);
+
 /* The same scan for a batch of filters over one sequence store: every plane row is read once for up to
  * SILO_GPU_MAX_SCAN_BATCH filters per pass (larger batches take several passes), counts_out_dev[q] is
  * accumulated with filters_dev[q].  This is how concurrent Mutations queries share the HBM stream. */

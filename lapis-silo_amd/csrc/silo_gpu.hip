@@ -235,14 +235,23 @@ __device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
    }
 }
 
+constexpr uint32_t SCAN_MAX_RANGES = 16;
+
+/// One launch of the scan: up to SILO_GPU_MAX_SCAN_BATCH filters against up to SCAN_MAX_RANGES position ranges of
+/// sequence stores with the same layout (the 12 genes of an AminoAcidMutations query, the segments of a segmented
+/// genome): blocks (k_scan_sliced) or waves (k_scan_gather) are dealt to the ranges by first_unit.
 struct ScanBatchArgs {
    const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
-   uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
    // sparse-filter routing (K1s): sparse_sectors[q] = number of 64-byte sectors of filter q with a set bit, written by
    // k_compact_filter earlier on the same stream; a filter with at most sparse_capacity of them is served by
    // k_scan_gather and is treated as empty by k_scan_sliced.  nullptr = no routing.
    const uint32_t* sparse_sectors;
    uint32_t sparse_capacity;
+   uint32_t n_ranges;
+   const uint64_t* planes[SCAN_MAX_RANGES];    // first plane row of the range
+   uint32_t n_positions[SCAN_MAX_RANGES];
+   uint32_t first_unit[SCAN_MAX_RANGES + 1];   // prefix sums of the blocks / waves per range
+   uint32_t* counts[SCAN_MAX_RANGES][SILO_GPU_MAX_SCAN_BATCH];  // counts[range][filter], at the first position of the range
 };
 
 // positions whose partial counts sit in LDS between two flushes: ~16 KiB of LDS whatever NSYM * Q is
@@ -261,8 +270,7 @@ constexpr int scanMinBlocks() {
 
 template <int BITS, int NSYM, int WPT, int Q>
 __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void k_scan_sliced(
-   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, uint32_t row_words, uint32_t n_positions, uint32_t positions_per_block,
-   uint32_t n_tiles
+   const ScanBatchArgs batch, uint32_t row_words, uint32_t positions_per_block, uint32_t n_tiles
 ) {
    constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread and plane
    constexpr uint32_t TILE_WORDS = SCAN_THREADS * WPT;
@@ -272,8 +280,15 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
    const uint32_t tid = threadIdx.x;
    const uint32_t wave = tid >> 6;
    const bool writer = (tid & 63u) == 63u;  // waveSumToLane63 leaves the total in lane 63
-   const uint32_t tile = blockIdx.x % n_tiles;
-   const uint32_t position_group = blockIdx.x / n_tiles;
+   uint32_t range = 0;
+   while (range + 1 < batch.n_ranges && blockIdx.x >= batch.first_unit[range + 1]) {
+      ++range;
+   }
+   const uint32_t block_in_range = blockIdx.x - batch.first_unit[range];
+   const uint64_t* __restrict__ planes = batch.planes[range];
+   const uint32_t n_positions = batch.n_positions[range];
+   const uint32_t tile = block_in_range % n_tiles;
+   const uint32_t position_group = block_in_range / n_tiles;
    const uint32_t pos_begin = position_group * positions_per_block;
    const uint32_t pos_end = min(n_positions, pos_begin + positions_per_block);
    const uint32_t last_pos = pos_end - 1;
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             total += s_partial[buffer][w][position][rest];
          }
          if (total != 0) {
-            atomicAdd(&batch.counts[rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
+            atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
          }
       }
    };
@@ -516,9 +531,8 @@ __global__ __launch_bounds__(256) void k_compact_filter(
 // One WAVE per group of POSG consecutive positions (no LDS, no block-level reduction: a sparse filter may have fewer
 // non-zero words than a block has lanes); lanes stride over the words of the listed sectors, POSG * BITS gathers in flight each.
 template <int BITS, int NSYM, int POSG>
-__global__ __launch_bounds__(256) void k_scan_gather(
-   const uint64_t* __restrict__ planes, const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity,
-   uint32_t row_words, uint32_t n_positions
+__global__ __launch_bounds__(256, 5) void k_scan_gather(
+   const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity, uint32_t row_words
 ) {
    const uint32_t q = blockIdx.y;
    const uint32_t n_sectors = batch.sparse_sectors[q];
@@ -527,11 +541,17 @@ __global__ __launch_bounds__(256) void k_scan_gather(
    }
    const uint32_t n_words = n_sectors * SECTOR_WORDS;
    const uint32_t lane = threadIdx.x & 63u;
-   const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-   const uint32_t pos_begin = group * POSG;
-   if (pos_begin >= n_positions) {
+   const uint32_t unit = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // this wave
+   if (unit >= batch.first_unit[batch.n_ranges]) {
       return;
    }
+   uint32_t range = 0;
+   while (range + 1 < batch.n_ranges && unit >= batch.first_unit[range + 1]) {
+      ++range;
+   }
+   const uint64_t* __restrict__ planes = batch.planes[range];
+   const uint32_t n_positions = batch.n_positions[range];
+   const uint32_t pos_begin = (unit - batch.first_unit[range]) * POSG;
    const uint32_t last_pos = n_positions - 1;
    const uint32_t* index = sector_index + static_cast<size_t>(q) * capacity;
    const uint64_t* filter = batch.filters[q];
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(256) void k_scan_gather(
       for (int symbol = 0; symbol < NSYM; ++symbol) {
          const uint32_t total = waveSumToLane63(acc[g][symbol]);
          if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
-            atomicAdd(&batch.counts[q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
+            atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
          }
       }
    }
@@ -1586,16 +1606,17 @@ void silo_gpu_free(void* dev_ptr) {
 
 namespace {
 
-/// Launches k_scan_sliced for `q_count` filters (1..SILO_GPU_MAX_SCAN_BATCH) over positions [pos_begin, pos_end).
+/// A position range of one sequence store with the count tables of every filter of the launch.
+struct ScanRange {
+   const SeqStoreDev* dev;
+   uint32_t pos_begin;
+   uint32_t pos_end;
+   uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
+};
+
+/// Launches k_scan_sliced for the `q_count` filters and the ranges already entered in `batch` (planes, n_positions, counts).
 template <int BITS, int NSYM>
-int launchSlicedScan(
-   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
-   hipStream_t hip_stream
-) {
-   const uint32_t row_words = dev.row_words;
-   const uint32_t n_positions = pos_end - pos_begin;
-   const uint64_t* planes = scanPlanes(dev, pos_begin);
-   (void)store;
+int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
    // words per thread: 8 for one nucleotide filter (3 planes x 4 chunks per position and buffer), 4 otherwise (amino
    // acids: 5 planes; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
    const int variant = g_tune_scan_variant.load();
@@ -1609,15 +1630,23 @@ int launchSlicedScan(
    const uint32_t tile_words = SCAN_THREADS * (medium ? 6 : (wide ? 8 : 4));
    int positions_per_block = g_tune_rows_per_block.load();
    const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
+   uint64_t total_positions = 0;
+   for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+      total_positions += batch.n_positions[r];
+   }
    if (positions_per_block <= 0) {
       // nucleotides: 128 positions (384 plane rows) per block while that still leaves >= 4096 blocks, else 64; amino
       // acids 12 (60 plane rows) — profiles/r01_scan_variants.md
-      positions_per_block = BITS <= 3 ? (static_cast<uint64_t>(n_tiles) * ((n_positions + 127) / 128) >= 4096 ? 128 : 64) : 12;
+      positions_per_block = BITS <= 3 ? (static_cast<uint64_t>(n_tiles) * ((total_positions + 127) / 128) >= 4096 ? 128 : 64) : 12;
    }
    positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
-   const dim3 grid(n_tiles * ((n_positions + positions_per_block - 1) / positions_per_block));
+   batch.first_unit[0] = 0;
+   for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+      batch.first_unit[r + 1] = batch.first_unit[r] + n_tiles * ((batch.n_positions[r] + positions_per_block - 1) / positions_per_block);
+   }
+   const dim3 grid(batch.first_unit[batch.n_ranges]);
 #define SILO_LAUNCH_SLICED(WPT, Q) \
-   k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(planes, batch, row_words, n_positions, positions_per_block, n_tiles)
+   k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
    if (medium) {
       if constexpr (BITS <= 3) {
          SILO_LAUNCH_SLICED(6, 1);
@@ -1646,6 +1675,19 @@ int launchSlicedScan(
       }
    }
 #undef SILO_LAUNCH_SLICED
+   HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+/// Launches k_scan_gather (one wave per POSG positions) for the ranges in `batch`; grid.y = filter.
+template <int BITS, int NSYM, int POSG>
+int launchGatherScan(ScanBatchArgs& batch, const uint32_t* sector_index, uint32_t stride, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
+   batch.first_unit[0] = 0;
+   for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+      batch.first_unit[r + 1] = batch.first_unit[r] + (batch.n_positions[r] + POSG - 1) / POSG;
+   }
+   const uint32_t waves = batch.first_unit[batch.n_ranges];
+   k_scan_gather<BITS, NSYM, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(batch, sector_index, stride, row_words);
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }
@@ -1702,23 +1744,72 @@ void releaseSparseScratch(SparseScratch* block, hipStream_t stream) {
    block->in_flight = false;
 }
 
-/// Scan for up to SILO_GPU_MAX_SCAN_BATCH filters in one pass; dispatches on the layout of the sequence store.
-int slicedScanDense(
-   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
-   hipStream_t hip_stream
+
+/// The dense kernels for `q_count` filters over `ranges` (all of one layout), at most SCAN_MAX_RANGES ranges and — for
+/// amino acids — 4 filters per launch.  `routing` carries the sparse-filter counters (or nullptr).
+int scanRangesDense(
+   const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, const uint32_t* sparse_sectors,
+   uint32_t sparse_capacity, hipStream_t hip_stream
 ) {
-   if (dev.row_words < SCAN_THREADS * 4) {
-      // short rows: one wave per position, one filter at a time
-      const uint32_t n_positions = pos_end - pos_begin;
-      const uint32_t waves = std::min<uint32_t>(n_positions, 256u * 32u);
-      const uint32_t blocks = (waves + 3) / 4;
-      for (uint32_t q = 0; q < q_count; ++q) {
-         if (dev.n_bits == 3 && dev.n_scan == 5) {
-            k_scan_sliced_rowwave<3, 5><<<blocks, 256, 0, hip_stream>>>(scanPlanes(dev, pos_begin), batch.filters[q], batch.counts[q], dev.row_words, n_positions);
-         } else if (dev.n_bits == 5 && dev.n_scan == 22) {
-            k_scan_sliced_rowwave<5, 22><<<blocks, 256, 0, hip_stream>>>(scanPlanes(dev, pos_begin), batch.filters[q], batch.counts[q], dev.row_words, n_positions);
-         } else {
-            return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
+   const SeqStoreDev& layout = *ranges.front().dev;
+   const uint32_t filters_per_pass = layout.n_bits == 3 ? SILO_GPU_MAX_SCAN_BATCH : 4;
+   for (size_t first_range = 0; first_range < ranges.size(); first_range += SCAN_MAX_RANGES) {
+      const uint32_t n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, ranges.size() - first_range));
+      for (uint32_t first = 0; first < q_count; first += filters_per_pass) {
+         const uint32_t n = std::min<uint32_t>(filters_per_pass, q_count - first);
+         ScanBatchArgs batch{};
+         batch.n_ranges = n_ranges;
+         batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first : nullptr;
+         batch.sparse_capacity = sparse_capacity;
+         for (uint32_t q = 0; q < n; ++q) {
+            batch.filters[q] = filters[first + q];
+         }
+         for (uint32_t r = 0; r < n_ranges; ++r) {
+            const ScanRange& range = ranges[first_range + r];
+            batch.planes[r] = scanPlanes(*range.dev, range.pos_begin);
+            batch.n_positions[r] = range.pos_end - range.pos_begin;
+            for (uint32_t q = 0; q < n; ++q) {
+               batch.counts[r][q] = range.counts[first + q];
+            }
+         }
+         const int rc = layout.n_bits == 3 ? launchSlicedScan<3, 5>(batch, layout.row_words, n, hip_stream)
+                                           : launchSlicedScan<5, 22>(batch, layout.row_words, n, hip_stream);
+         if (rc != SILO_GPU_OK) {
+            return rc;
+         }
+      }
+   }
+   return SILO_GPU_OK;
+}
+
+/// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores with one layout (all
+/// nucleotide or all amino-acid), with the sparse-filter routing (K1s) around the dense kernels: every filter is
+/// compacted ONCE for all ranges, the dense kernels skip the sparse ones, the gather kernel serves them.  All
+/// decisions are taken on the device.
+int scanRanges(
+   const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream
+) {
+   const SeqStoreDev& layout = *ranges.front().dev;
+   const bool nucleotide = layout.n_bits == 3 && layout.n_scan == 5;
+   if (!nucleotide && !(layout.n_bits == 5 && layout.n_scan == 22)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
+   }
+   if (layout.row_words < SCAN_THREADS * 4) {
+      // short rows: one wave per position, one filter and one range at a time
+      for (const ScanRange& range : ranges) {
+         const uint32_t n_positions = range.pos_end - range.pos_begin;
+         const uint32_t waves = std::min<uint32_t>(n_positions, 256u * 32u);
+         const uint32_t blocks = (waves + 3) / 4;
+         for (uint32_t q = 0; q < q_count; ++q) {
+            if (nucleotide) {
+               k_scan_sliced_rowwave<3, 5><<<blocks, 256, 0, hip_stream>>>(
+                  scanPlanes(*range.dev, range.pos_begin), filters[q], range.counts[q], layout.row_words, n_positions
+               );
+            } else {
+               k_scan_sliced_rowwave<5, 22><<<blocks, 256, 0, hip_stream>>>(
+                  scanPlanes(*range.dev, range.pos_begin), filters[q], range.counts[q], layout.row_words, n_positions
+               );
+            }
          }
       }
       HIP_TRY(hipGetLastError());
@@ -1726,78 +1817,48 @@ int slicedScanDense(
       return SILO_GPU_OK;
    }
    g_last_scan_kernel = q_count == 1 ? "k_scan_sliced" : "k_scan_sliced_batch";
-   if (dev.n_bits == 3 && dev.n_scan == 5) {
-      return launchSlicedScan<3, 5>(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
-   }
-   if (dev.n_bits == 5 && dev.n_scan == 22) {
-      for (uint32_t first = 0; first < q_count; first += 4) {  // amino acids: at most 4 filters per pass
-         ScanBatchArgs part{};
-         const uint32_t n = std::min<uint32_t>(4, q_count - first);
-         for (uint32_t q = 0; q < n; ++q) {
-            part.filters[q] = batch.filters[first + q];
-            part.counts[q] = batch.counts[first + q];
-         }
-         part.sparse_sectors = batch.sparse_sectors != nullptr ? batch.sparse_sectors + first : nullptr;
-         part.sparse_capacity = batch.sparse_capacity;
-         const int rc = launchSlicedScan<5, 22>(store, dev, part, n, pos_begin, pos_end, hip_stream);
-         if (rc != SILO_GPU_OK) {
-            return rc;
-         }
-      }
-      return SILO_GPU_OK;
-   }
-   return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
-}
-
-/// The scan with sparse-filter routing (K1s) around the dense kernels: compact every filter, let the dense kernels
-/// skip the sparse ones, and serve those with the gather kernel.  All decisions are taken on the device.
-int slicedScan(
-   const silo_gpu_store* store, const SeqStoreDev& dev, const ScanBatchArgs& batch_in, uint32_t q_count, uint32_t pos_begin, uint32_t pos_end,
-   hipStream_t hip_stream
-) {
    const int divisor = g_tune_sparse_divisor.load();
-   const bool layout_known = (dev.n_bits == 3 && dev.n_scan == 5) || (dev.n_bits == 5 && dev.n_scan == 22);
-   if (divisor < 0 || dev.row_words < SCAN_THREADS * 4 || !layout_known) {
-      return slicedScanDense(store, dev, batch_in, q_count, pos_begin, pos_end, hip_stream);
+   if (divisor < 0) {
+      return scanRangesDense(ranges, filters, q_count, nullptr, 0, hip_stream);
    }
-   const uint32_t capacity = std::max<uint32_t>(4, dev.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
+   const uint32_t capacity = std::max<uint32_t>(4, layout.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
    const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
    if (acquired != SILO_GPU_OK) {
       return acquired;
    }
-   ScanBatchArgs batch = batch_in;
-   batch.sparse_sectors = scratch->sparse_sectors;
-   batch.sparse_capacity = capacity;
-   int rc = SILO_GPU_OK;
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
+   int rc = SILO_GPU_OK;
    if (hipMemsetAsync(scratch->sparse_sectors, 0, SILO_GPU_MAX_SCAN_BATCH * sizeof(uint32_t), hip_stream) != hipSuccess) {
       rc = fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipMemsetAsync failed");
    } else {
-      k_compact_filter<<<dim3((dev.row_words + 255) / 256, q_count), 256, 0, hip_stream>>>(
-         batch, dev.row_words, stride, scratch->sparse_sectors, scratch->sector_index
+      ScanBatchArgs compact{};
+      for (uint32_t q = 0; q < q_count; ++q) {
+         compact.filters[q] = filters[q];
+      }
+      k_compact_filter<<<dim3((layout.row_words + 255) / 256, q_count), 256, 0, hip_stream>>>(
+         compact, layout.row_words, stride, scratch->sparse_sectors, scratch->sector_index
       );
-      rc = slicedScanDense(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
+      rc = scanRangesDense(ranges, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
    }
-   if (rc == SILO_GPU_OK) {
-      const uint32_t n_positions = pos_end - pos_begin;
-      const ScanBatchArgs& gather = batch;
-      if (dev.n_bits == 3) {
-         constexpr int POSG = 4;
-         const uint32_t waves = (n_positions + POSG - 1) / POSG;
-         k_scan_gather<3, 5, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(
-            scanPlanes(dev, pos_begin), gather, scratch->sector_index, stride, dev.row_words, n_positions
-         );
-      } else {
-         constexpr int POSG = 2;
-         const uint32_t waves = (n_positions + POSG - 1) / POSG;
-         k_scan_gather<5, 22, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(
-            scanPlanes(dev, pos_begin), gather, scratch->sector_index, stride, dev.row_words, n_positions
-         );
+   for (size_t first_range = 0; rc == SILO_GPU_OK && first_range < ranges.size(); first_range += SCAN_MAX_RANGES) {
+      ScanBatchArgs batch{};
+      batch.n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, ranges.size() - first_range));
+      batch.sparse_sectors = scratch->sparse_sectors;
+      batch.sparse_capacity = capacity;
+      for (uint32_t q = 0; q < q_count; ++q) {
+         batch.filters[q] = filters[q];
       }
-      if (hipGetLastError() != hipSuccess) {
-         rc = fail(SILO_GPU_ERR_HIP, "k_scan_gather: launch failed");
+      for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+         const ScanRange& range = ranges[first_range + r];
+         batch.planes[r] = scanPlanes(*range.dev, range.pos_begin);
+         batch.n_positions[r] = range.pos_end - range.pos_begin;
+         for (uint32_t q = 0; q < q_count; ++q) {
+            batch.counts[r][q] = range.counts[q];
+         }
       }
+      rc = nucleotide ? launchGatherScan<3, 5, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
+                      : launchGatherScan<5, 22, 2>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream);
    }
    releaseSparseScratch(scratch, hip_stream);
    return rc;
@@ -1807,6 +1868,65 @@ int slicedScan(
 
 extern "C" {
 
+int silo_gpu_mutations_scan_ranges(
+   const silo_gpu_store* store, const silo_gpu_scan_range* ranges, uint32_t n_ranges, const uint64_t* const* filters_dev, uint32_t n_filters,
+   uint32_t* const* counts_out_dev, void* stream
+) {
+   if (store == nullptr || (n_ranges != 0 && ranges == nullptr) || (n_filters != 0 && filters_dev == nullptr) ||
+       (n_ranges != 0 && n_filters != 0 && counts_out_dev == nullptr)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_ranges: bad arguments");
+   }
+   for (uint32_t q = 0; q < n_filters; ++q) {
+      if (filters_dev[q] == nullptr) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_ranges: null filter");
+      }
+   }
+   for (uint32_t r = 0; r < n_ranges; ++r) {
+      if (ranges[r].seqstore_id >= store->seqstores.size()) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_ranges: no such sequence store");
+      }
+      const SeqStoreDev& dev = store->seqstores[ranges[r].seqstore_id].dev;
+      if (ranges[r].pos_begin > ranges[r].pos_end || ranges[r].pos_end > dev.positions) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");
+      }
+      for (uint32_t q = 0; q < n_filters; ++q) {
+         if (counts_out_dev[static_cast<size_t>(r) * n_filters + q] == nullptr) {
+            return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_ranges: null counts buffer");
+         }
+      }
+   }
+   if (n_ranges == 0 || n_filters == 0) {
+      return SILO_GPU_OK;
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   for (uint32_t first = 0; first < n_filters; first += SILO_GPU_MAX_SCAN_BATCH) {
+      const uint32_t q_count = std::min<uint32_t>(SILO_GPU_MAX_SCAN_BATCH, n_filters - first);
+      // ranges of one layout (3 code planes / 5 code planes) share launches
+      for (const uint32_t n_bits : {3u, 5u}) {
+         std::vector<ScanRange> group;
+         for (uint32_t r = 0; r < n_ranges; ++r) {
+            const SeqStoreDev& dev = store->seqstores[ranges[r].seqstore_id].dev;
+            if (ranges[r].pos_begin == ranges[r].pos_end || dev.n_scan == 0 || (dev.n_bits == 3 ? 3u : 5u) != n_bits) {
+               continue;
+            }
+            ScanRange range{&dev, ranges[r].pos_begin, ranges[r].pos_end, {}};
+            for (uint32_t q = 0; q < q_count; ++q) {
+               range.counts[q] = counts_out_dev[static_cast<size_t>(r) * n_filters + first + q];
+            }
+            group.push_back(range);
+         }
+         if (!group.empty()) {
+            const int rc = scanRanges(store, group, filters_dev + first, q_count, hip_stream);
+            if (rc != SILO_GPU_OK) {
+               return rc;
+            }
+         }
+      }
+   }
+   return SILO_GPU_OK;
+}
+
 int silo_gpu_mutations_scan_batch(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* const* filters_dev, uint32_t n_filters, uint32_t pos_begin,
    uint32_t pos_end, uint32_t* const* counts_out_dev, void* stream
@@ -1814,33 +1934,8 @@ int silo_gpu_mutations_scan_batch(
    if (store == nullptr || seqstore_id >= store->seqstores.size() || filters_dev == nullptr || counts_out_dev == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_batch: bad arguments");
    }
-   for (uint32_t q = 0; q < n_filters; ++q) {
-      if (filters_dev[q] == nullptr || counts_out_dev[q] == nullptr) {
-         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_batch: null filter or counts buffer");
-      }
-   }
-   const SeqStoreDev& dev = store->seqstores[seqstore_id].dev;
-   if (pos_begin > pos_end || pos_end > dev.positions) {
-      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "position range out of bounds");
-   }
-   if (pos_begin == pos_end || dev.n_scan == 0 || n_filters == 0) {
-      return SILO_GPU_OK;
-   }
-   HIP_TRY(hipSetDevice(store->device));
-   auto hip_stream = static_cast<hipStream_t>(stream);
-   for (uint32_t first = 0; first < n_filters; first += SILO_GPU_MAX_SCAN_BATCH) {
-      const uint32_t q_count = std::min<uint32_t>(SILO_GPU_MAX_SCAN_BATCH, n_filters - first);
-      ScanBatchArgs batch{};
-      for (uint32_t q = 0; q < q_count; ++q) {
-         batch.filters[q] = filters_dev[first + q];
-         batch.counts[q] = counts_out_dev[first + q];
-      }
-      const int rc = slicedScan(store, dev, batch, q_count, pos_begin, pos_end, hip_stream);
-      if (rc != SILO_GPU_OK) {
-         return rc;
-      }
-   }
-   return SILO_GPU_OK;
+   const silo_gpu_scan_range range{seqstore_id, pos_begin, pos_end};
+   return silo_gpu_mutations_scan_ranges(store, &range, 1, filters_dev, n_filters, counts_out_dev, stream);
 }
 
 int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) {
@@ -2348,10 +2443,8 @@ int silo_gpu_mutations_scan(
       g_last_scan_kernel = "k_add_u32 (cached totals)";
       return SILO_GPU_OK;
    }
-   ScanBatchArgs batch{};
-   batch.filters[0] = filter_dev;
-   batch.counts[0] = counts_out_dev;
-   return slicedScan(store, dev, batch, 1, pos_begin, pos_end, static_cast<hipStream_t>(stream));
+   const silo_gpu_scan_range range{seqstore_id, pos_begin, pos_end};
+   return silo_gpu_mutations_scan_ranges(store, &range, 1, &filter_dev, 1, &counts_out_dev, stream);
 }
 
 int silo_gpu_reconstruct_sequences(

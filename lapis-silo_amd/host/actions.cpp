@@ -135,41 +135,75 @@ ScanBatcher* ScanBatcher::active() {
 }
 
 void ScanBatcher::flush() {
-   // requests over the same planes (store, sequence store, position range) share passes
-   std::vector<bool> done(requests.size(), false);
-   for (size_t i = 0; i < requests.size(); ++i) {
+   // Per (store, filter) the position ranges it is to be scanned over, in recording order; filters with the same list
+   // of ranges — the queries of a batch that ask for the same sequence stores — share one multi-range call, in which
+   // the planes of every range are streamed once for all of them (K1c) and every filter is looked at once (K1s).
+   struct FilterScans {
+      silo_gpu_store* store;
+      const uint64_t* filter;
+      std::vector<silo_gpu_scan_range> ranges;
+      std::vector<uint32_t*> counts;
+   };
+   const auto same_range = [](const silo_gpu_scan_range& a, const silo_gpu_scan_range& b) {
+      return a.seqstore_id == b.seqstore_id && a.pos_begin == b.pos_begin && a.pos_end == b.pos_end;
+   };
+   std::vector<FilterScans> by_filter;
+   for (const Request& request : requests) {
+      if (request.filter == nullptr) {  // full filter: cached totals, no pass over the planes
+         checkGpu(
+            silo_gpu_mutations_scan(request.store, request.seqstore_id, nullptr, request.pos_begin, request.pos_end, request.counts, queryStream()),
+            "silo_gpu_mutations_scan"
+         );
+         continue;
+      }
+      const silo_gpu_scan_range range{request.seqstore_id, request.pos_begin, request.pos_end};
+      FilterScans* entry = nullptr;
+      for (FilterScans& candidate : by_filter) {
+         if (candidate.store == request.store && candidate.filter == request.filter &&
+             std::none_of(candidate.ranges.begin(), candidate.ranges.end(), [&](const auto& other) { return same_range(other, range); })) {
+            entry = &candidate;
+            break;
+         }
+      }
+      if (entry == nullptr) {
+         by_filter.push_back({request.store, request.filter, {}, {}});
+         entry = &by_filter.back();
+      }
+      entry->ranges.push_back(range);
+      entry->counts.push_back(request.counts);
+   }
+   std::vector<bool> done(by_filter.size(), false);
+   for (size_t i = 0; i < by_filter.size(); ++i) {
       if (done[i]) {
          continue;
       }
-      const Request& first = requests[i];
+      const FilterScans& first = by_filter[i];
+      std::vector<size_t> group;
+      for (size_t k = i; k < by_filter.size(); ++k) {
+         const FilterScans& other = by_filter[k];
+         if (!done[k] && other.store == first.store && other.ranges.size() == first.ranges.size() &&
+             std::equal(other.ranges.begin(), other.ranges.end(), first.ranges.begin(), same_range)) {
+            done[k] = true;
+            group.push_back(k);
+         }
+      }
       std::vector<const uint64_t*> filters;
-      std::vector<uint32_t*> counts;
-      for (size_t k = i; k < requests.size(); ++k) {
-         const Request& other = requests[k];
-         if (done[k] || other.store != first.store || other.seqstore_id != first.seqstore_id || other.pos_begin != first.pos_begin ||
-             other.pos_end != first.pos_end) {
-            continue;
-         }
-         done[k] = true;
-         if (other.filter == nullptr) {  // full filter: cached totals, no pass over the planes
-            checkGpu(
-               silo_gpu_mutations_scan(other.store, other.seqstore_id, nullptr, other.pos_begin, other.pos_end, other.counts, queryStream()),
-               "silo_gpu_mutations_scan"
-            );
-         } else {
-            filters.push_back(other.filter);
-            counts.push_back(other.counts);
+      for (const size_t k : group) {
+         filters.push_back(by_filter[k].filter);
+      }
+      std::vector<uint32_t*> counts;  // [range][filter]
+      for (size_t r = 0; r < first.ranges.size(); ++r) {
+         for (const size_t k : group) {
+            counts.push_back(by_filter[k].counts[r]);
          }
       }
-      if (!filters.empty()) {
-         checkGpu(
-            silo_gpu_mutations_scan_batch(
-               first.store, first.seqstore_id, filters.data(), static_cast<uint32_t>(filters.size()), first.pos_begin, first.pos_end,
-               counts.data(), queryStream()
-            ),
-            "silo_gpu_mutations_scan_batch"
-         );
-      }
+      checkGpu(
+         silo_gpu_mutations_scan_ranges(
+            first.store, first.ranges.data(), static_cast<uint32_t>(first.ranges.size()), filters.data(), static_cast<uint32_t>(filters.size()),
+            counts.data(), queryStream()
+         ),
+         "silo_gpu_mutations_scan_ranges"
+      );
    }
    requests.clear();
    for (const Reduction& reduction : reductions) {
@@ -385,6 +419,11 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
 
    const PrefilteredBitmaps no_bitmaps{};
    std::vector<std::string> scanned;  // a store requested twice is scanned once
+   // a query on its own still records its scans — one per sequence store — so that they leave as ONE multi-range call
+   std::optional<ScanBatcher> own_batcher;
+   if (ScanBatcher::active() == nullptr) {
+      own_batcher.emplace();
+   }
    try {
    for (const auto& sequence_name : pending->sequence_names) {
       if (std::find(scanned.begin(), scanned.end(), sequence_name) != scanned.end()) {
@@ -417,14 +456,13 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
       );
       scans.fetch = HostFetch(list, 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(scans.row_capacity), queryStream());
    };
-   if (ScanBatcher* batcher = ScanBatcher::active(); batcher != nullptr) {
-      if (database.all_reduce != nullptr) {
-         batcher->addReduction(database, device_counts, n_counts);
-      }
-      batcher->afterFlush(select_and_fetch);  // the scans are only recorded so far
-   } else {
-      allReduce(database, device_counts, n_counts);  // the whole query in one collective
-      select_and_fetch();
+   ScanBatcher* batcher = ScanBatcher::active();
+   if (database.all_reduce != nullptr) {
+      batcher->addReduction(database, device_counts, n_counts);  // the whole query in one collective
+   }
+   batcher->afterFlush(select_and_fetch);  // the scans are only recorded so far
+   if (own_batcher) {
+      own_batcher->flush();
    }
    } catch (...) {
       // launches of this query may be in flight on the stream: let them finish before its buffers return to the pool

@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
-    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
 ]
@@ -136,6 +136,7 @@ def load_library():
     lib.silo_gpu_popcount.argtypes = [vp, vp, vp, vp]
     lib.silo_gpu_mutations_scan.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
     lib.silo_gpu_mutations_scan_batch.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), vp]
+    lib.silo_gpu_mutations_scan_ranges.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(vp), ctypes.c_uint32, ctypes.POINTER(vp), vp]
     lib.silo_gpu_memset_async.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
     lib.silo_gpu_upload_column.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
     lib.silo_gpu_bitset_from_compare.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
@@ -431,6 +432,29 @@ class GpuStore:
         counts = (ctypes.c_void_p * len(outs))(*[o.value for o in outs])
         _check(self.lib.silo_gpu_mutations_scan_batch(self.handle, seqstore_id, filters, len(filter_ptrs), pos_begin, pos_end, counts, stream))
         tables = [self.read(o, np.uint32, n, stream).reshape(pos_end - pos_begin, n_scan) for o in outs]
+        for o in outs:
+            self.free(o)
+        return tables
+
+    def mutations_scan_ranges(self, ranges, filter_ptrs, stream=None):
+        """Every filter over every (seqstore_id, pos_begin, pos_end) range in as few launches as the layouts allow;
+        returns tables[range][filter]."""
+        flat = (ctypes.c_uint32 * (3 * len(ranges)))(*[int(v) for r in ranges for v in r])  # silo_gpu_scan_range[]
+        outs = []
+        for seqstore_id, pos_begin, pos_end in ranges:
+            n = (pos_end - pos_begin) * len(self.scan_symbols[seqstore_id])
+            for _ in filter_ptrs:
+                buf = self.malloc(max(4, 4 * n))
+                self.memset(buf, 0, max(4, 4 * n), stream)
+                outs.append(buf)
+        filters = (ctypes.c_void_p * len(filter_ptrs))(*[(f.value if isinstance(f, ctypes.c_void_p) else f) for f in filter_ptrs])
+        counts = (ctypes.c_void_p * max(1, len(outs)))(*[o.value for o in outs])
+        _check(self.lib.silo_gpu_mutations_scan_ranges(self.handle, flat, len(ranges), filters, len(filter_ptrs), counts, stream))
+        tables = []
+        for r, (seqstore_id, pos_begin, pos_end) in enumerate(ranges):
+            n_scan = len(self.scan_symbols[seqstore_id])
+            tables.append([self.read(outs[r * len(filter_ptrs) + q], np.uint32, (pos_end - pos_begin) * n_scan, stream).reshape(pos_end - pos_begin, n_scan)
+                           for q in range(len(filter_ptrs))])
         for o in outs:
             self.free(o)
         return tables

@@ -254,6 +254,38 @@ def test_sparse_filters_take_the_gather_scan_and_give_the_same_tables(built, n, 
         store.tune(3, 0)
 
 
+@pytest.mark.parametrize("n", [900, 140000])
+def test_scan_over_several_ranges_in_one_call(built, n):
+    """silo_gpu_mutations_scan_ranges: every filter over ranges of nucleotide and amino-acid stores of different lengths
+    (more than 16 ranges, so more than one launch per layout), dense and sparse filters mixed."""
+    rng = np.random.default_rng(n + 13)
+    lengths = [("nuc", 23), ("aa", 7), ("nuc", 40), ("aa", 31)] + [("aa", 3 + i) for i in range(17)]
+    syms = [random_symbols(rng, n, positions, alphabet) for alphabet, positions in lengths]
+    stores = [dict(name=f"s{i}", alphabet=alphabet, reference=sym[0].copy()) for i, ((alphabet, _), sym) in enumerate(zip(lengths, syms))]
+    with make_store(n, stores) as store:
+        for i, ((alphabet, _), sym) in enumerate(zip(lengths, syms)):
+            store.append_sequences(i, 0, (NUC_CHARS if alphabet == "nuc" else AA_CHARS)[sym])
+        store.finalize()
+        sparse = np.zeros(n, bool)
+        sparse[rng.choice(n, size=5, replace=False)] = True
+        masks = [rng.random(n) < 0.3, sparse, rng.random(n) < 0.8, np.zeros(n, bool), sparse | (rng.random(n) < 0.001)]
+        ptrs = []
+        for mask in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            ptrs.append(ptr)
+        ranges = [(i, 0, positions) for i, (_, positions) in enumerate(lengths)]
+        ranges[0] = (0, 2, 17)
+        ranges[3] = (3, 30, 31)
+        ranges.append((2, 5, 5))  # empty
+        for n_filters in (1, 3, 5):
+            tables = store.mutations_scan_ranges(ranges, ptrs[:n_filters])
+            for (seqstore_id, pos_begin, pos_end), per_filter in zip(ranges, tables):
+                for mask, table in zip(masks, per_filter):
+                    want = dense.mutation_counts(syms[seqstore_id], mask, list(store.scan_symbols[seqstore_id]), pos_begin, pos_end)
+                    assert np.array_equal(table, want), (seqstore_id, n_filters)
+
+
 @pytest.mark.parametrize("n", [1, 64, 1000, 250007])
 def test_column_compare_matches_numpy(built, n):
     """K5: every comparator on int32 / uint32 / float64 columns, NULL markers and NaN included."""
