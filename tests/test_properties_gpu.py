@@ -73,6 +73,44 @@ def test_linearity_complement_and_conservation(big):
     assert np.array_equal(np.concatenate(parts), c1)
 
 
+def test_sparse_filter_routing_changes_nothing(big):
+    """K1s at a size where the gather really runs (row_words 46 880, capacity 2 930 sectors): single small lineages
+    with the routing on and off, additivity over disjoint small filters, and the filter at either side of the capacity."""
+    store, tree, lineage = big
+    sizes = np.bincount(lineage, minlength=L)
+    smallest = [int(i) for i in np.argsort(sizes) if sizes[i] > 0][:3]
+    tables = []
+    for index in smallest:
+        member = np.zeros(L, dtype=np.uint8)
+        member[index] = 1
+        ptr = store.bitset_alloc()
+        store.bitset_from_lineages(ptr, member)
+        routed = store.mutations_scan(0, ptr)
+        store.tune(3, -1)
+        dense_only = store.mutations_scan(0, ptr)
+        store.tune(3, 0)
+        assert np.array_equal(routed, dense_only)
+        assert int(routed.sum(axis=1).max()) <= int(sizes[index])
+        tables.append(routed.astype(np.int64))
+    member = np.zeros(L, dtype=np.uint8)
+    member[smallest] = 1
+    union = store.bitset_alloc()
+    store.bitset_from_lineages(union, member)
+    assert np.array_equal(store.mutations_scan(0, union), tables[0] + tables[1] + tables[2])
+    # rows spread over exactly `capacity` and `capacity + 1` sectors: last routed filter, first dense one
+    capacity = store.row_words // 16
+    for n_sectors in (capacity, capacity + 1):
+        words = np.zeros(store.row_words, dtype=np.uint64)
+        words[np.arange(n_sectors) * 8 * (store.row_words // 8 // n_sectors) + 3] = np.uint64(1) << np.uint64(17)
+        ptr = store.bitset_alloc()
+        store.bitset_upload(ptr, words)
+        routed = store.mutations_scan(0, ptr)
+        store.tune(3, -1)
+        dense_only = store.mutations_scan(0, ptr)
+        store.tune(3, 0)
+        assert np.array_equal(routed, dense_only) and int(routed.sum(axis=1).max()) <= n_sectors
+
+
 def test_empty_database_and_empty_partition(built):
     from silo_amd.engine import Engine
 
