@@ -379,6 +379,8 @@ def main():
     ap.add_argument("--sequences", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
+    ap.add_argument("--no-client-threads", action="store_true",
+                    help="skip the config-2 filter-query leg (8 client threads): rocprofv3's kernel tracing segfaults inside hipStreamQuery when several host threads poll their streams")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed / RCCL path even with one rank (testing)")
     ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     args = ap.parse_args()
@@ -418,19 +420,33 @@ def main():
 
         aliases = {}  # (device pointer, length) -> tensor aliasing it: the engine's pool hands the same buffer out every step
 
-        def all_reduce(device_ptr, n, _stream):
+        streams = {}  # the engine's HIP stream handle -> torch view of it
+
+        def on_engine_stream(stream):
+            """The collective is issued with the engine's own stream as torch's current stream, so that RCCL's
+            stream waits for the scan kernels on it and the engine's next kernel waits for the collective."""
+            if not stream:
+                return torch.cuda.stream(torch.cuda.default_stream(local_rank))
+            view = streams.get(stream)
+            if view is None:
+                view = streams[stream] = torch.cuda.ExternalStream(stream, device=torch.device("cuda", local_rank))
+            return torch.cuda.stream(view)
+
+        def all_reduce(device_ptr, n, stream):
             tensor = aliases.get((device_ptr, n))
             if tensor is None:
                 tensor = aliases[(device_ptr, n)] = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
-            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI; ordered after the scan on the null stream
+            with on_engine_stream(stream):
+                dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI
 
         class DeviceBytes:
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-        def broadcast(device_ptr, nbytes, root, _stream):
+        def broadcast(device_ptr, nbytes, root, stream):
             tensor = torch.as_tensor(DeviceBytes(device_ptr, nbytes), device=torch.device("cuda", local_rank))
-            dist.broadcast(tensor, src=root)  # a filter leaf travelling from the rank that owns its position
+            with on_engine_stream(stream):
+                dist.broadcast(tensor, src=root)  # a filter leaf travelling from the rank that owns its position
 
         build_engine.broadcast = broadcast
 
@@ -530,7 +546,8 @@ def main():
         except Exception as error:  # the baseline is informational; a failure to build it must not hide the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
     if rank == 0 and world == 1 and not use_dist and not args.no_also:
-        result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
+        if not args.no_client_threads:
+            result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
         result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)
         result["selective_queries"] = selective_workload(engine, lib, tree, lineage, positions, args.sequences, sync)
     lib.silo_gpu_free(filt)

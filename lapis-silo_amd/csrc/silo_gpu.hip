@@ -236,13 +236,16 @@ __device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
 }
 
 constexpr uint32_t SCAN_MAX_RANGES = 16;
+// the per-filter sector counters sit 256 bytes apart: atomics on one L2 channel serialise (~12 ns each), and a dense
+// filter makes every block add to its counter
+constexpr uint32_t SPARSE_COUNTER_STRIDE = 64;
 
 /// One launch of the scan: up to SILO_GPU_MAX_SCAN_BATCH filters against up to SCAN_MAX_RANGES position ranges of
 /// sequence stores with the same layout (the 12 genes of an AminoAcidMutations query, the segments of a segmented
 /// genome): blocks (k_scan_sliced) or waves (k_scan_gather) are dealt to the ranges by first_unit.
 struct ScanBatchArgs {
    const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
-   // sparse-filter routing (K1s): sparse_sectors[q] = number of 64-byte sectors of filter q with a set bit, written by
+   // sparse-filter routing (K1s): sparse_sectors[q * SPARSE_COUNTER_STRIDE] = number of 64-byte sectors of filter q with a set bit, written by
    // k_compact_filter earlier on the same stream; a filter with at most sparse_capacity of them is served by
    // k_scan_gather and is treated as empty by k_scan_sliced.  nullptr = no routing.
    const uint32_t* sparse_sectors;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
    bool dense[Q];
 #pragma unroll
    for (int q = 0; q < Q; ++q) {
-      dense[q] = batch.sparse_sectors == nullptr || batch.sparse_sectors[q] > batch.sparse_capacity;
+      dense[q] = batch.sparse_sectors == nullptr || batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE] > batch.sparse_capacity;
    }
    bool any_dense = false;
 #pragma unroll
@@ -495,18 +498,19 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
 // capacity of row_words / 16 sectors.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t SECTOR_WORDS = 8;
+constexpr uint32_t COMPACT_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void k_compact_filter(
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
    const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index
 ) {
+   __shared__ uint32_t s_wave_first[COMPACT_THREADS / 64];
+   __shared__ uint32_t s_block_first;
    const uint32_t q = blockIdx.y;
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // row_words is a multiple of 32: sectors never straddle the row end
    const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t wave = threadIdx.x >> 6;
    const uint64_t value = w < row_words ? batch.filters[q][w] : 0;
    const uint64_t ballot = __ballot(value != 0);
-   if (ballot == 0) {
-      return;
-   }
    // one bit per sector of this wave (at the sector's first lane): does any of its 8 words have a set bit?
    uint64_t leaders = 0;
 #pragma unroll
@@ -515,13 +519,22 @@ __global__ __launch_bounds__(256) void k_compact_filter(
          leaders |= 1ull << (sector * SECTOR_WORDS);
       }
    }
-   uint32_t base = 0;
    if (lane == 0) {
-      base = atomicAdd(sparse_sectors + q, static_cast<uint32_t>(__popcll(leaders)));
+      s_wave_first[wave] = static_cast<uint32_t>(__popcll(leaders));
    }
-   base = __shfl(base, 0);
+   __syncthreads();
+   if (threadIdx.x == 0) {  // exclusive prefix over the waves, ONE atomic per block
+      uint32_t total = 0;
+      for (uint32_t k = 0; k < COMPACT_THREADS / 64; ++k) {
+         const uint32_t count = s_wave_first[k];
+         s_wave_first[k] = total;
+         total += count;
+      }
+      s_block_first = total != 0 ? atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE, total) : 0;
+   }
+   __syncthreads();
    if (((leaders >> lane) & 1ull) != 0) {
-      const uint32_t slot = base + static_cast<uint32_t>(__popcll(leaders & ((1ull << lane) - 1ull)));
+      const uint32_t slot = s_block_first + s_wave_first[wave] + static_cast<uint32_t>(__popcll(leaders & ((1ull << lane) - 1ull)));
       if (slot < capacity) {
          sector_index[static_cast<size_t>(q) * capacity + slot] = w / SECTOR_WORDS;
       }
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(256, 5) void k_scan_gather(
    const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity, uint32_t row_words
 ) {
    const uint32_t q = blockIdx.y;
-   const uint32_t n_sectors = batch.sparse_sectors[q];
+   const uint32_t n_sectors = batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE];
    if (n_sectors == 0 || n_sectors > batch.sparse_capacity) {
       return;  // empty filter, or a dense one (k_scan_sliced has it); `capacity` is the stride of the lists
    }
@@ -1698,7 +1711,7 @@ int launchGatherScan(ScanBatchArgs& batch, const uint32_t* sector_index, uint32_
 struct SparseScratch {
    int device = 0;
    uint32_t capacity = 0;  // sectors per filter
-   uint32_t* sparse_sectors = nullptr;  // [SILO_GPU_MAX_SCAN_BATCH]
+   uint32_t* sparse_sectors = nullptr;  // [SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE]
    uint32_t* sector_index = nullptr;    // [SILO_GPU_MAX_SCAN_BATCH][capacity]
    hipEvent_t last_use = nullptr;
    bool in_flight = false;  // handed out and not yet released
@@ -1723,7 +1736,7 @@ int acquireSparseScratch(int device, uint32_t capacity, SparseScratch** out) {
    block->capacity = capacity;
    void* memory = nullptr;
    // one allocation: the index lists, then the counters
-   const size_t bytes = (static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity + SILO_GPU_MAX_SCAN_BATCH) * sizeof(uint32_t);
+   const size_t bytes = (static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity + SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE) * sizeof(uint32_t);
    HIP_TRY(hipMalloc(&memory, bytes));
    block->sector_index = static_cast<uint32_t*>(memory);
    block->sparse_sectors = block->sector_index + static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity;
@@ -1759,7 +1772,7 @@ int scanRangesDense(
          const uint32_t n = std::min<uint32_t>(filters_per_pass, q_count - first);
          ScanBatchArgs batch{};
          batch.n_ranges = n_ranges;
-         batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first : nullptr;
+         batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first * SPARSE_COUNTER_STRIDE : nullptr;
          batch.sparse_capacity = sparse_capacity;
          for (uint32_t q = 0; q < n; ++q) {
             batch.filters[q] = filters[first + q];
@@ -1829,14 +1842,14 @@ int scanRanges(
    }
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
    int rc = SILO_GPU_OK;
-   if (hipMemsetAsync(scratch->sparse_sectors, 0, SILO_GPU_MAX_SCAN_BATCH * sizeof(uint32_t), hip_stream) != hipSuccess) {
+   if (hipMemsetAsync(scratch->sparse_sectors, 0, SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE * sizeof(uint32_t), hip_stream) != hipSuccess) {
       rc = fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipMemsetAsync failed");
    } else {
       ScanBatchArgs compact{};
       for (uint32_t q = 0; q < q_count; ++q) {
          compact.filters[q] = filters[q];
       }
-      k_compact_filter<<<dim3((layout.row_words + 255) / 256, q_count), 256, 0, hip_stream>>>(
+      k_compact_filter<<<dim3((layout.row_words + COMPACT_THREADS - 1) / COMPACT_THREADS, q_count), COMPACT_THREADS, 0, hip_stream>>>(
          compact, layout.row_words, stride, scratch->sparse_sectors, scratch->sector_index
       );
       rc = scanRangesDense(ranges, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
