@@ -395,13 +395,21 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             }
          }
       }
+      // wave reduction, two symbols per register: a lane counted at most WPT * 64 <= 512 rows per symbol, so a wave total
+      // fits 16 bits (<= 32 768) and the 6 DPP steps serve two symbols at once
+      static_assert(WPT * 64 * 64 < 65536, "packed wave totals need 16 bits per symbol");
 #pragma unroll
-      for (int symbol = 0; symbol < NSYM; ++symbol) {
+      for (int symbol = 0; symbol < NSYM; symbol += 2) {
 #pragma unroll
          for (int q = 0; q < Q; ++q) {
-            const uint32_t total = waveSumToLane63(acc[symbol][q]);
+            const bool pair = symbol + 1 < NSYM;
+            const uint32_t packed = pair ? (acc[symbol][q] | (acc[symbol + 1 < NSYM ? symbol + 1 : symbol][q] << 16)) : acc[symbol][q];
+            const uint32_t total = waveSumToLane63(packed);
             if (writer && store) {
-               s_partial[buffer][wave][slot][q * NSYM + symbol] = total;
+               s_partial[buffer][wave][slot][q * NSYM + symbol] = pair ? (total & 0xFFFFu) : total;
+               if (pair) {
+                  s_partial[buffer][wave][slot][q * NSYM + symbol + 1] = total >> 16;
+               }
             }
          }
       }
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
 // One WAVE per group of POSG consecutive positions (no LDS, no block-level reduction: a sparse filter may have fewer
 // non-zero words than a block has lanes); lanes stride over the words of the listed sectors, POSG * BITS gathers in flight each.
 template <int BITS, int NSYM, int POSG>
-__global__ __launch_bounds__(256, 5) void k_scan_gather(
+__global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
    const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity, uint32_t row_words
 ) {
    const uint32_t q = blockIdx.y;
@@ -1640,7 +1648,8 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
       wide = true;
    }
    const bool medium = variant == 14 && BITS <= 3 && q_count == 1;  // experiment: 6 words per thread
-   const uint32_t tile_words = SCAN_THREADS * (medium ? 6 : (wide ? 8 : 4));
+   const bool narrow = variant == 16 && BITS == 5 && q_count == 1;  // experiment: 2 words per thread (amino acids, more waves per SIMD)
+   const uint32_t tile_words = SCAN_THREADS * (narrow ? 2 : (medium ? 6 : (wide ? 8 : 4)));
    int positions_per_block = g_tune_rows_per_block.load();
    const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    uint64_t total_positions = 0;
@@ -1660,7 +1669,11 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    const dim3 grid(batch.first_unit[batch.n_ranges]);
 #define SILO_LAUNCH_SLICED(WPT, Q) \
    k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
-   if (medium) {
+   if (narrow) {
+      if constexpr (BITS == 5) {
+         SILO_LAUNCH_SLICED(2, 1);
+      }
+   } else if (medium) {
       if constexpr (BITS <= 3) {
          SILO_LAUNCH_SLICED(6, 1);
       }

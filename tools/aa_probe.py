@@ -15,9 +15,12 @@ from silo_amd import binding  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sequences", type=int, default=1_000_000)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--nuc-positions", type=int, default=None, help="cut the nucleotide store to a stub (10 M sequences: the genes alone are 73 GB)")
+ap.add_argument("--variants", type=str, default="0", help="SILO_GPU_TUNE_SCAN_VARIANT values to try (16 = 2 words per thread)")
+ap.add_argument("--rows", type=str, default="", help="positions per block to try for the one-call scan of all genes, e.g. 12,24,32,64")
 args = ap.parse_args()
 
-engine, model, tree, lineage, window = bench.build_engine(args.sequences, 0, 1, None, 0, with_genes=True)
+engine, model, tree, lineage, window = bench.build_engine(args.sequences, 0, 1, None, 0, with_genes=True, nuc_positions=args.nuc_positions)
 lib = binding.load_library()
 store = engine.partition_store(0)
 genes = bench.load_reference_genomes(True)["genes"]
@@ -60,17 +63,24 @@ stop.record()
 ms = start.elapsed_ms(stop) / args.reps
 print(f"12 launches back to back {ms:.3f} ms -> {all_bytes / ms / 1e6:.0f} GB/s")
 
-if hasattr(lib, "silo_gpu_mutations_scan_multi"):
-    id_array = (ctypes.c_uint32 * len(ids))(*ids)
-    table_array = (ctypes.c_void_p * len(ids))(*[t.value for t in tables])
+ranges = (ctypes.c_uint32 * (3 * len(ids)))(*[v for sid, length in zip(ids, lengths) for v in (sid, 0, length)])
+table_array = (ctypes.c_void_p * len(ids))(*[t.value for t in tables])
+filters = (ctypes.c_void_p * 1)(filt.value)
+for variant, rows in [(int(v), r) for v in args.variants.split(",") for r in [0] + [int(r) for r in args.rows.split(",") if r]]:
+    lib.silo_gpu_tune(0, rows)
+    lib.silo_gpu_tune(1, variant)
     for _ in range(2):
-        binding._check(lib.silo_gpu_mutations_scan_multi(store.handle, id_array, len(ids), filt, table_array, None))
+        binding._check(lib.silo_gpu_mutations_scan_ranges(store.handle, ranges, len(ids), filters, 1, table_array, None))
     start.record()
     for _ in range(args.reps):
-        binding._check(lib.silo_gpu_mutations_scan_multi(store.handle, id_array, len(ids), filt, table_array, None))
+        binding._check(lib.silo_gpu_mutations_scan_ranges(store.handle, ranges, len(ids), filters, 1, table_array, None))
     stop.record()
     ms = start.elapsed_ms(stop) / args.reps
-    print(f"one fused launch over 12 genes {ms:.3f} ms -> {all_bytes / ms / 1e6:.0f} GB/s  ({lib.silo_gpu_last_scan_kernel().decode()})")
+    phys = sum(lengths) * 5 * w8
+    print(f"one call over 12 genes, variant {variant}, positions per block {rows or 'default'}: {ms:.3f} ms -> {all_bytes / ms / 1e6:.0f} GB/s algorithmic, "
+          f"{phys / ms / 1e6:.0f} GB/s physical", flush=True)
+lib.silo_gpu_tune(0, 0)
+lib.silo_gpu_tune(1, 0)
 
 query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
                     "filterExpression": json.loads(bench.make_query())["filterExpression"]}).encode()
