@@ -444,3 +444,61 @@ def test_insertion_search_unit_test_vectors(built):
             assert [int(row["key"]) for row in rows] == search["expected"], search
         assert engine.execute_query({"action": {"type": "Details", "fields": ["insertions"], "orderByFields": ["insertions"], "limit": 2},
                                      "filterExpression": {"type": "True"}}) == [{"insertions": "25701:ACCA"}, {"insertions": "25701:ACCA"}]
+
+
+def _keyed_engine(n, extra_columns, lineages=None, sequences=None):
+    """A tiny database: `n` rows, a string primary key "0".."n-1", the given metadata columns."""
+    from silo_amd.engine import Engine
+
+    engine = Engine({"nucleotideSequences": [{"name": "main", "sequence": "ACGT"}], "genes": []})
+    engine.set_schema("key")
+    part = engine.add_partition(n)
+    engine.append_sequences(part, "main", False, 0, sequences or [None] * n)
+    engine.append_metadata(part, "key", "string", [str(i) for i in range(n)])
+    for name, kind, values in extra_columns:
+        engine.append_metadata(part, name, kind, values)
+    if lineages is not None:
+        engine.set_lineage_column(part, "pango_lineage", lineages)
+    engine.finalize()
+    return engine
+
+
+def _selected_rows(engine, expression):
+    rows = engine.execute_query({"action": {"type": "Details", "fields": ["key"]}, "filterExpression": expression})
+    return sorted(int(row["key"]) for row in rows)
+
+
+def test_column_unit_test_vectors(built):
+    """pango_lineage_column.test.cpp, indexed_string_column.test.cpp, pango_lineage.test.cpp (isSublineageOf),
+    nucleotide_symbols.test.cpp ('.' is a gap) as row sets of filters evaluated on the device."""
+    import os
+
+    vectors = json.load(open(os.path.join(dataset.GOLDEN, "operators", "operator_vectors.json")))
+    for vec in vectors["pango_lineage_column"]:
+        with _keyed_engine(len(vec["rows"]), [], lineages=vec["rows"]) as engine:
+            for value, including_sublineages, expected in vec["queries"]:
+                got = _selected_rows(engine, {"type": "PangoLineage", "column": "pango_lineage", "value": value,
+                                              "includeSublineages": including_sublineages})
+                assert got == expected, (vec["cite"], value, including_sublineages)
+    for vec in vectors["indexed_string_column"]:
+        for kind in ("indexed_string", "string"):
+            with _keyed_engine(len(vec["rows"]), [("name", kind, vec["rows"])]) as engine:
+                for value, expected in vec["queries"]:
+                    assert _selected_rows(engine, {"type": "StringEquals", "column": "name", "value": value}) == expected, (vec["cite"], kind, value)
+    cases = vectors["sublineage_relation"]["cases"]
+    with _keyed_engine(len(cases), [], lineages=[lineage for lineage, _, _ in cases]) as engine:
+        for row, (lineage, other, expected) in enumerate(cases):
+            got = _selected_rows(engine, {"type": "PangoLineage", "column": "pango_lineage", "value": other, "includeSublineages": True})
+            assert (row in got) == expected, (lineage, other)
+    conversion = vectors["symbol_conversion"]["nucleotide"]
+    with _keyed_engine(3, [], sequences=["A.GT", "A-GT", "ACGT"]) as engine:  # both gap characters are the same symbol
+        assert conversion["gap_characters"] == [".", "-"]
+        assert _selected_rows(engine, {"type": "NucleotideEquals", "position": 2, "symbol": "-"}) == [0, 1]
+    for char in conversion["illegal"]:
+        with pytest.raises(Exception, match="[Ii]llegal|invalid"):
+            _keyed_engine(1, [], sequences=["AC" + char + "T"])
+    for vec in vectors["leaf_operators"]:
+        if vec["operator"] != "IndexScan":
+            with _keyed_engine(vec["row_count"], []) as engine:
+                expression = {"type": "True"} if vec["operator"] == "Full" else {"type": "False"}
+                assert _selected_rows(engine, expression) == vec["expected"], vec["cite"]

@@ -211,3 +211,39 @@ def test_lineage_alias_vectors(example_data):
     lookup = so.PangoLineageAliasLookup(example_data["alias"])
     for text, expected in vectors["example_file"]:
         assert lookup.unalias(text) == expected, text
+
+
+@pytest.mark.parametrize("vec", VECTORS["pango_lineage_column"], ids=lambda v: v["cite"])
+def test_pango_lineage_column_vectors(vec):
+    column = so.PangoLineageColumnPartition(so.PangoLineageAliasLookup({}))
+    for value in vec["rows"]:
+        column.insert(value)
+    for value, including_sublineages, expected in vec["queries"]:
+        bits = column.filter_including_sublineages(value) if including_sublineages else column.filter(value)
+        assert so.ids_from_bits(bits or 0) == expected, (value, including_sublineages)
+        assert (bits is None) == (expected == [])  # std::nullopt for a value that was never indexed
+
+
+def test_sublineage_relation_vectors():
+    for lineage, other, expected in VECTORS["sublineage_relation"]["cases"]:  # isSublineageOf = `other` is one of the parent lineages
+        assert (other in so.get_parent_lineages(lineage)) == expected, (lineage, other)
+
+
+def test_leaf_operator_vectors():
+    for vec in VECTORS["leaf_operators"]:
+        rc = vec["row_count"]
+        op = {"Full": lambda: so.Full(rc), "Empty": lambda: so.Empty(rc),
+              "IndexScan": lambda: so.IndexScan(so.bits_from_ids(vec.get("bitmap", [])), rc)}[vec["operator"]]()
+        assert so.ids_from_bits(op.evaluate()) == vec["expected"], vec["cite"]
+
+
+def test_symbol_conversion_vectors():
+    vec = VECTORS["symbol_conversion"]
+    for key, alphabet in (("nucleotide", so.Nucleotide), ("amino_acid", so.AminoAcid)):
+        gap = alphabet.char_to_symbol("-")
+        for char in vec[key]["gap_characters"]:
+            assert alphabet.char_to_symbol(char) == gap
+        for char in vec[key]["legal"]:
+            assert alphabet.char_to_symbol(char) is not None and alphabet.char_to_symbol(char) != gap
+        for char in vec[key]["illegal"]:
+            assert alphabet.char_to_symbol(char) is None
