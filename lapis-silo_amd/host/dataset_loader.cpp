@@ -282,31 +282,90 @@ std::unordered_map<std::string, std::string> readFlatYaml(const std::string& pat
       if (colon == std::string::npos || line.find_first_not_of(" \t") == std::string::npos || line[line.find_first_not_of(" \t")] == '#') {
          continue;
       }
-      out[unquote(line.substr(0, colon))] = unquote(line.substr(colon + 1));
+      const std::string value = unquote(line.substr(colon + 1));
+      if (value.empty() && unquote(line.substr(colon + 1) + "x").size() <= 1) {
+         continue;  // "key:" without a value is YAML null — not set; `key: ""` below is an (empty) string and is kept
+      }
+      out[unquote(line.substr(0, colon))] = value;
    }
    return out;
 }
 
 struct DatabaseSchema {
+   std::string instance_name;
    std::string primary_key;
    std::optional<std::string> date_to_sort_by;
+   std::optional<std::string> partition_by;
    std::optional<std::string> default_nucleotide_sequence;
    struct Column {
       std::string name;
       std::string type;
       bool generate_index = false;
+      bool generate_index_given = false;
    };
    std::vector<Column> metadata;  // in file order
 };
 
-DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config.cpp:47-90
+/// config_repository.cpp:22-108 (validateConfig): the rules a database config has to satisfy, with the reference's messages.
+void validateDatabaseSchema(const DatabaseSchema& schema) {
+   std::map<std::string, std::string> type_of;
+   for (const auto& column : schema.metadata) {
+      if (type_of.count(column.name) != 0) {
+         throw PreprocessingException("Metadata " + column.name + " is defined twice in the config");
+      }
+      if (column.generate_index && column.type != "string" && column.type != "pango_lineage") {
+         throw PreprocessingException(
+            "Metadata '" + column.name + "' generate_index is set, but generating an index is only allowed for types STRING and PANGOLINEAGE"
+         );
+      }
+      if (!column.generate_index && column.type == "pango_lineage") {
+         throw PreprocessingException(
+            "Metadata '" + column.name + "' generate_index is not set, but generating an index is mandatory for type PANGOLINEAGE"
+         );
+      }
+      type_of[column.name] = column.type;
+   }
+   if (schema.metadata.empty()) {
+      throw PreprocessingException("Database config without fields not possible");
+   }
+   if (type_of.count(schema.primary_key) == 0) {
+      throw PreprocessingException("Primary key is not in metadata");
+   }
+   if (schema.date_to_sort_by.has_value()) {
+      const auto found = type_of.find(*schema.date_to_sort_by);
+      if (found == type_of.end()) {
+         throw PreprocessingException("date_to_sort_by '" + *schema.date_to_sort_by + "' is not in metadata");
+      }
+      if (found->second != "date") {
+         throw PreprocessingException("date_to_sort_by '" + *schema.date_to_sort_by + "' must be of type DATE");
+      }
+   }
+   if (schema.partition_by.has_value()) {
+      const auto found = type_of.find(*schema.partition_by);
+      if (found == type_of.end()) {
+         throw PreprocessingException("partition_by '" + *schema.partition_by + "' is not in metadata");
+      }
+      if (found->second != "pango_lineage") {
+         throw PreprocessingException("partition_by '" + *schema.partition_by + "' must be of type PANGOLINEAGE");
+      }
+   }
+}
+
+DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config.cpp:47-90, 197-231
    DatabaseSchema schema;
    std::ifstream stream(path);
    if (!stream) {
-      throw PreprocessingException("cannot open " + path);
+      throw PreprocessingException("Failed to read database config: cannot open " + path);
    }
    std::string line;
+   std::string open_list;      // the key whose (block) value the following "- " items belong to
+   size_t list_indent = 0;
+   bool has_schema = false, has_metadata = false, has_primary_key = false;
    while (std::getline(stream, line)) {
+      const auto first = line.find_first_not_of(" \t");
+      if (first == std::string::npos || line[first] == '#') {
+         continue;
+      }
       const auto colon = line.find(':');
       if (colon == std::string::npos) {
          continue;
@@ -317,27 +376,59 @@ DatabaseSchema readDatabaseConfig(const std::string& path) {  // database_config
       if (!key.empty() && key.front() == '-') {
          key = unquote(key.substr(1));
          starts_item = true;
+      } else if (value.empty()) {
+         if (key == "schema") {
+            has_schema = true;
+         } else {
+            open_list = key;  // "metadata:", "features:"
+            list_indent = first;
+            has_metadata = has_metadata || key == "metadata";
+         }
+         continue;
+      } else if (!open_list.empty() && first <= list_indent) {
+         open_list.clear();  // a scalar at the level of the list's key ends the list
       }
-      if (starts_item) {
+      const bool in_metadata = open_list == "metadata";
+      if (starts_item && in_metadata) {
          schema.metadata.emplace_back();
       }
-      if (key == "primaryKey") {
-         schema.primary_key = value;
-      } else if (key == "dateToSortBy") {
-         schema.date_to_sort_by = value;
-      } else if (key == "defaultNucleotideSequence") {
-         schema.default_nucleotide_sequence = value;
-      } else if (key == "name" && !schema.metadata.empty()) {
-         schema.metadata.back().name = value;
-      } else if (key == "type" && !schema.metadata.empty()) {
-         schema.metadata.back().type = value;
-      } else if (key == "generateIndex" && !schema.metadata.empty()) {
-         schema.metadata.back().generate_index = value == "true";
+      if (open_list.empty() || !in_metadata) {
+         if (key == "instanceName" && open_list.empty()) {
+            schema.instance_name = value;
+         } else if (key == "primaryKey" && open_list.empty()) {
+            schema.primary_key = value;
+            has_primary_key = true;
+         } else if (key == "dateToSortBy" && open_list.empty()) {
+            schema.date_to_sort_by = value;
+         } else if (key == "partitionBy" && open_list.empty()) {
+            schema.partition_by = value;
+         } else if (key == "defaultNucleotideSequence") {
+            schema.default_nucleotide_sequence = value;
+         }
+         continue;  // entries of other lists ("features") are none of ours (database_config.test.cpp:143-147)
       }
+      if (key == "name") {
+         schema.metadata.back().name = value;
+      } else if (key == "type") {
+         schema.metadata.back().type = value;
+      } else if (key == "generateIndex") {
+         schema.metadata.back().generate_index = value == "true";
+         schema.metadata.back().generate_index_given = true;
+      }
+   }
+   for (auto& column : schema.metadata) {
+      if (!column.generate_index_given) {
+         column.generate_index = column.type == "pango_lineage";  // the reference's default (database_config.cpp:138-142)
+      }
+   }
+   if (!has_schema || !has_metadata || !has_primary_key) {
+      // what yaml-cpp reports when the reference decodes a schema without the key (database_config.test.cpp:149-160)
+      const std::string missing = !has_schema ? "schema" : (!has_metadata ? "metadata" : "primaryKey");
+      throw PreprocessingException("database config " + path + ": invalid node; first invalid key: \"" + missing + "\"");
    }
    for (const auto& column : schema.metadata) {
       if (column.name.empty() || !config::columnTypeFromConfig(column.type, column.generate_index).has_value()) {
-         throw PreprocessingException("database config " + path + ": metadata entry '" + column.name + "' has no valid name / type");
+         throw PreprocessingException("database config " + path + ": metadata entry '" + column.name + "' has no valid name / type ('" + column.type + "')");
       }
    }
    return schema;
@@ -466,6 +557,29 @@ std::unordered_map<std::string, std::string> readFasta(const std::string& path) 
 
 }  // namespace
 
+std::string describeDatabaseConfig(const std::string& path, bool validate) {
+   const DatabaseSchema schema = readDatabaseConfig(path);
+   if (validate) {
+      validateDatabaseSchema(schema);
+   }
+   json::Value::Object out;
+   const auto optional_text = [](const std::optional<std::string>& value) { return value.has_value() ? json::Value(*value) : json::Value(nullptr); };
+   out.insertOrAssign("instanceName", schema.instance_name);
+   out.insertOrAssign("primaryKey", schema.primary_key);
+   out.insertOrAssign("dateToSortBy", optional_text(schema.date_to_sort_by));
+   out.insertOrAssign("partitionBy", optional_text(schema.partition_by));
+   json::Value::Array columns;
+   for (const auto& column : schema.metadata) {
+      json::Value::Object entry;
+      entry.insertOrAssign("name", column.name);
+      entry.insertOrAssign("type", column.type);
+      entry.insertOrAssign("generateIndex", column.generate_index);
+      columns.emplace_back(std::move(entry));
+   }
+   out.insertOrAssign("metadata", std::move(columns));
+   return json::Value(std::move(out)).dump();
+}
+
 DatasetSummary loadDataset(Database& database, const std::string& directory) {
    if (!database.partitions.empty()) {
       throw PreprocessingException("loadDataset needs an empty database");
@@ -477,7 +591,9 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
    }
    const auto setting = [&](const char* key, const char* fallback) {
       const auto found = config.find(key);
-      return found != config.end() && !found->second.empty() ? found->second : std::string(fallback);
+      // a key that is present wins even when it is the empty string: `nucleotideSequencePrefix: ""` names the files
+      // `<sequence>.fasta` (preprocessing_config_reader.test.cpp:35-50)
+      return found != config.end() ? found->second : std::string(fallback);
    };
    if (config.count("ndjsonInputFilename") != 0 && config.count("metadataFilename") != 0) {  // preprocessing_config_reader.cpp:54-60
       throw PreprocessingException(
@@ -486,6 +602,7 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
       );
    }
    const DatabaseSchema schema = readDatabaseConfig((root / "database_config.yaml").string());
+   validateDatabaseSchema(schema);  // ConfigRepository::getValidatedConfig
    if (schema.default_nucleotide_sequence.has_value()) {
       database.database_config.default_nucleotide_sequence = *schema.default_nucleotide_sequence;
    }

@@ -37,6 +37,12 @@ struct DatasetSummary {
    size_t null_sequences = 0;
 };
 
+/// Reads (DatabaseConfigReader::readConfig, database_config.cpp:197-231) and, with `validate`, checks
+/// (ConfigRepository::validateConfig, config_repository.cpp:22-108) a database_config.yaml and renders
+/// what was understood as JSON: {"instanceName", "primaryKey", "dateToSortBy", "partitionBy", "metadata": [{"name", "type",
+/// "generateIndex"}]}.  Throws PreprocessingException with the reference's message for an invalid config.
+std::string describeDatabaseConfig(const std::string& path, bool validate);
+
 /// Fills `database` (must be empty) from the files in `directory` and finalises it.
 DatasetSummary loadDataset(Database& database, const std::string& directory);
 

@@ -6,6 +6,7 @@
 #include <chrono>
 
 #include "database.h"
+#include "dataset_loader.h"
 #include "query_engine.h"
 
 namespace {
@@ -54,6 +55,16 @@ int t_insertion_standardise(const char* default_sequence, const char* value, cha
       );
       return copyOut(column.insert(value, 0), out, capacity);
    } catch (const std::exception&) {
+      return -1;
+   }
+}
+
+/// What the loader understands of a database_config.yaml, as JSON (return >= 0), or the validation error (return -1).
+int t_describe_database_config(const char* path, int validate, char* out, size_t capacity) {
+   try {
+      return copyOut(silo::preprocessing::describeDatabaseConfig(path, validate != 0), out, capacity);
+   } catch (const std::exception& error) {
+      (void)copyOut(error.what(), out, capacity);
       return -1;
    }
 }

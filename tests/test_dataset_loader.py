@@ -165,3 +165,29 @@ def test_loader_reports_problems_not_crashes(built, tmp_path):
     (both / "preprocessing_config.yaml").write_text('ndjsonInputFilename: "a.ndjson"\nmetadataFilename: "b.tsv"\n')
     rc, message = load(both)
     assert rc != 0 and message == "Cannot specify both a ndjsonInputFilename ('a.ndjson') and metadataFilename('b.tsv')."
+
+
+@pytest.mark.gpu
+def test_overridden_file_prefixes(built, tmp_path):
+    """preprocessing_config_reader.test.cpp:35-50 (test_preprocessing_config_with_overridden_defaults.yaml): a
+    genePrefix of its own and an EMPTY nucleotideSequencePrefix — the sequence files are then `<name>.fasta` — give the
+    same database as the default names."""
+    import shutil
+
+    from silo_amd.engine import Engine
+
+    source = os.path.join(dataset.GOLDEN, "preprocessing", "tsvWithSqlKeywordField")
+    expected = json.load(open(os.path.join(source, "expected.json")))
+    for name in os.listdir(source):
+        target = name
+        if name.startswith("gene_"):
+            target = "aaSeq_" + name[len("gene_"):]
+        elif name.startswith("nuc_"):
+            target = name[len("nuc_"):]
+        shutil.copy(os.path.join(source, name), os.path.join(str(tmp_path), target))
+    with open(os.path.join(str(tmp_path), "preprocessing_config.yaml"), "a") as out:
+        out.write('\ngenePrefix: "aaSeq_"\nnucleotideSequencePrefix: ""\n')
+    with Engine.from_directory(str(tmp_path)) as engine:
+        assert engine.summary["sequenceCount"] == expected["expectedSequenceCount"]
+        status, document = engine.execute_raw(expected["query"])
+        assert status == 200 and document["queryResult"] == expected["expectedQueryResult"]

@@ -128,6 +128,7 @@ def host_logic(built):
     lib.t_date_to_string.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
     lib.t_lineage.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.t_insertion_standardise.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.t_describe_database_config.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.alias_json = open(os.path.join(ROOT, "tests", "golden", "exampleDataset", "pangolineage_alias.json")).read().encode()
     lib.alias_dict = json.loads(lib.alias_json)
     return lib
@@ -198,3 +199,25 @@ def test_reference_unit_test_vectors_on_the_host_functions(host_logic):
     for text, expected in alias["example_file"]:
         assert host_logic.t_lineage(host_logic.alias_json, text.encode(), 0, buffer, 256) >= 0
         assert buffer.value.decode() == expected, text
+
+
+def test_database_config_reader_and_validation_vectors(host_logic):
+    """database_config.test.cpp (the reference's own YAML fixtures through the loader's reader) and
+    config_repository.test.cpp (its validation rules, with the messages that test expects)."""
+    import json
+
+    directory = os.path.join(ROOT, "tests", "golden", "config")
+    buffer = ctypes.create_string_buffer(8192)
+    for case in json.load(open(os.path.join(directory, "config_vectors.json")))["cases"]:
+        status = host_logic.t_describe_database_config(os.path.join(directory, case["file"]).encode(), int(case["validate"]), buffer, 8192)
+        text = buffer.value.decode()
+        if case["error"] is not None:
+            assert status == -1 and case["error"] in text, (case["cite"], text)
+            continue
+        assert status >= 0, (case["cite"], text)
+        got = json.loads(text)
+        for key, value in case.get("expect", {}).items():
+            if key == "metadata":
+                assert [[c["name"], c["type"], c["generateIndex"]] for c in got["metadata"]] == value, case["cite"]
+            else:
+                assert got[key] == value, (case["cite"], key)
