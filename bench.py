@@ -478,11 +478,14 @@ def main():
     n_local = window[1] - window[0]
     kernel_ms, kernel_name, store, filt, counts_dev = time_kernel(engine, tree, window, reps=max(5, args.steps))
     # algorithmic bytes: the layout-independent figure of SURVEY.md §8(d) — 5 one-hot symbol columns per position plus the
-    # filter, 0.625 B per position x sequence.  The store is bit-sliced (3 code planes per position), so the kernel
-    # moves 3/5 of that: both are reported, `frac` by the contract's definition (algorithmic bytes / time / peak) and
-    # `physical_frac` for the bytes that actually cross the HBM interface.
+    # filter, 0.625 B per position x sequence.  The store is bit-sliced (3 code planes per position) and the scan reads
+    # the compact scan index derived from it at finalize (K1i: 2 code planes per position + the escape keys) when there
+    # is one: both figures are reported, `frac` by the contract's definition (algorithmic bytes / time / peak) and
+    # `physical_frac` for the bytes the scan really asks of the HBM interface.
+    scan_planes = int(lib.silo_gpu_store_scan_planes(store.handle, 0))
+    scan_escapes = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
     alg_bytes = n_local * 5 * w8 + w8
-    physical_bytes = n_local * 3 * w8 + w8
+    physical_bytes = n_local * scan_planes * w8 + w8 + 8 * scan_escapes
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM traffic of the same launch shape from the committed rocprofv3 PMC passes (tools/rocprof_summary.py):
     # counters cannot be read in-process, so this is null unless a profile of exactly this grid is on file.
@@ -491,7 +494,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
-            if name.startswith("k_scan_sliced") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * 3:
+            if name.startswith("k_scan_sliced") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * scan_planes:
                 traffic = entry["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         pass
@@ -531,8 +534,12 @@ def main():
             "physical_bytes_per_launch": physical_bytes,
             "physical_GBps": physical_bytes / (kernel_ms * 1e-3) / 1e9,
             "physical_frac": physical_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "layout": "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes (SURVEY.md §8d keeps the "
-                      "algorithmic figure layout-independent)",
+            "scan_planes_per_position": scan_planes,
+            "escape_keys": scan_escapes,
+            "layout": ("bit-sliced store (3 code planes per position); the scan reads the compact scan index built at finalize: 2 code "
+                       "planes per position (the 3 most frequent valid symbols of the position) + the other rows as escape keys"
+                       if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes")
+                      + " (SURVEY.md §8d keeps the algorithmic figure layout-independent)",
         },
     }
 
@@ -569,7 +576,9 @@ def main():
             "unit": "positions*sequences/s",
             "ms_per_step": elapsed_aa_full / args.steps * 1e3,
             "algorithmic_GBps_whole_query": aa_positions * 22 * w8_full / (elapsed_aa_full / args.steps) / 1e9,
-            "physical_GBps_whole_query": aa_positions * 5 * w8_full / (elapsed_aa_full / args.steps) / 1e9,
+            "scan_planes_per_position": int(lib.silo_gpu_store_scan_planes(engine_aa.partition_store(0).handle, engine_aa.seqstore_id(0, "S", True))),
+            "physical_GBps_whole_query": aa_positions * int(lib.silo_gpu_store_scan_planes(engine_aa.partition_store(0).handle, engine_aa.seqstore_id(0, "S", True)))
+                                         * w8_full / (elapsed_aa_full / args.steps) / 1e9,
             "mutation_rows": len(rows_aa_full),
         }
         engine_aa.close()
@@ -586,7 +595,8 @@ def main():
             "unit": "positions*sequences/s",
             "ms_per_step": elapsed_aa / args.steps * 1e3,
             "algorithmic_GBps_whole_query": aa_bytes / (elapsed_aa / args.steps) / 1e9,
-            "physical_GBps_whole_query": aa_positions * 5 * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
+            "physical_GBps_whole_query": aa_positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, engine1.seqstore_id(0, "S", True)))
+                                         * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
             "mutation_rows": len(rows_aa),
         }
         kernel_ms1, _, _, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
@@ -598,7 +608,7 @@ def main():
             "ms_per_step": elapsed1 / args.steps * 1e3,
             "kernel_ms": kernel_ms1,
             "roofline_frac": alg1 / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "physical_frac": (positions * 3 * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "physical_frac": (positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, 0)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "mutation_rows": len(rows1),
         }
         result["also_metadata"] = metadata_workload(engine1, 1_000_000, sync)

@@ -316,6 +316,16 @@ int silo_gpu_mutations_scan(
    const silo_gpu_store* store, uint32_t seqstore_id, const uint64_t* filter_dev,
    uint32_t pos_begin, uint32_t pos_end, uint32_t* counts_out_dev, void* stream
 );
+/* K1i, the compact scan index.  silo_gpu_store_finalize derives, per sequence store, two code planes per position (code
+ * 1..3 = the three most frequent valid symbols AT THAT POSITION, 0 = anything else) plus the few rows whose valid symbol
+ * is none of the three as explicit keys; the Mutations scan streams those 2 planes instead of the 3 / 5 full code planes
+ * and adds the exceptions in one small pass — same counts.  Built only when the exceptions stay below 1/512 of the cells
+ * and the device memory is there (otherwise, and for every other consumer, the full planes serve).
+ * silo_gpu_store_scan_planes: plane rows the scan reads per position (2 with the index, else 3 / 5);
+ * silo_gpu_store_scan_escapes: number of exception keys (0 without the index). */
+uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqstore_id);
+uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqstore_id);
+
 /* K1 over several position ranges at once — the 12 genes of an AminoAcidMutations query, the segments of a segmented
  * genome, the sequence stores of several batched queries: every filter is applied to every range;
  * counts_out_dev[r * n_filters + q] is the table of filter q on range r, indexed from the range's first position and
@@ -344,6 +354,7 @@ int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream);
 
 /* Tuning knobs of K1 (0 = default); returns the previous value.  For benchmarks only. */
 enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SILO_GPU_TUNE_EVAL_LEAF_BATCH = 2 /* 8 (default) or 16 leaf loads in flight per lane in K3 */,
+       SILO_GPU_TUNE_COMPACT_INDEX = 4 /* < 0: neither build nor scan the compact scan index (K1i) */,
        SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };
 int silo_gpu_tune(int knob, int value);
 

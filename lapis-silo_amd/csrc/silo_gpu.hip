@@ -35,6 +35,7 @@ thread_local const char* g_last_scan_kernel = "none";
 std::atomic<int> g_tune_rows_per_block{0};
 std::atomic<int> g_tune_scan_variant{0};
 std::atomic<int> g_tune_eval_leaf_batch{0};
+std::atomic<int> g_tune_compact_index{0};  // < 0: never scan the compact index (K1i), even where one was built
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
 int fail(int code, const std::string& msg) {
@@ -156,6 +157,14 @@ struct SeqStoreHost {
    // cardinalities for a full filter (mutations.cpp:98-136); computed by one scan on first use
    uint32_t* d_totals = nullptr;
    bool totals_ready = false;
+   // K1i, the compact scan index: see buildCompactIndex
+   struct CompactIndex {
+      uint64_t* planes = nullptr;        // [positions][2][row_words]
+      uint8_t* code_map = nullptr;       // [positions][4]
+      uint64_t* escapes = nullptr;       // position << 37 | scan symbol index << 32 | sequence, grouped by position
+      std::vector<uint32_t> escape_first;  // [positions + 1], host copy of the prefix
+      bool ready = false;
+   } compact;
 };
 
 }  // namespace
@@ -181,6 +190,8 @@ struct silo_gpu_store {
 };
 
 namespace {
+
+int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore);  // K1i, defined next to the scan launchers
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -255,6 +266,10 @@ struct ScanBatchArgs {
    uint32_t n_positions[SCAN_MAX_RANGES];
    uint32_t first_unit[SCAN_MAX_RANGES + 1];   // prefix sums of the blocks / waves per range
    uint32_t* counts[SCAN_MAX_RANGES][SILO_GPU_MAX_SCAN_BATCH];  // counts[range][filter], at the first position of the range
+   // compact scan index (K1i, BITS == 2): per position of the range 4 bytes, [c] = the scan symbol that code c stands for
+   // at this position (0xFF = none); out_symbols = symbols per position of the count tables (5 / 22)
+   const uint8_t* code_map[SCAN_MAX_RANGES];
+   uint32_t out_symbols;
 };
 
 // positions whose partial counts sit in LDS between two flushes: ~16 KiB of LDS whatever NSYM * Q is
@@ -371,11 +386,15 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
                }
             }
             uint64_t high[BITS <= 3 ? 2 : 8];
-            if constexpr (BITS == 3) {
+            if constexpr (BITS == 2) {
+               static_assert(NSYM == 3, "two code planes carry three codes");
+               high[0] = ~0ull;  // the codes ARE the low pair
+               high[1] = 0;
+            } else if constexpr (BITS == 3) {
                high[0] = ~bits[2];
                high[1] = bits[2];
             } else {
-               static_assert(BITS == 5, "decode tree written for 3 or 5 code bits");
+               static_assert(BITS == 5, "decode tree written for 2, 3 or 5 code bits");
 #pragma unroll
                for (int k = 0; k < 8; ++k) {
                   high[k] = ((k & 1) != 0 ? bits[2] : ~bits[2]) & ((k & 2) != 0 ? bits[3] : ~bits[3]) & ((k & 4) != 0 ? bits[4] : ~bits[4]);
@@ -383,10 +402,8 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             }
 #pragma unroll
             for (int symbol = 0; symbol < NSYM; ++symbol) {
-               constexpr int dummy = 0;
-               (void)dummy;
                const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
-               const uint64_t match = low[code & 3u] & high[code >> 2];
+               const uint64_t match = BITS == 2 ? low[code & 3u] : (low[code & 3u] & high[code >> 2]);
 #pragma unroll
                for (int q = 0; q < Q; ++q) {
                   const uint64_t filter_word = half == 0 ? f[q][j].x : f[q][j].y;
@@ -425,7 +442,12 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             total += s_partial[buffer][w][position][rest];
          }
          if (total != 0) {
-            atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
+            if constexpr (BITS == 2) {  // compact index: code -> the symbol it stands for at this position
+               const uint32_t symbol = batch.code_map[range][static_cast<size_t>(batch_first_position + position) * 4 + 1 + rest % NSYM];
+               atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * batch.out_symbols + symbol], total);
+            } else {
+               atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
+            }
          }
       }
    };
@@ -505,6 +527,9 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
 // (profiles/r01_sparse_filters.md): ~1 µs per listed sector against 16.5 ms for the dense scan, hence the default
 // capacity of row_words / 16 sectors.
 // ------------------------------------------------------------------------------------------------
+// the index pays while the escapes of a position cost less than streaming the plane rows it saves: a key costs about as
+// much as 40 plane bytes (7.6 M keys in 46 us, profiles/r01_compact_index.md), i.e. break-even at N/320 keys per position
+constexpr uint64_t COMPACT_ESCAPE_DIVISOR = 512;
 constexpr uint32_t SECTOR_WORDS = 8;
 constexpr uint32_t COMPACT_THREADS = 1024;
 
@@ -633,6 +658,120 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
          if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
             atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
          }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1i: the compact scan index.  At almost every position of real alignments three symbols cover all but a handful of
+// rows (the reference symbol, the gap or a lineage's substitution, one more), so finalize() derives a SECOND, smaller
+// representation for the scan alone: two code planes per position — code c in 1..3 = the c-th most frequent valid symbol
+// at that position (code_map), 0 = anything else — plus the few rows whose valid symbol is none of the three, as
+// explicit keys ("escapes", grouped by position).  The Mutations scan then streams 2 planes instead of 3 (nucleotides)
+// or 5 (amino acids) and adds the escapes with one small pass; every other consumer (filter leaves, FastaAligned, the
+// sparse-filter gather, the totals) keeps reading the full code planes, which also remain the fallback: the index is
+// only built when the escapes stay below 1/512 of the cells and the memory is there.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_choose_codes(
+   const uint32_t* __restrict__ totals, uint32_t n_scan, uint32_t positions, uint8_t* __restrict__ code_map, uint32_t* __restrict__ escape_count
+) {
+   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= positions) {
+      return;
+   }
+   uint32_t best_count[3] = {0, 0, 0};
+   uint32_t best_symbol[3] = {0xFFu, 0xFFu, 0xFFu};
+   uint64_t sum = 0;
+   for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+      const uint32_t count = totals[static_cast<size_t>(p) * n_scan + symbol];
+      sum += count;
+      if (count > best_count[0]) {  // strictly greater: ties keep the lower symbol index in front
+         best_count[2] = best_count[1], best_symbol[2] = best_symbol[1];
+         best_count[1] = best_count[0], best_symbol[1] = best_symbol[0];
+         best_count[0] = count, best_symbol[0] = symbol;
+      } else if (count > best_count[1]) {
+         best_count[2] = best_count[1], best_symbol[2] = best_symbol[1];
+         best_count[1] = count, best_symbol[1] = symbol;
+      } else if (count > best_count[2]) {
+         best_count[2] = count, best_symbol[2] = symbol;
+      }
+   }
+   code_map[static_cast<size_t>(p) * 4 + 0] = 0xFFu;
+   for (int c = 0; c < 3; ++c) {
+      code_map[static_cast<size_t>(p) * 4 + 1 + c] = static_cast<uint8_t>(best_symbol[c]);
+   }
+   escape_count[p] = static_cast<uint32_t>(sum - best_count[0] - best_count[1] - best_count[2]);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void k_encode_compact(
+   const uint64_t* __restrict__ scan, uint32_t row_words, const uint8_t* __restrict__ code_map, const uint32_t* __restrict__ escape_first,
+   uint32_t* __restrict__ escape_cursor, uint64_t* __restrict__ planes, uint64_t* __restrict__ escapes
+) {
+   const uint32_t p = blockIdx.y;
+   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= row_words) {
+      return;
+   }
+   uint64_t bits[BITS];
+   uint64_t valid = 0;
+#pragma unroll
+   for (int bit = 0; bit < BITS; ++bit) {
+      bits[bit] = scan[(static_cast<size_t>(p) * BITS + bit) * row_words + w];
+      valid |= bits[bit];
+   }
+   uint64_t match[3];
+#pragma unroll
+   for (int c = 0; c < 3; ++c) {
+      const uint32_t symbol = code_map[static_cast<size_t>(p) * 4 + 1 + c];
+      const uint32_t code = symbol + 1u;
+      uint64_t m = symbol == 0xFFu ? 0 : ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < BITS; ++bit) {
+         m &= ((code >> bit) & 1u) != 0 ? bits[bit] : ~bits[bit];
+      }
+      match[c] = m;
+   }
+   planes[(static_cast<size_t>(p) * 2 + 0) * row_words + w] = match[0] | match[2];  // codes 1 (01) and 3 (11)
+   planes[(static_cast<size_t>(p) * 2 + 1) * row_words + w] = match[1] | match[2];  // codes 2 (10) and 3 (11)
+   uint64_t escaped = valid & ~(match[0] | match[1] | match[2]);
+   while (escaped != 0) {
+      const uint32_t row_bit = static_cast<uint32_t>(__builtin_ctzll(escaped));
+      escaped &= escaped - 1;
+      uint32_t code = 0;
+#pragma unroll
+      for (int bit = 0; bit < BITS; ++bit) {
+         code |= static_cast<uint32_t>((bits[bit] >> row_bit) & 1ull) << bit;
+      }
+      const uint32_t slot = escape_first[p] + atomicAdd(escape_cursor + p, 1u);
+      escapes[slot] = (static_cast<uint64_t>(p) << 37) | (static_cast<uint64_t>(code - 1u) << 32) | (static_cast<uint64_t>(w) * 64u + row_bit);
+   }
+}
+
+/// The rows the two code planes do not carry: one key per (position, symbol, sequence); grid.y = filter.
+__global__ __launch_bounds__(256) void k_scan_escapes(
+   const uint64_t* __restrict__ escapes, uint32_t n_escapes, const ScanBatchArgs batch, uint32_t pos_begin
+) {
+   const uint32_t q = blockIdx.y;
+   if (batch.sparse_sectors != nullptr && batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE] <= batch.sparse_capacity) {
+      return;  // this filter went to the gather kernel, which reads the full planes
+   }
+   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint64_t key = i < n_escapes ? escapes[i] : 0;
+   const uint32_t sequence = static_cast<uint32_t>(key);
+   bool pending = i < n_escapes && ((batch.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0;
+   // keys of one position sit together and share a few symbols: one atomic per distinct counter and wave, not per key
+   const uint32_t counter = (static_cast<uint32_t>(key >> 37) - pos_begin) * batch.out_symbols + (static_cast<uint32_t>(key >> 32) & 31u);
+   for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
+      const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
+      const uint32_t leader_counter = __shfl(counter, leader);
+      const uint64_t same = __ballot(pending && counter == leader_counter);
+      if (lane == leader) {
+         atomicAdd(&batch.counts[0][q][leader_counter], static_cast<uint32_t>(__popcll(same)));
+      }
+      if (counter == leader_counter) {
+         pending = false;
       }
    }
 }
@@ -1197,6 +1336,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR) {
       return g_tune_sparse_divisor.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_COMPACT_INDEX) {
+      return g_tune_compact_index.exchange(value);
+   }
    return -1;
 }
 
@@ -1327,6 +1469,9 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_sparse);
       (void)hipFree(seqstore.d_sparse_count);
       (void)hipFree(seqstore.d_totals);
+      (void)hipFree(seqstore.compact.planes);
+      (void)hipFree(seqstore.compact.code_map);
+      (void)hipFree(seqstore.compact.escapes);
    }
    (void)hipFree(store->d_ones);
    (void)hipFree(store->d_lineage);
@@ -1368,6 +1513,7 @@ int silo_gpu_store_append_sequences(
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
    seqstore.finalized = false;
    seqstore.totals_ready = false;
+   seqstore.compact.ready = false;
    const uint32_t positions = seqstore.dev.positions;
    const uint32_t pitch = positions;  // rows stay contiguous: ONE host-to-device copy per batch
 
@@ -1466,6 +1612,7 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
    seqstore.finalized = false;
    seqstore.totals_ready = false;
+   seqstore.compact.ready = false;
    const uint32_t n = store->sequence_count;
    const uint32_t positions = seqstore.dev.positions;
 
@@ -1607,6 +1754,10 @@ int silo_gpu_store_finalize(silo_gpu_store* store) {
          HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
       }
       seqstore.finalized = true;
+      const int rc = buildCompactIndex(store, seqstore);
+      if (rc != SILO_GPU_OK) {
+         return rc;
+      }
    }
    return SILO_GPU_OK;
 }
@@ -1633,6 +1784,7 @@ struct ScanRange {
    uint32_t pos_begin;
    uint32_t pos_end;
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
+   const SeqStoreHost::CompactIndex* compact;  // the compact scan index of the store (K1i), or nullptr
 };
 
 /// Launches k_scan_sliced for the `q_count` filters and the ranges already entered in `batch` (planes, n_positions, counts).
@@ -1778,7 +1930,18 @@ int scanRangesDense(
    uint32_t sparse_capacity, hipStream_t hip_stream
 ) {
    const SeqStoreDev& layout = *ranges.front().dev;
-   const uint32_t filters_per_pass = layout.n_bits == 3 ? SILO_GPU_MAX_SCAN_BATCH : 4;
+   // ranges with a compact scan index (two code planes per position + escapes) and ranges without go in separate launches
+   const bool allow_compact = g_tune_compact_index.load() >= 0;
+   const bool compact = allow_compact && ranges.front().compact != nullptr;
+   if (std::any_of(ranges.begin(), ranges.end(), [&](const ScanRange& range) { return (allow_compact && range.compact != nullptr) != compact; })) {
+      std::vector<ScanRange> with_index, without_index;
+      for (const ScanRange& range : ranges) {
+         (allow_compact && range.compact != nullptr ? with_index : without_index).push_back(range);
+      }
+      const int rc = scanRangesDense(with_index, filters, q_count, sparse_sectors, sparse_capacity, hip_stream);
+      return rc != SILO_GPU_OK ? rc : scanRangesDense(without_index, filters, q_count, sparse_sectors, sparse_capacity, hip_stream);
+   }
+   const uint32_t filters_per_pass = compact || layout.n_bits == 3 ? SILO_GPU_MAX_SCAN_BATCH : 4;
    for (size_t first_range = 0; first_range < ranges.size(); first_range += SCAN_MAX_RANGES) {
       const uint32_t n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, ranges.size() - first_range));
       for (uint32_t first = 0; first < q_count; first += filters_per_pass) {
@@ -1787,21 +1950,39 @@ int scanRangesDense(
          batch.n_ranges = n_ranges;
          batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first * SPARSE_COUNTER_STRIDE : nullptr;
          batch.sparse_capacity = sparse_capacity;
+         batch.out_symbols = layout.n_scan;
          for (uint32_t q = 0; q < n; ++q) {
             batch.filters[q] = filters[first + q];
          }
          for (uint32_t r = 0; r < n_ranges; ++r) {
             const ScanRange& range = ranges[first_range + r];
-            batch.planes[r] = scanPlanes(*range.dev, range.pos_begin);
+            batch.planes[r] = compact ? range.compact->planes + static_cast<size_t>(range.pos_begin) * 2 * layout.row_words
+                                      : scanPlanes(*range.dev, range.pos_begin);
+            batch.code_map[r] = compact ? range.compact->code_map + static_cast<size_t>(range.pos_begin) * 4 : nullptr;
             batch.n_positions[r] = range.pos_end - range.pos_begin;
             for (uint32_t q = 0; q < n; ++q) {
                batch.counts[r][q] = range.counts[first + q];
             }
          }
-         const int rc = layout.n_bits == 3 ? launchSlicedScan<3, 5>(batch, layout.row_words, n, hip_stream)
-                                           : launchSlicedScan<5, 22>(batch, layout.row_words, n, hip_stream);
+         const int rc = compact ? launchSlicedScan<2, 3>(batch, layout.row_words, n, hip_stream)
+                                : (layout.n_bits == 3 ? launchSlicedScan<3, 5>(batch, layout.row_words, n, hip_stream)
+                                                      : launchSlicedScan<5, 22>(batch, layout.row_words, n, hip_stream));
          if (rc != SILO_GPU_OK) {
             return rc;
+         }
+         for (uint32_t r = 0; compact && r < n_ranges; ++r) {  // the rows the two planes do not carry
+            const ScanRange& range = ranges[first_range + r];
+            const uint32_t begin = range.compact->escape_first[range.pos_begin];
+            const uint32_t count = range.compact->escape_first[range.pos_end] - begin;
+            if (count == 0) {
+               continue;
+            }
+            ScanBatchArgs escapes = batch;
+            for (uint32_t q = 0; q < n; ++q) {
+               escapes.counts[0][q] = batch.counts[r][q];
+            }
+            k_scan_escapes<<<dim3((count + 255) / 256, n), 256, 0, hip_stream>>>(range.compact->escapes + begin, count, escapes, range.pos_begin);
+            HIP_TRY(hipGetLastError());
          }
       }
    }
@@ -1890,6 +2071,111 @@ int scanRanges(
    return rc;
 }
 
+/// finalize(): derive the compact scan index of one sequence store (see K1i above) — or leave the store without one
+/// when it would not pay (short rows), would not be compact (too many escapes) or would not fit.
+int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   const SeqStoreDev& dev = seqstore.dev;
+   SeqStoreHost::CompactIndex& compact = seqstore.compact;
+   compact.ready = false;
+   (void)hipFree(compact.planes);
+   (void)hipFree(compact.code_map);
+   (void)hipFree(compact.escapes);
+   compact.planes = nullptr;
+   compact.code_map = nullptr;
+   compact.escapes = nullptr;
+   const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
+   if ((!nucleotide && !(dev.n_bits == 5 && dev.n_scan == 22)) || dev.row_words < SCAN_THREADS * 4 || dev.positions == 0 ||
+       store->sequence_count == 0 || g_tune_compact_index.load() < 0) {
+      return SILO_GPU_OK;
+   }
+   // the unfiltered totals decide the codes (and are what a full filter adds later on)
+   const size_t n_totals = static_cast<size_t>(dev.positions) * dev.n_scan;
+   if (seqstore.d_totals == nullptr) {
+      HIP_TRY(hipMalloc(&seqstore.d_totals, n_totals * sizeof(uint32_t)));
+   }
+   if (!seqstore.totals_ready) {
+      HIP_TRY(hipMemsetAsync(seqstore.d_totals, 0, n_totals * sizeof(uint32_t), nullptr));
+      ScanRange all{&dev, 0, dev.positions, {}, nullptr};
+      all.counts[0] = seqstore.d_totals;
+      const uint64_t* ones = store->d_ones;
+      const int rc = scanRanges(store, {all}, &ones, 1, nullptr);
+      if (rc != SILO_GPU_OK) {
+         return rc;
+      }
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      seqstore.totals_ready = true;
+   }
+   uint32_t* d_count = nullptr;  // escapes per position, later the cursors of the encoder
+   HIP_TRY(hipMalloc(&compact.code_map, static_cast<size_t>(dev.positions) * 4));
+   HIP_TRY(hipMalloc(&d_count, static_cast<size_t>(dev.positions + 1) * sizeof(uint32_t)));
+   k_choose_codes<<<(dev.positions + 255) / 256, 256>>>(seqstore.d_totals, dev.n_scan, dev.positions, compact.code_map, d_count);
+   std::vector<uint32_t> counts(dev.positions);
+   hipError_t status = hipMemcpy(counts.data(), d_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+   uint64_t total = 0;
+   compact.escape_first.assign(dev.positions + 1, 0);
+   for (uint32_t p = 0; p < dev.positions; ++p) {
+      compact.escape_first[p] = static_cast<uint32_t>(total);
+      total += counts[p];
+   }
+   compact.escape_first[dev.positions] = static_cast<uint32_t>(total);
+   const size_t plane_bytes = static_cast<size_t>(dev.positions) * 2 * dev.row_words * sizeof(uint64_t);
+   const size_t escape_bytes = std::max<uint64_t>(total, 1) * sizeof(uint64_t);
+   size_t free_bytes = 0, total_bytes = 0;
+   if (status == hipSuccess) {
+      status = hipMemGetInfo(&free_bytes, &total_bytes);
+   }
+   const size_t reserve = std::min<size_t>(size_t{40} << 30, total_bytes / 4);  // derived-plane cache, query buffers, the next store
+   const bool worth_it = total * COMPACT_ESCAPE_DIVISOR <= static_cast<uint64_t>(store->sequence_count) * dev.positions && total < (uint64_t{1} << 32);
+   if (status != hipSuccess || !worth_it || free_bytes < plane_bytes + escape_bytes + reserve) {
+      (void)hipFree(d_count);
+      (void)hipFree(compact.code_map);
+      compact.code_map = nullptr;
+      compact.escape_first.clear();
+      HIP_TRY(status);
+      return SILO_GPU_OK;  // the full code planes serve the scan
+   }
+   uint32_t* d_first = nullptr;
+   status = hipMalloc(&compact.planes, plane_bytes);
+   if (status == hipSuccess) {
+      status = hipMalloc(&compact.escapes, escape_bytes);
+   }
+   if (status == hipSuccess) {
+      status = hipMalloc(&d_first, compact.escape_first.size() * sizeof(uint32_t));
+   }
+   if (status == hipSuccess) {
+      status = hipMemcpy(d_first, compact.escape_first.data(), compact.escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+   }
+   if (status == hipSuccess) {
+      status = hipMemset(d_count, 0, static_cast<size_t>(dev.positions + 1) * sizeof(uint32_t));
+   }
+   if (status == hipSuccess) {
+      const dim3 grid((dev.row_words + 255) / 256, dev.positions);
+      if (nucleotide) {
+         k_encode_compact<3><<<grid, 256>>>(dev.scan, dev.row_words, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
+      } else {
+         k_encode_compact<5><<<grid, 256>>>(dev.scan, dev.row_words, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
+      }
+      status = hipGetLastError();
+   }
+   if (status == hipSuccess) {
+      status = hipDeviceSynchronize();
+   }
+   (void)hipFree(d_first);
+   (void)hipFree(d_count);
+   if (status != hipSuccess) {
+      (void)hipFree(compact.planes);
+      (void)hipFree(compact.escapes);
+      (void)hipFree(compact.code_map);
+      compact.planes = nullptr;
+      compact.escapes = nullptr;
+      compact.code_map = nullptr;
+      HIP_TRY(status);
+   }
+   store->device_bytes += plane_bytes + escape_bytes + static_cast<size_t>(dev.positions) * 4;
+   compact.ready = true;
+   return SILO_GPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1936,7 +2222,8 @@ int silo_gpu_mutations_scan_ranges(
             if (ranges[r].pos_begin == ranges[r].pos_end || dev.n_scan == 0 || (dev.n_bits == 3 ? 3u : 5u) != n_bits) {
                continue;
             }
-            ScanRange range{&dev, ranges[r].pos_begin, ranges[r].pos_end, {}};
+            const SeqStoreHost& seqstore = store->seqstores[ranges[r].seqstore_id];
+            ScanRange range{&dev, ranges[r].pos_begin, ranges[r].pos_end, {}, seqstore.compact.ready ? &seqstore.compact : nullptr};
             for (uint32_t q = 0; q < q_count; ++q) {
                range.counts[q] = counts_out_dev[static_cast<size_t>(r) * n_filters + first + q];
             }
@@ -1962,6 +2249,21 @@ int silo_gpu_mutations_scan_batch(
    }
    const silo_gpu_scan_range range{seqstore_id, pos_begin, pos_end};
    return silo_gpu_mutations_scan_ranges(store, &range, 1, filters_dev, n_filters, counts_out_dev, stream);
+}
+
+uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size()) {
+      return 0;
+   }
+   const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   return seqstore.compact.ready && g_tune_compact_index.load() >= 0 ? 2 : seqstore.dev.n_bits;
+}
+
+uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || !store->seqstores[seqstore_id].compact.ready) {
+      return 0;
+   }
+   return store->seqstores[seqstore_id].compact.escape_first.back();
 }
 
 int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) {

@@ -254,6 +254,70 @@ def test_sparse_filters_take_the_gather_scan_and_give_the_same_tables(built, n, 
         store.tune(3, 0)
 
 
+def skewed_symbols(rng, n, positions, alphabet):
+    """Alignment-like columns: per position a dominant symbol (97.2 %), a second (1.5 %) and a third (0.8 %) valid symbol,
+    0.03 % spread over the remaining valid symbols, 0.5 % missing / ambiguous."""
+    from silo_amd import alphabet as alphabets
+
+    table = alphabets.NUCLEOTIDE if alphabet == "nuc" else alphabets.AMINO_ACID
+    valid = np.array(list(table.valid_mutation_symbols))
+    others = np.array([s for s in range(table.count) if s not in set(valid.tolist())])
+    out = np.empty((n, positions), dtype=np.uint8)
+    for p in range(positions):
+        order = rng.permutation(valid)
+        probs = np.zeros(table.count)
+        probs[order[0]], probs[order[1]], probs[order[2]] = 0.9717, 0.015, 0.008
+        probs[order[3:]] = 0.0003 / (len(valid) - 3)
+        probs[others] = 0.005 / len(others)
+        out[:, p] = rng.choice(table.count, size=n, p=probs / probs.sum())
+    return out
+
+
+@pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc")])
+def test_compact_scan_index_gives_the_same_tables(built, n, alphabet):
+    """K1i: on alignment-like data finalize() builds the 2-plane scan index with its escape keys; the scan through it
+    (single, batched, sub-ranges, sparse filters, several ranges) equals the naive counts and the scan of the full planes."""
+    rng = np.random.default_rng(n + 17)
+    positions = 29
+    sym = skewed_symbols(rng, n, positions, alphabet)
+    sym2 = skewed_symbols(rng, n, 11, alphabet)
+    chars = NUC_CHARS if alphabet == "nuc" else AA_CHARS
+    with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:
+        store.append_sequences(0, 0, chars[sym])
+        store.append_sequences(1, 0, chars[sym2])
+        store.finalize()
+        scan_symbols = list(store.scan_symbols[0])
+        assert store.scan_planes(0) == 2 and store.scan_planes(1) == 2
+        escapes = store.scan_escapes(0)
+        valid = np.isin(sym, scan_symbols)
+        assert 0 < escapes <= n * positions // 512
+        sparse = np.zeros(n, bool)
+        sparse[rng.choice(n, size=9, replace=False)] = True
+        masks = [rng.random(n) < 0.4, sparse, np.ones(n, bool), rng.random(n) < 0.02, np.zeros(n, bool)]
+        ptrs = []
+        for mask in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            ptrs.append(ptr)
+        want = [dense.mutation_counts(sym, mask, scan_symbols) for mask in masks]
+        want2 = [dense.mutation_counts(sym2, mask, scan_symbols) for mask in masks]
+        assert int(want[2].sum()) == int(valid.sum())
+        for knob in (0, -1):  # through the index, then through the full code planes
+            store.tune(4, knob)
+            assert store.scan_planes(0) == (2 if knob == 0 else (3 if alphabet == "nuc" else 5))
+            for ptr, table in zip(ptrs, want):
+                assert np.array_equal(store.mutations_scan(0, ptr), table), knob
+            assert np.array_equal(store.mutations_scan(0, None), want[2])
+            for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
+                assert np.array_equal(got, table), knob
+            assert np.array_equal(store.mutations_scan(0, ptrs[0], 3, 20), dense.mutation_counts(sym, masks[0], scan_symbols, 3, 20))
+            tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6)], ptrs[:3])
+            for q in range(3):
+                assert np.array_equal(tables[0][q], want[q]) and np.array_equal(tables[1][q], want2[q])
+                assert np.array_equal(tables[2][q], want[q][5:6])
+        store.tune(4, 0)
+
+
 @pytest.mark.parametrize("n", [900, 140000])
 def test_scan_over_several_ranges_in_one_call(built, n):
     """silo_gpu_mutations_scan_ranges: every filter over ranges of nucleotide and amino-acid stores of different lengths

@@ -39,6 +39,8 @@ for gene in genes:
     binding._check(lib.silo_gpu_memset_async(table, 0, 4 * lengths[-1] * 22, None))
     tables.append(table)
 
+print("scan planes per position:", {gene["name"]: (int(lib.silo_gpu_store_scan_planes(store.handle, sid)), int(lib.silo_gpu_store_scan_escapes(store.handle, sid)))
+                                    for gene, sid in zip(genes, ids)}, flush=True)
 start, stop = binding.GpuEvent(), binding.GpuEvent()
 total_single = 0.0
 for gene, sid, length, table in zip(genes, ids, lengths, tables):
