@@ -494,7 +494,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
-            if name.startswith("k_scan_sliced") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * scan_planes:
+            if name.startswith(f"k_scan_sliced<{scan_planes},") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * scan_planes:
                 traffic = entry["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         pass
@@ -567,6 +567,12 @@ def main():
         aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
                                "filterExpression": json.loads(query)["filterExpression"]})
         aa_positions = sum(len(g["sequence"]) for g in load_reference_genomes(True)["genes"])
+
+        def aa_planes(engine):
+            """Plane rows per position the scan reads for every gene: 2 with a compact scan index (K1i), else 5."""
+            handle = engine.partition_store(0).handle
+            return {g["name"]: int(lib.silo_gpu_store_scan_planes(handle, engine.seqstore_id(0, g["name"], True))) for g in load_reference_genomes(True)["genes"]}
+
         engine_aa = build_engine(args.sequences, 0, 1, None, local_rank, with_genes=True, nuc_positions=64)[0]
         elapsed_aa_full, rows_aa_full = run_steps(engine_aa, aa_query, args.steps, args.warmup, sync)
         w8_full = 8 * ((args.sequences + 63) // 64)
@@ -576,8 +582,8 @@ def main():
             "unit": "positions*sequences/s",
             "ms_per_step": elapsed_aa_full / args.steps * 1e3,
             "algorithmic_GBps_whole_query": aa_positions * 22 * w8_full / (elapsed_aa_full / args.steps) / 1e9,
-            "scan_planes_per_position": int(lib.silo_gpu_store_scan_planes(engine_aa.partition_store(0).handle, engine_aa.seqstore_id(0, "S", True))),
-            "physical_GBps_whole_query": aa_positions * int(lib.silo_gpu_store_scan_planes(engine_aa.partition_store(0).handle, engine_aa.seqstore_id(0, "S", True)))
+            "scan_planes_per_gene": aa_planes(engine_aa),
+            "physical_GBps_whole_query": sum(len(g["sequence"]) * aa_planes(engine_aa)[g["name"]] for g in load_reference_genomes(True)["genes"])
                                          * w8_full / (elapsed_aa_full / args.steps) / 1e9,
             "mutation_rows": len(rows_aa_full),
         }
@@ -595,7 +601,7 @@ def main():
             "unit": "positions*sequences/s",
             "ms_per_step": elapsed_aa / args.steps * 1e3,
             "algorithmic_GBps_whole_query": aa_bytes / (elapsed_aa / args.steps) / 1e9,
-            "physical_GBps_whole_query": aa_positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, engine1.seqstore_id(0, "S", True)))
+            "physical_GBps_whole_query": sum(len(g["sequence"]) * aa_planes(engine1)[g["name"]] for g in load_reference_genomes(True)["genes"])
                                          * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
             "mutation_rows": len(rows_aa),
         }
