@@ -632,11 +632,15 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
          low[2] = bits[g][1] & ~bits[g][0] & filter_word;
          low[3] = bits[g][1] & bits[g][0] & filter_word;
          uint64_t high[BITS <= 3 ? 2 : 8];
-         if constexpr (BITS == 3) {
+         if constexpr (BITS == 2) {
+            static_assert(NSYM == 3, "two code planes carry three codes");
+            high[0] = ~0ull;  // compact scan index: the codes are the low pair
+            high[1] = 0;
+         } else if constexpr (BITS == 3) {
             high[0] = ~bits[g][2];
             high[1] = bits[g][2];
          } else {
-            static_assert(BITS == 5, "decode tree written for 3 or 5 code bits");
+            static_assert(BITS == 5, "decode tree written for 2, 3 or 5 code bits");
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                high[k] = ((k & 1) != 0 ? bits[g][2] : ~bits[g][2]) & ((k & 2) != 0 ? bits[g][3] : ~bits[g][3]) &
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
 #pragma unroll
          for (int symbol = 0; symbol < NSYM; ++symbol) {
             const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
-            acc[g][symbol] += static_cast<uint32_t>(__popcll(low[code & 3u] & high[code >> 2]));
+            acc[g][symbol] += static_cast<uint32_t>(__popcll(BITS == 2 ? low[code & 3u] : (low[code & 3u] & high[code >> 2])));
          }
       }
    }
@@ -656,7 +660,12 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
       for (int symbol = 0; symbol < NSYM; ++symbol) {
          const uint32_t total = waveSumToLane63(acc[g][symbol]);
          if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
-            atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
+            if constexpr (BITS == 2) {  // code -> the symbol it stands for at this position
+               const uint32_t mapped = batch.code_map[range][static_cast<size_t>(pos_begin + g) * 4 + 1 + symbol];
+               atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * batch.out_symbols + mapped], total);
+            } else {
+               atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
+            }
          }
       }
    }
@@ -752,10 +761,7 @@ __global__ __launch_bounds__(256) void k_encode_compact(
 __global__ __launch_bounds__(256) void k_scan_escapes(
    const uint64_t* __restrict__ escapes, uint32_t n_escapes, const ScanBatchArgs batch, uint32_t pos_begin
 ) {
-   const uint32_t q = blockIdx.y;
-   if (batch.sparse_sectors != nullptr && batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE] <= batch.sparse_capacity) {
-      return;  // this filter went to the gather kernel, which reads the full planes
-   }
+   const uint32_t q = blockIdx.y;  // every filter: dense scan and sparse-filter gather of an indexed range both read the two planes
    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
    const uint32_t lane = threadIdx.x & 63u;
    const uint64_t key = i < n_escapes ? escapes[i] : 0;
@@ -1801,7 +1807,8 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    }
    const bool medium = variant == 14 && BITS <= 3 && q_count == 1;  // experiment: 6 words per thread
    const bool narrow = variant == 16 && BITS == 5 && q_count == 1;  // experiment: 2 words per thread (amino acids, more waves per SIMD)
-   const uint32_t tile_words = SCAN_THREADS * (narrow ? 2 : (medium ? 6 : (wide ? 8 : 4)));
+   const int extra_wide = BITS == 2 && q_count == 1 && variant == 18 ? 12 : 0;  // experiment: 12 words per thread
+   const uint32_t tile_words = SCAN_THREADS * (extra_wide != 0 ? extra_wide : (narrow ? 2 : (medium ? 6 : (wide ? 8 : 4))));
    int positions_per_block = g_tune_rows_per_block.load();
    const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    uint64_t total_positions = 0;
@@ -1821,7 +1828,11 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    const dim3 grid(batch.first_unit[batch.n_ranges]);
 #define SILO_LAUNCH_SLICED(WPT, Q) \
    k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
-   if (narrow) {
+   if (extra_wide != 0) {
+      if constexpr (BITS == 2) {
+         SILO_LAUNCH_SLICED(12, 1);
+      }
+   } else if (narrow) {
       if constexpr (BITS == 5) {
          SILO_LAUNCH_SLICED(2, 1);
       }
@@ -2048,24 +2059,39 @@ int scanRanges(
       );
       rc = scanRangesDense(ranges, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
    }
-   for (size_t first_range = 0; rc == SILO_GPU_OK && first_range < ranges.size(); first_range += SCAN_MAX_RANGES) {
-      ScanBatchArgs batch{};
-      batch.n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, ranges.size() - first_range));
-      batch.sparse_sectors = scratch->sparse_sectors;
-      batch.sparse_capacity = capacity;
-      for (uint32_t q = 0; q < q_count; ++q) {
-         batch.filters[q] = filters[q];
-      }
-      for (uint32_t r = 0; r < batch.n_ranges; ++r) {
-         const ScanRange& range = ranges[first_range + r];
-         batch.planes[r] = scanPlanes(*range.dev, range.pos_begin);
-         batch.n_positions[r] = range.pos_end - range.pos_begin;
-         for (uint32_t q = 0; q < q_count; ++q) {
-            batch.counts[r][q] = range.counts[q];
+   // the gather over the sectors of the sparse filters: ranges with a compact scan index read its two planes (their escape
+   // keys were added for every filter above), the others the full planes
+   const bool allow_compact = g_tune_compact_index.load() >= 0;
+   for (const bool indexed : {true, false}) {
+      std::vector<const ScanRange*> group;
+      for (const ScanRange& range : ranges) {
+         if ((allow_compact && range.compact != nullptr) == indexed) {
+            group.push_back(&range);
          }
       }
-      rc = nucleotide ? launchGatherScan<3, 5, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
-                      : launchGatherScan<5, 22, 2>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream);
+      for (size_t first_range = 0; rc == SILO_GPU_OK && first_range < group.size(); first_range += SCAN_MAX_RANGES) {
+         ScanBatchArgs batch{};
+         batch.n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, group.size() - first_range));
+         batch.sparse_sectors = scratch->sparse_sectors;
+         batch.sparse_capacity = capacity;
+         batch.out_symbols = layout.n_scan;
+         for (uint32_t q = 0; q < q_count; ++q) {
+            batch.filters[q] = filters[q];
+         }
+         for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+            const ScanRange& range = *group[first_range + r];
+            batch.planes[r] = indexed ? range.compact->planes + static_cast<size_t>(range.pos_begin) * 2 * layout.row_words
+                                      : scanPlanes(*range.dev, range.pos_begin);
+            batch.code_map[r] = indexed ? range.compact->code_map + static_cast<size_t>(range.pos_begin) * 4 : nullptr;
+            batch.n_positions[r] = range.pos_end - range.pos_begin;
+            for (uint32_t q = 0; q < q_count; ++q) {
+               batch.counts[r][q] = range.counts[q];
+            }
+         }
+         rc = indexed      ? launchGatherScan<2, 3, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
+              : nucleotide ? launchGatherScan<3, 5, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
+                           : launchGatherScan<5, 22, 2>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream);
+      }
    }
    releaseSparseScratch(scratch, hip_stream);
    return rc;
