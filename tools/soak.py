@@ -41,6 +41,13 @@ queries.append(json.dumps({"action": {"type": "AminoAcidMutations", "minProporti
                            "filterExpression": {"type": "Not", "child": lineage_filter("B.1")}}))
 queries.append(json.dumps({"action": {"type": "Aggregated", "groupByFields": ["country", "age"], "orderByFields": ["count", "country", "age"], "limit": 20},
                            "filterExpression": {"type": "Maybe", "child": {"type": "NucleotideEquals", "position": 241, "symbol": "T"}}}))
+# selective filters: single deep lineages (a few hundred rows) go through the sparse-filter gather (K1s), whose scratch
+# blocks are pooled across the client threads
+deep = sorted((name for name in tree.names if name.count(".") >= 5), key=len)[-6:]
+for name in deep:
+    exact = {"type": "PangoLineage", "column": "pango_lineage", "value": name, "includeSublineages": False}
+    queries.append(json.dumps({"action": {"type": "Mutations", "minProportion": 0.05}, "filterExpression": exact}))
+    queries.append(json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05}, "filterExpression": exact}))
 queries = [q.encode() for q in queries]
 expected = [engine.execute_text(q) for q in queries]
 assert all(status == 200 for status, _ in expected), [body for status, body in expected if status != 200][:1]
