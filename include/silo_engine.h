@@ -98,7 +98,10 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
 
 /* Tunables.  "mutation_row_capacity": Mutations / AminoAcidMutations select their result rows on the device into a
  * list of this many cells per query (default 4096); a query selecting more fetches the whole count table
- * and selects on the host; 0 = always the host selection.  Results are identical either way.  Unknown name: error. */
+ * and selects on the host; 0 = always the host selection.  Results are identical either way.
+ * "compact_scan_index" (1 default / 0): whether silo_engine_finalize derives — and the Mutations scans read — the compact
+ * scan index of the sequence stores (include/silo_gpu.h, K1i: +50 % HBM for the stores, the scan 1.5x faster for
+ * nucleotides and up to 2.5x for amino acids); a process-wide setting of the device library.  Unknown name: error. */
 int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value);
 
 /* Executes one query.  *out_json is malloc'ed (free with silo_engine_free_string) and holds either the

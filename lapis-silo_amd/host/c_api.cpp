@@ -319,6 +319,12 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
       engine->database.mutation_row_capacity = static_cast<uint32_t>(value);
       return 0;
    }
+   if (std::strcmp(name, "compact_scan_index") == 0 && (value == 0 || value == 1)) {
+      // process-wide (the device library's knob): 0 before silo_engine_finalize = no index is built (saves a third of the
+      // sequence stores' HBM); 0 afterwards = built indexes are not scanned
+      (void)silo_gpu_tune(SILO_GPU_TUNE_COMPACT_INDEX, value == 1 ? 0 : -1);
+      return 0;
+   }
    return fail(SILO_GPU_ERR_INVALID_ARGUMENT, std::string("silo_engine_set_option: unknown option or bad value: ") + name);
 }
 

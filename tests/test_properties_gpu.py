@@ -135,3 +135,28 @@ def test_empty_database_and_empty_partition(built):
         assert got[0] == [{"count": 2}] and got[1] == [{"count": 1}]
         assert got[2] == []                    # the only non-null genome equals the reference
         assert got[3] == [{"count": 1, "mutation": "K2R", "proportion": 0.5, "sequenceName": "S"}]
+
+
+def test_compact_scan_index_option(built):
+    """silo_engine_set_option("compact_scan_index", 0) before finalize: no index is built (2/3 of the HBM), same answers."""
+    import bench
+    from silo_amd import binding
+    from silo_amd.engine import Engine
+
+    lib = binding.load_library()
+    query = json.dumps({"action": {"type": "Mutations", "minProportion": 0.02},
+                        "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.2", "includeSublineages": True}}).encode()
+    answers, sizes = [], []
+    try:
+        for enabled in (1, 0):
+            with Engine({"nucleotideSequences": [{"name": "main", "sequence": "ACGT"}], "genes": []}) as any_engine:
+                any_engine.set_option("compact_scan_index", enabled)  # a process-wide setting of the device library
+            with bench.build_engine(200_000, 0, 1, None, 0)[0] as engine:
+                store = engine.partition_store(0)
+                sizes.append(store.device_bytes)
+                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (2 if enabled else 3)
+                answers.append(engine.execute_text(query))
+    finally:
+        lib.silo_gpu_tune(4, 0)
+    assert answers[0] == answers[1] and answers[0][0] == 200
+    assert sizes[0] > 1.4 * sizes[1]
