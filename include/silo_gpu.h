@@ -319,7 +319,7 @@ int silo_gpu_mutations_scan(
 /* K1i, the compact scan index.  silo_gpu_store_finalize derives, per sequence store, two code planes per position (code
  * 1..3 = the three most frequent valid symbols AT THAT POSITION, 0 = anything else) plus the few rows whose valid symbol
  * is none of the three as explicit keys; the Mutations scan streams those 2 planes instead of the 3 / 5 full code planes
- * and adds the exceptions in one small pass — same counts.  Built only when the exceptions stay below 1/512 of the cells
+ * and adds the exceptions in one small pass — same counts.  Built only when the exceptions stay below 1/512 (nucleotides) or 1/170 (amino acids) of the cells
  * and the device memory is there (otherwise, and for every other consumer, the full planes serve).
  * silo_gpu_store_scan_planes: plane rows the scan reads per position (2 with the index, else 3 / 5);
  * silo_gpu_store_scan_escapes: number of exception keys (0 without the index). */

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
 // explicit keys ("escapes", grouped by position).  The Mutations scan then streams 2 planes instead of 3 (nucleotides)
 // or 5 (amino acids) and adds the escapes with one small pass; every other consumer (filter leaves, FastaAligned, the
 // sparse-filter gather, the totals) keeps reading the full code planes, which also remain the fallback: the index is
-// only built when the escapes stay below 1/512 of the cells and the memory is there.
+// only built when the escapes stay below 1/512 (nucleotides; 1/170 for amino acids) of the cells and the memory is there.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_choose_codes(
    const uint32_t* __restrict__ totals, uint32_t n_scan, uint32_t positions, uint8_t* __restrict__ code_map, uint32_t* __restrict__ escape_count
@@ -2151,7 +2151,9 @@ int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
       status = hipMemGetInfo(&free_bytes, &total_bytes);
    }
    const size_t reserve = std::min<size_t>(size_t{40} << 30, total_bytes / 4);  // derived-plane cache, query buffers, the next store
-   const bool worth_it = total * COMPACT_ESCAPE_DIVISOR <= static_cast<uint64_t>(store->sequence_count) * dev.positions && total < (uint64_t{1} << 32);
+   // the budget grows with the planes the index saves per position: 1 of 3 (nucleotides), 3 of 5 (amino acids)
+   const uint64_t divisor = COMPACT_ESCAPE_DIVISOR / (dev.n_bits - 2);
+   const bool worth_it = total * divisor <= static_cast<uint64_t>(store->sequence_count) * dev.positions && total < (uint64_t{1} << 32);
    if (status != hipSuccess || !worth_it || free_bytes < plane_bytes + escape_bytes + reserve) {
       (void)hipFree(d_count);
       (void)hipFree(compact.code_map);
