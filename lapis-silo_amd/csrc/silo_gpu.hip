@@ -161,7 +161,7 @@ struct SeqStoreHost {
    struct CompactIndex {
       uint64_t* planes = nullptr;        // [positions][2][row_words]
       uint8_t* code_map = nullptr;       // [positions][4]
-      uint64_t* escapes = nullptr;       // position << 37 | scan symbol index << 32 | sequence, grouped by position
+      uint64_t* escapes = nullptr;       // position << 37 | scan symbol index << 32 | sequence, grouped by (position, symbol)
       std::vector<uint32_t> escape_first;  // [positions + 1], host copy of the prefix
       bool ready = false;
    } compact;
@@ -690,10 +690,8 @@ __global__ __launch_bounds__(256) void k_choose_codes(
    }
    uint32_t best_count[3] = {0, 0, 0};
    uint32_t best_symbol[3] = {0xFFu, 0xFFu, 0xFFu};
-   uint64_t sum = 0;
    for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
       const uint32_t count = totals[static_cast<size_t>(p) * n_scan + symbol];
-      sum += count;
       if (count > best_count[0]) {  // strictly greater: ties keep the lower symbol index in front
          best_count[2] = best_count[1], best_symbol[2] = best_symbol[1];
          best_count[1] = best_count[0], best_symbol[1] = best_symbol[0];
@@ -709,13 +707,17 @@ __global__ __launch_bounds__(256) void k_choose_codes(
    for (int c = 0; c < 3; ++c) {
       code_map[static_cast<size_t>(p) * 4 + 1 + c] = static_cast<uint8_t>(best_symbol[c]);
    }
-   escape_count[p] = static_cast<uint32_t>(sum - best_count[0] - best_count[1] - best_count[2]);
+   // rows that become escape keys, per (position, symbol): exactly the totals of the symbols that got no code
+   for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+      const bool coded = symbol == best_symbol[0] || symbol == best_symbol[1] || symbol == best_symbol[2];
+      escape_count[static_cast<size_t>(p) * n_scan + symbol] = coded ? 0u : totals[static_cast<size_t>(p) * n_scan + symbol];
+   }
 }
 
 template <int BITS>
 __global__ __launch_bounds__(256) void k_encode_compact(
-   const uint64_t* __restrict__ scan, uint32_t row_words, const uint8_t* __restrict__ code_map, const uint32_t* __restrict__ escape_first,
-   uint32_t* __restrict__ escape_cursor, uint64_t* __restrict__ planes, uint64_t* __restrict__ escapes
+   const uint64_t* __restrict__ scan, uint32_t row_words, uint32_t n_scan, const uint8_t* __restrict__ code_map,
+   const uint32_t* __restrict__ escape_first, uint32_t* __restrict__ escape_cursor, uint64_t* __restrict__ planes, uint64_t* __restrict__ escapes
 ) {
    const uint32_t p = blockIdx.y;
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -752,7 +754,9 @@ __global__ __launch_bounds__(256) void k_encode_compact(
       for (int bit = 0; bit < BITS; ++bit) {
          code |= static_cast<uint32_t>((bits[bit] >> row_bit) & 1ull) << bit;
       }
-      const uint32_t slot = escape_first[p] + atomicAdd(escape_cursor + p, 1u);
+      // the keys of one (position, symbol) sit together: k_scan_escapes then needs one atomic per wave and counter
+      const size_t counter = static_cast<size_t>(p) * n_scan + (code - 1u);
+      const uint32_t slot = escape_first[counter] + atomicAdd(escape_cursor + counter, 1u);
       escapes[slot] = (static_cast<uint64_t>(p) << 37) | (static_cast<uint64_t>(code - 1u) << 32) | (static_cast<uint64_t>(w) * 64u + row_bit);
    }
 }
@@ -2131,18 +2135,24 @@ int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
       HIP_TRY(hipStreamSynchronize(nullptr));
       seqstore.totals_ready = true;
    }
-   uint32_t* d_count = nullptr;  // escapes per position, later the cursors of the encoder
+   uint32_t* d_count = nullptr;  // escapes per (position, symbol), later the cursors of the encoder
+   const size_t n_counters = n_totals;
    HIP_TRY(hipMalloc(&compact.code_map, static_cast<size_t>(dev.positions) * 4));
-   HIP_TRY(hipMalloc(&d_count, static_cast<size_t>(dev.positions + 1) * sizeof(uint32_t)));
+   HIP_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
    k_choose_codes<<<(dev.positions + 255) / 256, 256>>>(seqstore.d_totals, dev.n_scan, dev.positions, compact.code_map, d_count);
-   std::vector<uint32_t> counts(dev.positions);
+   std::vector<uint32_t> counts(n_counters);
    hipError_t status = hipMemcpy(counts.data(), d_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
    uint64_t total = 0;
+   std::vector<uint32_t> counter_first(n_counters + 1, 0);  // slot of the first key of every (position, symbol)
    compact.escape_first.assign(dev.positions + 1, 0);
-   for (uint32_t p = 0; p < dev.positions; ++p) {
-      compact.escape_first[p] = static_cast<uint32_t>(total);
-      total += counts[p];
+   for (size_t k = 0; k < n_counters; ++k) {
+      if (k % dev.n_scan == 0) {
+         compact.escape_first[k / dev.n_scan] = static_cast<uint32_t>(total);
+      }
+      counter_first[k] = static_cast<uint32_t>(total);
+      total += counts[k];
    }
+   counter_first[n_counters] = static_cast<uint32_t>(total);
    compact.escape_first[dev.positions] = static_cast<uint32_t>(total);
    const size_t plane_bytes = static_cast<size_t>(dev.positions) * 2 * dev.row_words * sizeof(uint64_t);
    const size_t escape_bytes = std::max<uint64_t>(total, 1) * sizeof(uint64_t);
@@ -2168,20 +2178,20 @@ int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
       status = hipMalloc(&compact.escapes, escape_bytes);
    }
    if (status == hipSuccess) {
-      status = hipMalloc(&d_first, compact.escape_first.size() * sizeof(uint32_t));
+      status = hipMalloc(&d_first, counter_first.size() * sizeof(uint32_t));
    }
    if (status == hipSuccess) {
-      status = hipMemcpy(d_first, compact.escape_first.data(), compact.escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      status = hipMemcpy(d_first, counter_first.data(), counter_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
    }
    if (status == hipSuccess) {
-      status = hipMemset(d_count, 0, static_cast<size_t>(dev.positions + 1) * sizeof(uint32_t));
+      status = hipMemset(d_count, 0, n_counters * sizeof(uint32_t));
    }
    if (status == hipSuccess) {
       const dim3 grid((dev.row_words + 255) / 256, dev.positions);
       if (nucleotide) {
-         k_encode_compact<3><<<grid, 256>>>(dev.scan, dev.row_words, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
+         k_encode_compact<3><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
       } else {
-         k_encode_compact<5><<<grid, 256>>>(dev.scan, dev.row_words, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
+         k_encode_compact<5><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
       }
       status = hipGetLastError();
    }
