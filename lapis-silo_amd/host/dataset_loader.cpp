@@ -534,28 +534,54 @@ std::vector<std::string> splitTabs(const std::string& line) {
    }
 }
 
-std::unordered_map<std::string, std::string> readFasta(const std::string& path) {  // common/fasta_reader.cpp
+std::unordered_map<std::string, std::string> readFasta(const std::string& path) {  // common/fasta_reader.cpp:11-47
+   // The reference reads strict two-line records (key line, genome line) and throws FastaFormatException for a key line
+   // without '>' or a key without a genome line; sequences wrapped over several lines are accepted here in addition.
    std::unordered_map<std::string, std::string> out;
    LineReader reader(path);
    std::string line;
    std::string* current = nullptr;
+   std::string current_key;
+   bool current_has_genome = true;
    while (reader.next(line)) {
       if (line.empty()) {
          continue;
       }
       if (line.front() == '>') {
-         current = &out[line.substr(1)];
+         if (!current_has_genome) {
+            throw PreprocessingException("Missing genome sequence in line following key: " + current_key);
+         }
+         current_key = line.substr(1);
+         current = &out[current_key];
          current->clear();
+         current_has_genome = false;
       } else if (current != nullptr) {
          current->append(line);
+         current_has_genome = true;
       } else {
-         throw PreprocessingException("Fasta file " + path + " does not start with '>'");
+         throw PreprocessingException("Fasta key prefix '>' missing for key: " + line);
       }
+   }
+   if (!current_has_genome) {
+      throw PreprocessingException("Missing genome sequence in line following key: " + current_key);
    }
    return out;
 }
 
 }  // namespace
+
+std::string describeFasta(const std::string& path) {
+   std::vector<std::pair<std::string, std::string>> records;
+   for (auto& [key, genome] : readFasta(path)) {
+      records.emplace_back(key, std::move(genome));
+   }
+   std::sort(records.begin(), records.end());
+   json::Value::Array out;
+   for (const auto& [key, genome] : records) {
+      out.emplace_back(json::Value::Array{json::Value(key), json::Value(genome)});
+   }
+   return json::Value(std::move(out)).dump();
+}
 
 std::string describeDatabaseConfig(const std::string& path, bool validate) {
    const DatabaseSchema schema = readDatabaseConfig(path);

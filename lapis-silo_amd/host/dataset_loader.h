@@ -43,6 +43,10 @@ struct DatasetSummary {
 /// "generateIndex"}]}.  Throws PreprocessingException with the reference's message for an invalid config.
 std::string describeDatabaseConfig(const std::string& path, bool validate);
 
+/// The records of a FASTA file (plain / .zst / .xz) as the loader reads them, a JSON array of [key, genome] sorted by key;
+/// throws PreprocessingException with the reference's FastaFormatException messages (fasta_reader.cpp:11-47).
+std::string describeFasta(const std::string& path);
+
 /// Fills `database` (must be empty) from the files in `directory` and finalises it.
 DatasetSummary loadDataset(Database& database, const std::string& directory);
 

@@ -69,6 +69,16 @@ int t_describe_database_config(const char* path, int validate, char* out, size_t
    }
 }
 
+/// The records the loader reads from a FASTA file as JSON [[key, genome], ...] (return >= 0), or the error (return -1).
+int t_describe_fasta(const char* path, char* out, size_t capacity) {
+   try {
+      return copyOut(silo::preprocessing::describeFasta(path), out, capacity);
+   } catch (const std::exception& error) {
+      (void)copyOut(error.what(), out, capacity);
+      return -1;
+   }
+}
+
 /// Average microseconds to parse `query_json` into a Query (JSON -> Expression tree + Action), or -1 if it is invalid.
 double t_parse_query_us(const char* query_json, int repetitions) {
    try {

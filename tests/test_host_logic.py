@@ -128,6 +128,7 @@ def host_logic(built):
     lib.t_date_to_string.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
     lib.t_lineage.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.t_insertion_standardise.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.t_describe_fasta.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.t_describe_database_config.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     lib.alias_json = open(os.path.join(ROOT, "tests", "golden", "exampleDataset", "pangolineage_alias.json")).read().encode()
     lib.alias_dict = json.loads(lib.alias_json)
@@ -221,3 +222,18 @@ def test_database_config_reader_and_validation_vectors(host_logic):
                 assert [[c["name"], c["type"], c["generateIndex"]] for c in got["metadata"]] == value, case["cite"]
             else:
                 assert got[key] == value, (case["cite"], key)
+
+
+def test_fasta_reader_vectors(host_logic):
+    """fasta_reader.test.cpp on the reference's own fixture files, through the loader's FASTA reader."""
+    import json
+
+    directory = os.path.join(ROOT, "tests", "golden", "fasta")
+    buffer = ctypes.create_string_buffer(4096)
+    for case in json.load(open(os.path.join(directory, "fasta_vectors.json")))["cases"]:
+        status = host_logic.t_describe_fasta(os.path.join(directory, case["file"]).encode(), buffer, 4096)
+        text = buffer.value.decode()
+        if "error" in case:
+            assert status == -1 and case["error"] in text, (case["cite"], text)
+        else:
+            assert status >= 0 and json.loads(text) == case["records"], (case["cite"], text)
