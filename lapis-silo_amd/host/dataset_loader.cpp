@@ -680,11 +680,81 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
    if (from_ndjson) {  // preprocessor.cpp:87-131: one JSON object per line
       LineReader reader(input_path);
       std::string line;
-      while (reader.next(line)) {
-         if (line.find_first_not_of(" \t") == std::string::npos) {
-            continue;
+      bool first_record = true;
+      // One JSON object per record; normally one per line, but the reference's reader (DuckDB read_json) also takes objects
+      // spread over several lines (testBaseData/ndjsonFiles/oneline_*.json.zst): lines are joined until the braces balance.
+      const auto next_record = [&reader](std::string& record_text) {
+         record_text.clear();
+         std::string part;
+         int depth = 0;
+         bool in_string = false, escaped = false, seen_value = false;
+         while (reader.next(part)) {
+            if (record_text.empty() && part.find_first_not_of(" \t\r") == std::string::npos) {
+               continue;
+            }
+            if (record_text.empty() && part.size() > 2 && part.front() == '{' && part.back() == '}') {
+               record_text.swap(part);  // the usual case, one object per line: no need to look inside 30 kb of sequence text
+               return true;
+            }
+            for (const char c : part) {
+               if (in_string) {
+                  if (escaped) {
+                     escaped = false;
+                  } else if (c == '\\') {
+                     escaped = true;
+                  } else if (c == '"') {
+                     in_string = false;
+                  }
+               } else if (c == '"') {
+                  in_string = true;
+               } else if (c == '{' || c == '[') {
+                  ++depth;
+                  seen_value = true;
+               } else if (c == '}' || c == ']') {
+                  --depth;
+               }
+            }
+            record_text += part;
+            record_text += '\n';
+            if (depth <= 0 && (seen_value || !in_string)) {
+               return true;
+            }
          }
+         return !record_text.empty();
+      };
+      while (next_record(line)) {
          const json::Value record = json::parse(line);
+         if (first_record) {
+            // sequence_info.cpp:91-157 (SequenceInfo::validate): the sequence names of the FIRST record and of the
+            // reference genomes have to be the same sets
+            first_record = false;
+            const auto validate_names = [&](const char* section, const char* kind, const std::vector<std::pair<std::string, StoreWriter>>& writers) {
+               std::vector<std::string> in_file;
+               if (record.contains(section) && record[section].is_object()) {
+                  for (const auto& [name, value] : record[section].members()) {
+                     in_file.push_back(name);
+                  }
+               }
+               for (const std::string& name : in_file) {
+                  if (std::none_of(writers.begin(), writers.end(), [&](const auto& writer) { return writer.first == name; })) {
+                     throw PreprocessingException(
+                        std::string("The aligned ") + kind + " sequence " + name + " which is contained in the input file " + input_path +
+                        " is not contained in the reference sequences."
+                     );
+                  }
+               }
+               for (const auto& [name, writer] : writers) {
+                  if (std::find(in_file.begin(), in_file.end(), name) == in_file.end()) {
+                     throw PreprocessingException(
+                        std::string("The aligned ") + kind + " sequence " + name + " which is contained in the reference sequences is not contained in the input file " +
+                        input_path + "."
+                     );
+                  }
+               }
+            };
+            validate_names("alignedNucleotideSequences", "nucleotide", nuc_writers);
+            validate_names("alignedAminoAcidSequences", "amino acid", aa_writers);
+         }
          const json::Value& metadata = record.at("metadata");
          for (size_t k = 0; k < metadata_writer.size(); ++k) {
             const std::string& column = metadata_writer.name(k);

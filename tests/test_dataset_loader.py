@@ -191,3 +191,42 @@ def test_overridden_file_prefixes(built, tmp_path):
         assert engine.summary["sequenceCount"] == expected["expectedSequenceCount"]
         status, document = engine.execute_raw(expected["query"])
         assert status == 200 and document["queryResult"] == expected["expectedQueryResult"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("input_file,references,message", [
+    # sequence_info.test.cpp:40-52 — the fixture is not valid JSON (a comma is missing before its extra "testSecondSequence"), so
+    # what the reference's test sees is DuckDB refusing the file; the loader refuses it with its parse error
+    ("oneline_second_nuc.json.zst", "exampleDataset1000Sequences", "parse error"),
+    ("oneline_without_ORF.json.zst", "exampleDataset1000Sequences", "which is contained in the reference sequences is not contained in the input file"),  # :54-66
+])
+def test_sequence_names_of_the_first_record_are_validated(built, tmp_path, input_file, references, message):
+    """SequenceInfo::validate (sequence_info.cpp:91-157) on the reference's own one-line ndjson fixtures: a record with
+    a sequence the reference genomes do not know, and one without a gene they do know, are refused with its messages."""
+    import shutil
+
+    from silo_amd.engine import Engine, SiloEngineError
+
+    directory = str(tmp_path)
+    shutil.copy(os.path.join(dataset.GOLDEN, "ndjsonFiles", input_file), os.path.join(directory, input_file))
+    shutil.copy(os.path.join(dataset.GOLDEN, references, "reference_genomes.json"), os.path.join(directory, "reference_genomes.json"))
+    with open(os.path.join(directory, "preprocessing_config.yaml"), "w") as out:
+        out.write(f'ndjsonInputFilename: "{input_file}"\nreferenceGenomeFilename: "reference_genomes.json"\n')
+    with open(os.path.join(directory, "database_config.yaml"), "w") as out:
+        out.write("schema:\n  instanceName: test\n  metadata:\n    - name: strain\n      type: string\n  primaryKey: strain\n")
+    with pytest.raises(SiloEngineError, match=message):
+        Engine.from_directory(directory)
+
+
+@pytest.mark.gpu
+def test_a_sequence_unknown_to_the_reference_genomes_is_refused(built, tmp_path):
+    """The other direction of SequenceInfo::validate (sequence_info.cpp:106-116), with a well-formed record: the
+    exampleDataset as ndjson holds "testSecondSequence", which the reference genomes of the 1000-sequence data set lack."""
+    import shutil
+
+    from silo_amd.engine import Engine, SiloEngineError
+
+    write_ndjson_dataset(str(tmp_path), "none")
+    shutil.copy(os.path.join(dataset.GOLDEN, "exampleDataset1000Sequences", "reference_genomes.json"), os.path.join(str(tmp_path), "reference_genomes.json"))
+    with pytest.raises(SiloEngineError, match="The aligned nucleotide sequence testSecondSequence which is contained in the input file .* is not contained in the reference sequences"):
+        Engine.from_directory(str(tmp_path))
