@@ -754,6 +754,16 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             };
             validate_names("alignedNucleotideSequences", "nucleotide", nuc_writers);
             validate_names("alignedAminoAcidSequences", "amino acid", aa_writers);
+            // metadata_info.cpp:13-47,121-163 (validateFromNdjsonFile): every configured column is a key of the first record's
+            // metadata (or one of the two top-level insertion maps)
+            for (size_t k = 0; k < metadata_writer.size(); ++k) {
+               const std::string& column = metadata_writer.name(k);
+               const bool in_metadata = record.contains("metadata") && record["metadata"].is_object() && record["metadata"].contains(column);
+               const bool insertion_map = (column == "nucleotideInsertions" || column == "aminoAcidInsertions") && record.contains(column);
+               if (!in_metadata && !insertion_map) {
+                  throw PreprocessingException("The metadata field '" + column + "' which is contained in the database config is not contained in the input.");
+               }
+            }
          }
          const json::Value& metadata = record.at("metadata");
          for (size_t k = 0; k < metadata_writer.size(); ++k) {
@@ -817,7 +827,8 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          const auto column_of = [&](const std::string& name) -> size_t {
             const auto found = std::find(header.begin(), header.end(), name);
             if (found == header.end()) {
-               throw PreprocessingException("metadata file " + input_path + " has no column '" + name + "'");
+               // metadata_info.cpp:40-46 (validateFieldsAgainstConfig)
+               throw PreprocessingException("The metadata field '" + name + "' which is contained in the database config is not contained in the input.");
             }
             return static_cast<size_t>(found - header.begin());
          };

@@ -230,3 +230,25 @@ def test_a_sequence_unknown_to_the_reference_genomes_is_refused(built, tmp_path)
     shutil.copy(os.path.join(dataset.GOLDEN, "exampleDataset1000Sequences", "reference_genomes.json"), os.path.join(str(tmp_path), "reference_genomes.json"))
     with pytest.raises(SiloEngineError, match="The aligned nucleotide sequence testSecondSequence which is contained in the input file .* is not contained in the reference sequences"):
         Engine.from_directory(str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndjson", [False, True])
+def test_a_configured_column_missing_from_the_input_is_refused(built, tmp_path, ndjson):
+    """metadata_info.test.cpp:8-32 (and its ndjson twin): a database config that names a column the metadata file /
+    the first record does not hold."""
+    import shutil
+
+    from silo_amd.engine import Engine, SiloEngineError
+
+    directory = str(tmp_path)
+    if ndjson:
+        write_ndjson_dataset(directory, "none")
+    else:
+        for name in os.listdir(EXAMPLE):
+            shutil.copy(os.path.join(EXAMPLE, name), os.path.join(directory, name))
+    config = open(os.path.join(directory, "database_config.yaml")).read()
+    config = config.replace("  metadata:\n", "  metadata:\n    - name: notInMetadata\n      type: pango_lineage\n", 1)
+    open(os.path.join(directory, "database_config.yaml"), "w").write(config)
+    with pytest.raises(SiloEngineError, match="The metadata field 'notInMetadata' which is contained in the database config is not contained in the input"):
+        Engine.from_directory(directory)
