@@ -385,6 +385,13 @@ def main():
     ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner
+    # when the communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the result line
+    # goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    result_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -626,7 +633,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=result_stream, flush=True)
 
 
 if __name__ == "__main__":

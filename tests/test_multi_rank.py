@@ -69,6 +69,8 @@ def test_bench_rccl_path_on_one_gpu(built):
     assert plain.returncode == 0, plain.stderr[-2000:]
     forced = subprocess.run(common + ["--force-dist"], capture_output=True, text=True, env=env, timeout=900)
     assert forced.returncode == 0, forced.stderr[-2000:]
+    # exactly ONE line on stdout, the JSON line — RCCL's version banner and the like go to stderr
+    assert len(plain.stdout.strip().splitlines()) == 1 and len(forced.stdout.strip().splitlines()) == 1, forced.stdout[:500]
     a = json.loads(plain.stdout.strip().splitlines()[-1])
     b = json.loads(forced.stdout.strip().splitlines()[-1])
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
