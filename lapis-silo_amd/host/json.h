@@ -255,6 +255,11 @@ inline Value& ObjectMembers::insertOrAssign(std::string key, Value value) {
       position->second = std::move(value);
       return position->second;
    }
+   if (members_->capacity() == 0) {
+      const auto offset = position - members_->begin();
+      members_->reserve(4);  // a query object has a handful of keys: no regrowth (moving 150-byte members) on the way there
+      position = members_->begin() + offset;
+   }
    return members_->emplace(position, std::move(key), std::move(value))->second;
 }
 inline const ObjectMembers::Member* ObjectMembers::begin() const {
@@ -434,6 +439,16 @@ class Parser {
 
    std::string parseString() {
       ++pos_;
+      // the usual string has no escapes: find its end and copy it in one piece
+      size_t end = pos_;
+      while (end < text_.size() && text_[end] != '"' && text_[end] != '\\' && static_cast<unsigned char>(text_[end]) >= 0x20) {
+         ++end;
+      }
+      if (end < text_.size() && text_[end] == '"') {
+         std::string whole(text_.data() + pos_, end - pos_);
+         pos_ = end + 1;
+         return whole;
+      }
       std::string out;
       while (true) {
          if (pos_ >= text_.size()) {
