@@ -381,6 +381,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
     ap.add_argument("--no-client-threads", action="store_true",
                     help="skip the config-2 filter-query leg (8 client threads): rocprofv3's kernel tracing segfaults inside hipStreamQuery when several host threads poll their streams")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="testing only: every rank uses GPU 0 and the collectives go through gloo — the multi-rank code path of this file "
+                         "on a one-GPU box (RCCL refuses two ranks on one device); the numbers mean nothing")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed / RCCL path even with one rank (testing)")
     ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     args = ap.parse_args()
@@ -393,7 +396,7 @@ def main():
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -417,7 +420,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
         class DeviceU32:
             """A raw device pointer exposed to torch (as int32: a wrapping int32 sum has the same bits as a uint32 sum)."""

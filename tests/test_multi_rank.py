@@ -121,3 +121,24 @@ def test_position_window_shards_partition_the_unsharded_result(built):
         shard.close()
     assert previous_end == model.positions
     assert seen == full
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_path_rehearsed_on_one_gpu(built):
+    """bench.py exactly as the driver launches it for --gpus 2 (python -m torch.distributed.run, one rank per process,
+    position-range shards, the count table all-reduced through the engine's callback), except that both ranks share GPU 0
+    and the collective is gloo (--rehearse-on-one-gpu: RCCL refuses two ranks on one device).  One JSON line, same rows."""
+    root = os.path.dirname(HERE)
+    options = ["--sequences", "200000", "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + options, capture_output=True, text=True, env=env, timeout=900)
+    assert single.returncode == 0, single.stderr[-2000:]
+    double = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                             "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + options,
+                            capture_output=True, text=True, env=env, timeout=900)
+    assert double.returncode == 0, double.stderr[-2000:]
+    lines = double.stdout.strip().splitlines()
+    assert len(lines) == 1, double.stdout[:500]
+    a, b = json.loads(single.stdout.strip()), json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["sharding"].startswith("position-range x2")
+    assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
