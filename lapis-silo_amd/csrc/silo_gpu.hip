@@ -208,10 +208,6 @@ __device__ __forceinline__ uint32_t waveSumToLane63(uint32_t v) {
    return v;
 }
 
-__device__ __forceinline__ uint32_t popc128(const ulonglong2& v, const ulonglong2& f) {
-   return static_cast<uint32_t>(__popcll(v.x & f.x)) + static_cast<uint32_t>(__popcll(v.y & f.y));
-}
-
 // ------------------------------------------------------------------------------------------------
 // K1: Mutations scan over the bit-sliced planes.
 //

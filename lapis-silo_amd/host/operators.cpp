@@ -82,7 +82,6 @@ uint32_t OperatorResult::cardinality() const {
          return *state->count;
       }
       // count-only launch: no bitset is written (Aggregated never needs it)
-      const DatabasePartition& partition = *state->rows.partition;
       if (state->root->type() == operators::EMPTY) {
          state->count = 0;
          return 0;
