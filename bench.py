@@ -62,7 +62,9 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
     lineage = synth.assign_lineages(n_sequences, tree, synth.DEFAULT_SEED)
     model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
     engine = Engine(genomes, device=device)
-    if world > 1 or sharded:
+    if getattr(build_engine, "comm", None) is not None and (world > 1 or sharded):
+        engine.set_comm(build_engine.comm, True)  # native RCCL all-reduce / broadcast on the engine's streams
+    elif world > 1 or sharded:
         engine.set_sharding(rank, world, True, all_reduce)
         if getattr(build_engine, "broadcast", None) is not None:
             engine.set_broadcast(build_engine.broadcast)
@@ -371,6 +373,24 @@ def run_steps(engine, query, steps, warmup, sync):
     return elapsed, json.loads(body.decode())["queryResult"]
 
 
+def launch_ranks(n_gpus):
+    """Runs this script under `python -m torch.distributed.run --nproc-per-node N` as a child process."""
+    import socket
+    import subprocess
+
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.run(command, stdout=subprocess.PIPE, env=env, text=True)  # stderr passes through
+    lines = [line for line in child.stdout.splitlines() if line.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode if child.returncode != 0 or lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +408,12 @@ def main():
     ap.add_argument("--cpu-positions", type=int, default=0, help="positions in the CPU baseline sample (0 = sized to ~10-30 s of CPU work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU, the same launcher the
+        # driver uses) before anything in this process has touched the GPU, relay rank 0's JSON line and leave with the
+        # launcher's exit code.  Never exec: a process that has initialised the GPU must not replace itself.
+        sys.exit(launch_ranks(args.gpus))
+
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner
     # when the communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the result line
     # goes to a private copy of the real stdout.
@@ -402,11 +428,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
     all_reduce = None
+    comm = None
     dist = None
     torch = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        # torch FIRST: it bundles its own HIP runtime under the same SONAME as /opt/rocm's; whichever is
+        # torch FIRST: it bundles its own HIP runtime (and RCCL) under the same SONAMEs as /opt/rocm's; whichever is
         # loaded first serves the whole process, and torch only works with its own.
         import torch
         import torch.distributed as dist
@@ -420,48 +447,37 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
+        # control plane (rendezvous, barrier, max over ranks, the communicator id): gloo over TCP.  Data path: the
+        # engine's own RCCL communicator (silo_gpu_comm_create -> ncclCommInitRank), whose all-reduce of the count table
+        # is enqueued on the engine's HIP stream between the scan kernels and the row selection.
+        dist.init_process_group("gloo")
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            # testing only: RCCL refuses two ranks on one device, so the collectives go through gloo and host memory,
+            # enqueued on (and synchronising) the engine stream they are handed
+            import ctypes
+
+            def all_reduce(device_ptr, n, stream):
+                host = np.empty(n, dtype=np.int32)  # a wrapping int32 sum has the same bits as a uint32 sum
+                binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, host.nbytes, stream))
+                tensor = torch.from_numpy(host)
+                dist.all_reduce(tensor)
+                binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, stream))
+
+            def broadcast(device_ptr, nbytes, root, stream):
+                host = np.empty(nbytes, dtype=np.uint8)
+                if rank == root:
+                    binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, nbytes, stream))
+                tensor = torch.from_numpy(host)
+                dist.broadcast(tensor, src=root)
+                if rank != root:
+                    binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, stream))
+
+            build_engine.broadcast = broadcast
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-        class DeviceU32:
-            """A raw device pointer exposed to torch (as int32: a wrapping int32 sum has the same bits as a uint32 sum)."""
-
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-
-        aliases = {}  # (device pointer, length) -> tensor aliasing it: the engine's pool hands the same buffer out every step
-
-        streams = {}  # the engine's HIP stream handle -> torch view of it
-
-        def on_engine_stream(stream):
-            """The collective is issued with the engine's own stream as torch's current stream, so that RCCL's
-            stream waits for the scan kernels on it and the engine's next kernel waits for the collective."""
-            if not stream:
-                return torch.cuda.stream(torch.cuda.default_stream(local_rank))
-            view = streams.get(stream)
-            if view is None:
-                view = streams[stream] = torch.cuda.ExternalStream(stream, device=torch.device("cuda", local_rank))
-            return torch.cuda.stream(view)
-
-        def all_reduce(device_ptr, n, stream):
-            tensor = aliases.get((device_ptr, n))
-            if tensor is None:
-                tensor = aliases[(device_ptr, n)] = torch.as_tensor(DeviceU32(device_ptr, n), device=torch.device("cuda", local_rank))
-            with on_engine_stream(stream):
-                dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-
-        class DeviceBytes:
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-        def broadcast(device_ptr, nbytes, root, stream):
-            tensor = torch.as_tensor(DeviceBytes(device_ptr, nbytes), device=torch.device("cuda", local_rank))
-            with on_engine_stream(stream):
-                dist.broadcast(tensor, src=root)  # a filter leaf travelling from the rank that owns its position
-
-        build_engine.broadcast = broadcast
+            unique_id = [binding.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(unique_id, src=0)
+            comm = binding.Comm(unique_id[0], rank, world, local_rank)  # ncclCommInitRank: collective over the ranks
+            build_engine.comm = comm
 
         def sync():
             dist.barrier()
@@ -479,7 +495,7 @@ def main():
 
     elapsed, rows = run_steps(engine, query, args.steps, args.warmup, sync)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     filter_us, action_us = engine.last_timings()
@@ -490,25 +506,25 @@ def main():
     w8 = 8 * ((args.sequences + 63) // 64)
     n_local = window[1] - window[0]
     kernel_ms, kernel_name, store, filt, counts_dev = time_kernel(engine, tree, window, reps=max(5, args.steps))
-    # algorithmic bytes: the layout-independent figure of SURVEY.md §8(d) — 5 one-hot symbol columns per position plus the
-    # filter, 0.625 B per position x sequence.  The store is bit-sliced (3 code planes per position) and the scan reads
-    # the compact scan index derived from it at finalize (K1i: 2 code planes per position + the escape keys) when there
-    # is one: both figures are reported, `frac` by the contract's definition (algorithmic bytes / time / peak) and
-    # `physical_frac` for the bytes the scan really asks of the HBM interface.
+    # physical bytes: the plane rows, the filter and the escape keys this launch reads; algorithmic bytes: the layout-
+    # independent figure of SURVEY.md §8(d) — 5 one-hot symbol columns per position plus the filter.
     scan_planes = int(lib.silo_gpu_store_scan_planes(store.handle, 0))
     scan_escapes = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
     alg_bytes = n_local * 5 * w8 + w8
     physical_bytes = n_local * scan_planes * w8 + w8 + 8 * scan_escapes
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM traffic of the same launch shape from the committed rocprofv3 PMC passes (tools/rocprof_summary.py):
-    # counters cannot be read in-process, so this is null unless a profile of exactly this grid is on file.
+    physical_gbps = physical_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch is a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    # the microarchitecture guide prescribes); counters cannot be read from inside this process, so the value is the one
+    # on file for exactly this launch shape — labelled with its source — or null.
     traffic = None
+    traffic_source = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
             if name.startswith(f"k_scan_sliced<{scan_planes},") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * scan_planes:
                 traffic = entry["hbm_bytes"]
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
     except (OSError, ValueError, KeyError):
         pass
 
@@ -531,28 +547,32 @@ def main():
             "sequences": args.sequences,
             "positions": positions,
             "mutation_rows": len(rows),
-            "sharding": "none" if not use_dist else f"position-range x{world}, all-reduce of counts[{positions}][5] over RCCL",
+            "sharding": "none" if not use_dist else f"position-range x{world}, all-reduce of counts[{positions}][5] "
+                        + ("through gloo and host memory (one-GPU rehearsal)" if comm is None else "by silo_gpu_allreduce_counts (native ncclAllReduce on the engine stream)"),
             "reference_phases_us": {"filter": filter_us, "action": action_us},
         },
         "roofline": {
+            # achieved / frac: the bytes this launch asks of the HBM interface (its physical bytes) / kernel time / peak.
+            # The layout-independent algorithmic figure of SURVEY.md §8(d) (5 one-hot symbol columns per position + the
+            # filter, 0.625 B per position x sequence) is kept beside it with the byte-reduction factor of the layout:
+            # algorithmic bytes / time exceeds the peak precisely because the scan moves 2.5x fewer bytes than that model.
             "bound": "hbm",
-            "achieved": achieved,
+            "achieved": physical_gbps,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
+            "frac": physical_gbps / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": kernel_name,
             "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": alg_bytes,
             "physical_bytes_per_launch": physical_bytes,
-            "physical_GBps": physical_bytes / (kernel_ms * 1e-3) / 1e9,
-            "physical_frac": physical_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+            "byte_reduction": alg_bytes / physical_bytes,
             "scan_planes_per_position": scan_planes,
             "escape_keys": scan_escapes,
-            "layout": ("bit-sliced store (3 code planes per position); the scan reads the compact scan index built at finalize: 2 code "
-                       "planes per position (the 3 most frequent valid symbols of the position) + the other rows as escape keys"
-                       if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes")
-                      + " (SURVEY.md §8d keeps the algorithmic figure layout-independent)",
+            "layout": ("2 code planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) + the other rows as escape keys"
+                       if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes"),
         },
     }
 
@@ -626,8 +646,8 @@ def main():
             "value": 1_000_000 * positions / (elapsed1 / args.steps),
             "ms_per_step": elapsed1 / args.steps * 1e3,
             "kernel_ms": kernel_ms1,
-            "roofline_frac": alg1 / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "physical_frac": (positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, 0)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_frac": (positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, 0)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_GBps": alg1 / (kernel_ms1 * 1e-3) / 1e9,
             "mutation_rows": len(rows1),
         }
         result["also_metadata"] = metadata_workload(engine1, 1_000_000, sync)
@@ -637,6 +657,9 @@ def main():
 
     if use_dist:
         dist.barrier()
+        if comm is not None:
+            build_engine.comm = None
+            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), file=result_stream, flush=True)

@@ -83,8 +83,19 @@ int silo_engine_finalize(silo_engine* engine);
 /* Multi-GPU (one process per GPU).  Call before silo_engine_add_partition.  shard_by_position != 0:
  * this rank holds and scans only positions [P*rank/world, P*(rank+1)/world) of every sequence store
  * (sequences appended must be that slice) and counts are all-reduced; otherwise the partitions of
- * this rank are a sequence-id shard and counts / cardinalities are all-reduced.  all_reduce sums n uint32 in place on
- * the device across ranks (RCCL over xGMI in production). */
+ * this rank are a sequence-id shard and counts / cardinalities are all-reduced.
+ *
+ * silo_engine_set_comm is the production form: rank and world are the communicator's, the count tables are summed by
+ * silo_gpu_allreduce_counts (ncclAllReduce over xGMI) and — under position sharding — filter leaves travel by
+ * silo_gpu_broadcast_bytes, both enqueued on the HIP stream of the request thread that runs the query (per-thread
+ * query streams stay in use; no host synchronisation around the collective).  The communicator must outlive the
+ * engine.  Every rank has to run the same queries in the same order (SPMD): the collectives of concurrent request
+ * threads are serialised per communicator, but their order across ranks is the caller's to keep.
+ *
+ * silo_engine_set_sharding / silo_engine_set_broadcast install caller-supplied collectives instead (tests back them
+ * with gloo through host memory; a host with its own transport can plug it in): all_reduce sums n uint32 in place on
+ * the device across ranks, and is handed the stream the engine's kernels before and after it run on. */
+int silo_engine_set_comm(silo_engine* engine, silo_gpu_comm* comm, int shard_by_position);
 typedef int (*silo_engine_all_reduce_u32)(void* context, uint32_t* device_values, size_t n, void* stream);
 int silo_engine_set_sharding(
    silo_engine* engine, uint32_t rank, uint32_t world, int shard_by_position, silo_engine_all_reduce_u32 all_reduce, void* context
@@ -108,6 +119,17 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
  * result or the error document; *out_http_status is 200, 400 or 500.  Returns 0 unless the arguments
  * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */
 int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status);
+
+/* The inner seam of SURVEY.md §8(b): Expression::compile + Operator::evaluate of ONE filter for ONE partition
+ * (query_engine.cpp:40-49; operator.h:32 `evaluate() -> OperatorResult`), handing back what the reference's
+ * OperatorResult holds — the set of sequence ids — as a bitset in host memory (bit i of word w = row 64 * w + i of the
+ * partition; n_words >= ceil(sequence_count / 64), the rest is zeroed; may be NULL) and its cardinality (may be NULL).
+ * filter_json is a filterExpression object.  *out_http_status is 200, or 400 / 500 with the error document in
+ * *out_error_json (malloc'ed, may be NULL to ignore) exactly as silo_engine_execute_query would report it. */
+int silo_engine_evaluate_filter(
+   const silo_engine* engine, const char* filter_json, int partition, uint64_t* out_bitset, size_t n_words, uint32_t* out_count,
+   char** out_error_json, int* out_http_status
+);
 
 /* Executes `n_queries` queries as one batch: every query is parsed, compiled and its filter evaluated, then
  * the Mutations / AminoAcidMutations scans of all of them are launched together so that queries over the same

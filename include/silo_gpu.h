@@ -366,6 +366,28 @@ int silo_gpu_event_synchronize(void* event); /* blocks the calling thread until 
 int silo_gpu_event_elapsed_ms(void* start_event, void* stop_event, float* out_ms); /* synchronises on stop */
 void silo_gpu_event_destroy(void* event);
 
+/* ---- exchange step of the sharded scan: RCCL over xGMI -------------------------------------
+ * One process per GPU.  The reference sums its partitions in a host loop inside one process (query_engine.cpp:40-49,
+ * mutations.cpp:71,108); across GPUs that sum is ONE all-reduce of the count table per query (position-range or
+ * sequence-id shards alike), and a filter leaf at a position another rank holds is ONE broadcast of a row bitset.
+ * silo_gpu_comm_unique_id: called by one rank; the SILO_GPU_COMM_ID_BYTES opaque bytes reach the other ranks out
+ * of band (the launcher's key-value store, MPI, a file).  silo_gpu_comm_create: collective over all `world` ranks.
+ * The collectives are enqueued on `stream` (any stream of the communicator's device; NULL = the null stream) and
+ * ordered with the kernels on it — no host synchronisation.  Every rank must enqueue the same collectives in the same
+ * order; calls on one communicator are serialised internally.  librccl is bound on first use: without it these
+ * fail with SILO_GPU_ERR_UNSUPPORTED and nothing else in the library is affected. */
+typedef struct silo_gpu_comm silo_gpu_comm;
+enum { SILO_GPU_COMM_ID_BYTES = 128 };
+int silo_gpu_comm_unique_id(uint8_t* out_id /* [SILO_GPU_COMM_ID_BYTES] */);
+int silo_gpu_comm_create(const uint8_t* id, uint32_t rank, uint32_t world, int device, silo_gpu_comm** out);
+void silo_gpu_comm_destroy(silo_gpu_comm* comm);
+uint32_t silo_gpu_comm_rank(const silo_gpu_comm* comm);
+uint32_t silo_gpu_comm_world(const silo_gpu_comm* comm);
+/* counts_dev[i] = sum over ranks of counts_dev[i], in place (ncclAllReduce, ncclUint32, ncclSum). */
+int silo_gpu_allreduce_counts(silo_gpu_comm* comm, uint32_t* counts_dev, size_t n, void* stream);
+/* bytes_dev of rank `root` to every rank, in place (ncclBroadcast). */
+int silo_gpu_broadcast_bytes(silo_gpu_comm* comm, void* bytes_dev, size_t n_bytes, uint32_t root, void* stream);
+
 /* Name of the last kernel variant silo_gpu_mutations_scan launched (for roofline attribution). */
 const char* silo_gpu_last_scan_kernel(void);
 

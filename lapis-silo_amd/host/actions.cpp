@@ -111,7 +111,7 @@ void allReduce(const Database& database, uint32_t* device_values, size_t n) {
    if (database.all_reduce != nullptr) {  // also with a single rank: lets a 1-GPU box exercise the collective path
       const int status = database.all_reduce(database.all_reduce_context, device_values, n, queryStream());
       if (status != 0) {
-         throw DeviceException("all-reduce of counts failed with status " + std::to_string(status));
+         throw DeviceException("all-reduce of counts failed with status " + std::to_string(status) + (status < 0 ? std::string(": ") + silo_gpu_last_error() : ""));
       }
    }
 }

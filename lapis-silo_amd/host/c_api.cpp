@@ -294,8 +294,30 @@ int silo_engine_set_sharding(
    engine->database.shard_by_position = shard_by_position != 0;
    engine->database.all_reduce = all_reduce;
    engine->database.all_reduce_context = context;
-   // the collective is ordered against the null stream by its provider (torch.distributed / RCCL)
-   silo::setQueryStreamsEnabled(all_reduce == nullptr);
+   return 0;
+}
+
+namespace {
+// the native collectives of include/silo_gpu.h behind the engine's two hooks (context = the communicator)
+int nativeAllReduce(void* context, uint32_t* device_values, size_t n, void* stream) {
+   return silo_gpu_allreduce_counts(static_cast<silo_gpu_comm*>(context), device_values, n, stream);
+}
+int nativeBroadcast(void* context, void* device_bytes, size_t bytes, uint32_t root, void* stream) {
+   return silo_gpu_broadcast_bytes(static_cast<silo_gpu_comm*>(context), device_bytes, bytes, root, stream);
+}
+}  // namespace
+
+int silo_engine_set_comm(silo_engine* engine, silo_gpu_comm* comm, int shard_by_position) {
+   if (engine == nullptr || comm == nullptr || silo_gpu_comm_world(comm) == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_set_comm: bad arguments");
+   }
+   engine->database.shard_rank = silo_gpu_comm_rank(comm);
+   engine->database.shard_world = silo_gpu_comm_world(comm);
+   engine->database.shard_by_position = shard_by_position != 0;
+   engine->database.all_reduce = nativeAllReduce;
+   engine->database.all_reduce_context = comm;
+   engine->database.broadcast = shard_by_position != 0 ? nativeBroadcast : nullptr;
+   engine->database.broadcast_context = shard_by_position != 0 ? comm : nullptr;
    return 0;
 }
 
@@ -305,9 +327,6 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
    }
    engine->database.broadcast = broadcast;
    engine->database.broadcast_context = context;
-   if (broadcast != nullptr) {
-      silo::setQueryStreamsEnabled(false);  // collectives are ordered against the null stream
-   }
    return 0;
 }
 
@@ -349,6 +368,64 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
       *out_http_status = 500;
    }
    return *out_json != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+}
+
+int silo_engine_evaluate_filter(
+   const silo_engine* engine, const char* filter_json, int partition, uint64_t* out_bitset, size_t n_words, uint32_t* out_count, char** out_error_json,
+   int* out_http_status
+) {
+   if (engine == nullptr || filter_json == nullptr || out_http_status == nullptr || partition < 0 ||
+       static_cast<size_t>(partition) >= engine->database.partitions.size()) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_evaluate_filter: bad arguments");
+   }
+   const silo::DatabasePartition& database_partition = engine->database.partitions[static_cast<size_t>(partition)];
+   const size_t needed_words = (static_cast<size_t>(database_partition.sequence_count) + 63) / 64;
+   if (out_bitset != nullptr && n_words < needed_words) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_evaluate_filter: the bitset buffer is shorter than ceil(sequence_count / 64) words");
+   }
+   if (out_error_json != nullptr) {
+      *out_error_json = nullptr;
+   }
+   const auto report = [&](const char* error, const std::string& message, int status) {
+      if (out_error_json != nullptr) {
+         *out_error_json = duplicate(errorDocument(error, message));
+      }
+      *out_http_status = status;
+   };
+   try {
+      silo::json::Value json;
+      try {
+         json = silo::json::parse(filter_json);
+      } catch (const silo::json::ParseError& ex) {
+         throw silo::QueryParseException("The query was not a valid JSON: " + std::string(ex.what()));
+      }
+      std::unique_ptr<silo::query_engine::filter_expressions::Expression> expression;
+      try {
+         expression = silo::query_engine::filter_expressions::parseExpression(json);
+      } catch (const std::out_of_range& ex) {
+         throw silo::QueryParseException("The query was not a valid JSON: " + std::string(ex.what()));
+      }
+      // Expression::compile + Operator::evaluate for this partition, query_engine.cpp:40-49
+      const silo::query_engine::OperatorResult result =
+         expression->compile(engine->database, database_partition, silo::query_engine::filter_expressions::Expression::AmbiguityMode::NONE)->evaluate();
+      if (out_bitset != nullptr) {
+         std::memset(out_bitset, 0, n_words * sizeof(uint64_t));
+         silo::checkGpu(
+            silo_gpu_bitset_download(database_partition.store, out_bitset, result.bitset(), needed_words, silo::queryStream()), "silo_gpu_bitset_download"
+         );
+      }
+      if (out_count != nullptr) {
+         *out_count = result.cardinality();
+      }
+      *out_http_status = 200;
+   } catch (const silo::QueryParseException& ex) {
+      report("Bad request", ex.what(), 400);
+   } catch (const std::exception& ex) {
+      report("Internal Server Error", ex.what(), 500);
+   } catch (...) {
+      report("Internal Server Error", "non recoverable error message", 500);
+   }
+   return 0;
 }
 
 int silo_engine_execute_batch(const silo_engine* engine, const char* const* query_jsons, uint32_t n_queries, char** out_jsons, int* out_http_statuses) {

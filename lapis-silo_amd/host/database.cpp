@@ -18,8 +18,6 @@ void checkGpu(int status, const char* what) {
 // ---- per-thread streams ---------------------------------------------------------------------------
 namespace {
 
-std::atomic<bool> g_query_streams_enabled{true};
-
 struct ThreadStream {  // never destroyed: thread exit may come after the HIP runtime has shut down
    void* stream = nullptr;
    bool tried = false;
@@ -27,14 +25,7 @@ struct ThreadStream {  // never destroyed: thread exit may come after the HIP ru
 
 }  // namespace
 
-void setQueryStreamsEnabled(bool enabled) {
-   g_query_streams_enabled.store(enabled);
-}
-
 void* queryStream() {
-   if (!g_query_streams_enabled.load()) {
-      return nullptr;
-   }
    thread_local ThreadStream holder;
    if (!holder.tried) {
       holder.tried = true;

@@ -45,11 +45,11 @@ void checkGpu(int status, const char* what);
 
 /// The HIP stream the calling thread's query work is issued on.  Every request thread gets its own
 /// non-blocking stream, so concurrent executeQuery calls (silo_api runs one thread per request,
-/// database_mutex.cpp:20-23) overlap on the device instead of serialising on the null stream.  When a
-/// collective callback is installed (multi-GPU) the null stream is used, which is what torch.distributed
-/// orders its RCCL work against.
+/// database_mutex.cpp:20-23) overlap on the device instead of serialising on the null stream.  Collectives of a
+/// sharded database (the all-reduce of a count table, the broadcast of a filter leaf) are enqueued on this same
+/// stream — natively through silo_gpu_allreduce_counts / silo_gpu_broadcast_bytes, or by a caller-supplied
+/// callback that is handed the stream — so sharding does not cost the per-request concurrency.
 void* queryStream();
-void setQueryStreamsEnabled(bool enabled);
 
 /// Phase marks of the calling thread's last query, microseconds since the query began — the finer
 /// grained companion of the reference's two LOG_PERFORMANCE timings (query_engine.cpp:63-65).

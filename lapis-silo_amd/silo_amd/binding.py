@@ -85,6 +85,8 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
+    "silo_gpu_comm_unique_id", "silo_gpu_comm_create", "silo_gpu_comm_destroy", "silo_gpu_comm_rank", "silo_gpu_comm_world",
+    "silo_gpu_allreduce_counts", "silo_gpu_broadcast_bytes",
 ]
 
 _lib = None
@@ -158,8 +160,52 @@ def load_library():
     lib.silo_gpu_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.silo_gpu_last_scan_kernel.restype = ctypes.c_char_p
     lib.silo_gpu_last_error.restype = ctypes.c_char_p
+    lib.silo_gpu_comm_unique_id.argtypes = [vp]
+    lib.silo_gpu_comm_create.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.silo_gpu_comm_destroy.argtypes = [vp]
+    lib.silo_gpu_comm_destroy.restype = None
+    lib.silo_gpu_comm_rank.argtypes = [vp]
+    lib.silo_gpu_comm_rank.restype = ctypes.c_uint32
+    lib.silo_gpu_comm_world.argtypes = [vp]
+    lib.silo_gpu_comm_world.restype = ctypes.c_uint32
+    lib.silo_gpu_allreduce_counts.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.silo_gpu_broadcast_bytes.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_uint32, vp]
     _lib = lib
     return lib
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The opaque id one rank creates and hands to the others out of band (silo_gpu_comm_unique_id)."""
+    buffer = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(load_library().silo_gpu_comm_unique_id(buffer))
+    return bytes(buffer)
+
+
+class Comm:
+    """silo_gpu_comm: the native RCCL communicator behind silo_gpu_allreduce_counts / silo_gpu_broadcast_bytes."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self.lib = load_library()
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("a communicator id has %d bytes" % COMM_ID_BYTES)
+        handle = ctypes.c_void_p()
+        _check(self.lib.silo_gpu_comm_create((ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id), rank, world, device, ctypes.byref(handle)))
+        self.handle = handle
+        self.rank, self.world = rank, world
+
+    def all_reduce_counts(self, device_ptr, n, stream=None):
+        _check(self.lib.silo_gpu_allreduce_counts(self.handle, device_ptr, n, stream))
+
+    def broadcast_bytes(self, device_ptr, nbytes, root, stream=None):
+        _check(self.lib.silo_gpu_broadcast_bytes(self.handle, device_ptr, nbytes, root, stream))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.silo_gpu_comm_destroy(self.handle)
+            self.handle = None
 
 
 def _check(rc):

@@ -53,12 +53,21 @@ def build_gpu(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libsilo_gpu.so")
     sources = _glob(CSRC, (".hip",))
-    deps = sources + _glob(CSRC, (".h",)) + _glob(INCLUDE, (".h",))
-    if force or _newer(target, deps):
-        _run([
-            hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-            "-Wall", "-Wextra", "-I", INCLUDE, *sources, "-o", target, "-Wl,-rpath,/opt/rocm/lib",
-        ])
+    headers = _glob(CSRC, (".h",)) + _glob(INCLUDE, (".h",))
+    # one object per translation unit (lib/obj/, git-ignored), so that touching one kernel file recompiles only it
+    obj_dir = os.path.join(LIB, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objects = []
+    for source in sources:
+        obj = os.path.join(obj_dir, os.path.basename(source) + ".o")
+        if force or _newer(obj, [source] + headers):
+            _run([
+                hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-I", INCLUDE,
+                "-c", source, "-o", obj,
+            ])
+        objects.append(obj)
+    if force or _newer(target, objects):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objects, "-o", target, "-Wl,-rpath,/opt/rocm/lib", "-ldl"])
     return target
 
 

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
+    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_comm", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_evaluate_filter", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
@@ -49,6 +49,9 @@ def load_library():
     lib.silo_engine_finalize.argtypes = [vp]
     lib.silo_engine_set_sharding.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ALL_REDUCE_FN, vp]
     lib.silo_engine_set_broadcast.argtypes = [vp, BROADCAST_FN, vp]
+    lib.silo_engine_set_comm.argtypes = [vp, vp, ctypes.c_int]
+    lib.silo_engine_evaluate_filter.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(vp),
+                                                ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_set_schema.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
     lib.silo_engine_append_metadata.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
     lib.silo_engine_append_unaligned_sequences.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
@@ -212,6 +215,11 @@ class Engine:
         self._callbacks.append(callback)
         _check(self.lib.silo_engine_set_sharding(self.handle, rank, world, int(shard_by_position), callback, None))
 
+    def set_comm(self, comm, shard_by_position):
+        """Native collectives (binding.Comm = RCCL over xGMI) on the engine's own streams; rank / world are the communicator's."""
+        self._callbacks.append(comm)  # the communicator must outlive the engine
+        _check(self.lib.silo_engine_set_comm(self.handle, comm.handle, int(shard_by_position)))
+
     def set_broadcast(self, broadcast):
         """broadcast(device_ptr:int, nbytes:int, root:int, stream): in-place broadcast from rank `root`."""
         def trampoline(_context, device_bytes, nbytes, root, stream):
@@ -263,6 +271,25 @@ class Engine:
         finally:
             self.lib.silo_engine_free_string(out)
         return status.value, body
+
+    def evaluate_filter(self, expression, partition=0, n_rows=None):
+        """Operator::evaluate for one partition: (bitset as uint64 words, cardinality).  n_rows = the partition's row count."""
+        text = expression if isinstance(expression, (str, bytes)) else json.dumps(expression)
+        if isinstance(text, str):
+            text = text.encode()
+        if n_rows is None:
+            n_rows = self.partition_store(partition).sequence_count
+        words = np.zeros((n_rows + 63) // 64, dtype=np.uint64)
+        count, status, error = ctypes.c_uint32(), ctypes.c_int(), ctypes.c_void_p()
+        _check(self.lib.silo_engine_evaluate_filter(
+            self.handle, text, partition, words.ctypes.data_as(ctypes.c_void_p), len(words), ctypes.byref(count), ctypes.byref(error), ctypes.byref(status)))
+        if status.value != 200:
+            try:
+                document = json.loads(ctypes.string_at(error).decode())
+            finally:
+                self.lib.silo_engine_free_string(error)
+            raise QueryError(status.value, document)
+        return words, count.value
 
     def execute_batch_text(self, queries):
         """One silo_engine_execute_batch call: [(http_status, response body as bytes)] in the order of `queries`."""

@@ -81,21 +81,23 @@ def main():
 
     lib = binding.load_library()
 
-    def all_reduce(device_ptr, n, _stream):
+    # the collectives are handed the stream the engine's kernels run on (the request thread's own stream): the copies
+    # below are enqueued on it and synchronise it, so they see the scans before and are seen by the kernels after
+    def all_reduce(device_ptr, n, stream):
         host = np.empty(n, dtype=np.int32)
-        binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, host.nbytes, None))
+        binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, host.nbytes, stream))
         tensor = torch.from_numpy(host)
         dist.all_reduce(tensor)
-        binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, None))
+        binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, stream))
 
-    def broadcast(device_ptr, nbytes, root, _stream):
+    def broadcast(device_ptr, nbytes, root, stream):
         host = np.empty(nbytes, dtype=np.uint8)
         if rank == root:
-            binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, nbytes, None))
+            binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, nbytes, stream))
         tensor = torch.from_numpy(host)
         dist.broadcast(tensor, src=root)
         if rank != root:
-            binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, None))
+            binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, stream))
 
     engine = Engine(doc)
     engine.set_sharding(rank, world, by_position, all_reduce)

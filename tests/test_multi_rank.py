@@ -58,9 +58,10 @@ def test_two_ranks_match_one_rank_gpu(built, shard):
 
 @pytest.mark.gpu
 def test_bench_rccl_path_on_one_gpu(built):
-    """bench.py --force-dist: torch.distributed (nccl = RCCL) initialised on one rank, the engine's count
-    table aliased as a torch tensor through __cuda_array_interface__ and all-reduced, with torch's HIP
-    runtime serving the kernels.  Must give the same rows as the plain single-process run."""
+    """bench.py --force-dist: the multi-rank code path with ONE rank — gloo for the control plane, the engine's own
+    RCCL communicator (silo_gpu_comm_create -> ncclCommInitRank) for the data path: the count table of every query is
+    all-reduced by silo_gpu_allreduce_counts (ncclAllReduce, ncclUint32) on the engine's stream, with torch's HIP
+    runtime and RCCL serving the process.  Must give the same rows as the plain single-process run."""
     root = os.path.dirname(HERE)
     common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--sequences", "200000", "--steps", "2", "--warmup", "1",
               "--no-also", "--no-cpu-baseline"]
@@ -74,8 +75,8 @@ def test_bench_rccl_path_on_one_gpu(built):
     a = json.loads(plain.stdout.strip().splitlines()[-1])
     b = json.loads(forced.stdout.strip().splitlines()[-1])
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
-    assert b["config"]["sharding"].startswith("position-range x1")
-    assert b["roofline"]["frac"] > 0.05
+    assert b["config"]["sharding"].startswith("position-range x1") and "silo_gpu_allreduce_counts" in b["config"]["sharding"]
+    assert 0.05 < b["roofline"]["frac"] <= 1.0  # physical bytes / time / peak: a fraction
 
 
 @pytest.mark.gpu
@@ -124,17 +125,23 @@ def test_position_window_shards_partition_the_unsharded_result(built):
 
 
 @pytest.mark.gpu
-def test_bench_two_rank_path_rehearsed_on_one_gpu(built):
-    """bench.py exactly as the driver launches it for --gpus 2 (python -m torch.distributed.run, one rank per process,
-    position-range shards, the count table all-reduced through the engine's callback), except that both ranks share GPU 0
-    and the collective is gloo (--rehearse-on-one-gpu: RCCL refuses two ranks on one device).  One JSON line, same rows."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_rank_path_rehearsed_on_one_gpu(built, launcher):
+    """bench.py for --gpus 2 both ways the driver may start it — `python bench.py --gpus 2` (bench.py spawns its ranks
+    itself as child processes before touching the GPU) and `python -m torch.distributed.run ... bench.py --gpus 2` — one
+    rank per process, position-range shards, the count table all-reduced through the engine's hook, except that both
+    ranks share GPU 0 and the collective is gloo (--rehearse-on-one-gpu: RCCL refuses two ranks on one device).
+    One JSON line, same rows."""
     root = os.path.dirname(HERE)
     options = ["--sequences", "200000", "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu-baseline"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(name, None)
     single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + options, capture_output=True, text=True, env=env, timeout=900)
     assert single.returncode == 0, single.stderr[-2000:]
-    double = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                             "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + options,
+    prefix = [sys.executable] if launcher == "self" else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
+    double = subprocess.run(prefix + [os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + options,
                             capture_output=True, text=True, env=env, timeout=900)
     assert double.returncode == 0, double.stderr[-2000:]
     lines = double.stdout.strip().splitlines()
@@ -142,3 +149,38 @@ def test_bench_two_rank_path_rehearsed_on_one_gpu(built):
     a, b = json.loads(single.stdout.strip()), json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["sharding"].startswith("position-range x2")
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
+
+
+@pytest.mark.gpu
+def test_native_comm_one_rank(built):
+    """silo_gpu_comm_* / silo_gpu_allreduce_counts / silo_gpu_broadcast_bytes (include/silo_gpu.h) with a one-rank
+    communicator, in a child process (RCCL is mapped there only): the sum over one rank and the broadcast from rank 0
+    leave the buffer as it is, on a non-blocking stream, ordered with a memset before and a copy after."""
+    code = r"""
+import ctypes, sys
+import numpy as np
+sys.path[:0] = [@ROOT@, @PKG@]
+from silo_amd import binding
+lib = binding.load_library()
+comm = binding.Comm(binding.comm_unique_id(), 0, 1, 0)
+assert lib.silo_gpu_comm_rank(comm.handle) == 0 and lib.silo_gpu_comm_world(comm.handle) == 1
+stream = ctypes.c_void_p()
+binding._check(lib.silo_gpu_stream_create(ctypes.byref(stream)))
+n = 29903 * 5
+host = (np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+dev = ctypes.c_void_p()
+binding._check(lib.silo_gpu_malloc(host.nbytes, ctypes.byref(dev)))
+binding._check(lib.silo_gpu_memcpy_h2d(dev, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, stream))
+comm.all_reduce_counts(dev, n, stream)
+comm.broadcast_bytes(dev, host.nbytes, 0, stream)
+back = np.empty_like(host)
+binding._check(lib.silo_gpu_memcpy_d2h(back.ctypes.data_as(ctypes.c_void_p), dev, back.nbytes, stream))
+assert np.array_equal(back, host)
+assert lib.silo_gpu_broadcast_bytes(comm.handle, dev, 4, 1, stream) < 0  # no such root
+lib.silo_gpu_free(dev)
+comm.close()
+print("ok")
+""".replace("@ROOT@", repr(os.path.dirname(HERE))).replace("@PKG@", repr(os.path.join(os.path.dirname(HERE), "lapis-silo_amd")))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert done.returncode == 0 and done.stdout.strip().endswith("ok"), done.stderr[-2000:]
