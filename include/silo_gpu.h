@@ -207,6 +207,17 @@ int silo_gpu_filter_eval(
    uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream
 );
 
+/* K3 for a batch of programs over one store in ONE launch: the filter -> Aggregated queries that are in flight at the
+ * same time (the reference evaluates each on its own request thread: intersection.cpp:111-126, union.cpp:39-44,
+ * threshold.cpp:93-128 once per request).  A single 32-column program is launch-latency bound (40 MB at 10 M
+ * sequences); a batch streams at memory speed.  out_bitsets_dev (may be NULL, entries may be NULL): per program a
+ * row-sized device bitset to receive the result; out_counts (host memory, may be NULL): the cardinalities.
+ * Synchronises `stream` before it returns.  Programs obey the limits of silo_gpu_filter_eval. */
+int silo_gpu_filter_eval_batch(
+   const silo_gpu_store* store, const silo_gpu_bitprog* programs, uint32_t n_programs, uint64_t* const* out_bitsets_dev, uint64_t* out_counts,
+   void* stream
+);
+
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
 /* Count slot: the cardinality of a filter without a copy or a stream synchronisation.  The last block of the K3
  * launch sums the count shards, stores the total into page-locked host memory (system-scope store) and re-arms the

@@ -910,6 +910,73 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3b: the fused filter evaluator for a BATCH of programs — the filter -> Aggregated queries that are in flight at the
+// same time (silo_api runs one request thread each; intersection.cpp:111-126, union.cpp:39-44 and threshold.cpp:93-128
+// then run once per request).  One query of 32 columns is 40 MB at 10 M sequences: 5 us of HBM time, the same order as a
+// launch, so a query on its own is latency-bound (k_filter_eval: ~1 wave per SIMD).  Q programs in ONE launch put
+// Q x 1221 waves on the chip and stream at memory speed.  blockIdx.x = program (fastest: programs that name the same
+// plane read the same tile of it close in time, so it is served from L2 / Infinity Cache), blockIdx.y = column tile of
+// EVAL_BATCH_THREADS * 2 words; every wave works on its own 128 words (no barrier).  The programs do not fit the
+// kernel-argument segment, so they sit in a device table (headers, then code and leaf pointers per program) and are
+// fetched with scalar loads; counts go to EVAL_BATCH_SHARDS counters per program.
+// ------------------------------------------------------------------------------------------------
+constexpr int EVAL_BATCH_THREADS = 256;
+constexpr uint32_t EVAL_BATCH_SHARDS = 16;
+
+struct BatchProgramHeader {
+   uint32_t n_instructions;
+   uint32_t n_slots;
+   uint32_t code_offset;  // bytes from the start of the table, 2 * n_instructions uint32
+   uint32_t leaf_offset;  // bytes from the start of the table, n_leaves device pointers
+   uint64_t* out;         // bitset of the result (row_words words) or nullptr
+   uint64_t reserved;
+};
+
+__global__ __launch_bounds__(EVAL_BATCH_THREADS) void k_filter_eval_batch(
+   const uint8_t* __restrict__ table, uint32_t first_program, uint32_t sequence_count, uint32_t row_words, uint32_t max_slots,
+   uint32_t* __restrict__ counts
+) {
+   extern __shared__ ulonglong2 s_slots[];  // [wave][max_slots][64]
+   using silo_gpu::Word2;
+   const uint32_t program = first_program + blockIdx.x;
+   const BatchProgramHeader header = reinterpret_cast<const BatchProgramHeader*>(table)[program];
+   const uint32_t* __restrict__ code = reinterpret_cast<const uint32_t*>(table + header.code_offset);
+   const uint64_t* const* __restrict__ leaves = reinterpret_cast<const uint64_t* const*>(table + header.leaf_offset);
+   const uint32_t lane = threadIdx.x & 63u;
+   ulonglong2* slots = s_slots + static_cast<size_t>(threadIdx.x >> 6) * max_slots * 64u;
+   const uint32_t w = (blockIdx.y * EVAL_BATCH_THREADS + threadIdx.x) * 2;  // row_words is even (multiple of 32)
+   const bool active = w < row_words;
+   const uint32_t w_safe = active ? w : 0;
+   Word2 valid{0, 0};
+   if (active) {
+      valid = {silo_gpu::valid_mask(w, sequence_count), silo_gpu::valid_mask(w + 1, sequence_count)};
+   }
+   const auto leaf = [&](uint32_t index) -> Word2 {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(leaves[index] + w_safe);
+      return {v.x, v.y};
+   };
+   const auto get = [&](uint32_t index) -> Word2 {
+      if (index >= SILO_GPU_LEAF_OPERAND) {
+         return leaf(index - SILO_GPU_LEAF_OPERAND);
+      }
+      const ulonglong2 v = slots[index * 64u + lane];
+      return {v.x, v.y};
+   };
+   const auto set = [&](uint32_t index, Word2 value) { slots[index * 64u + lane] = make_ulonglong2(value.x, value.y); };
+
+   Word2 result = silo_gpu::bitprog_run<Word2, 8>(code, header.n_instructions, valid, get, set, leaf);
+   result = result & valid;
+   if (active && header.out != nullptr) {
+      *reinterpret_cast<ulonglong2*>(header.out + w) = make_ulonglong2(result.x, result.y);
+   }
+   const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
+   const uint32_t wave_total = waveSumToLane63(bits);
+   if (lane == 63u && wave_total != 0) {
+      atomicAdd(counts + program * EVAL_BATCH_SHARDS + ((blockIdx.y * (EVAL_BATCH_THREADS / 64) + (threadIdx.x >> 6)) % EVAL_BATCH_SHARDS), wave_total);
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
 // plane writers shared by B1 / B2: `symbol` is this lane's symbol for sequence 64*word+lane
 // (SILO_GPU_SYMBOL_NONE contributes no bit).
 // ------------------------------------------------------------------------------------------------
@@ -2655,14 +2722,12 @@ int silo_gpu_count_slot_wait(silo_gpu_count_slot* slot, uint64_t* out_count, voi
 }
 
 namespace {
-int filterEvalLaunch(
-   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
-   unsigned long long* host_total_dev, void* stream
-) {
-   if (store == nullptr || program == nullptr || program->code == nullptr) {
-      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
+/// Limits and operands of a bit-program, checked on the host: a bad slot or leaf index would be an out-of-bounds LDS /
+/// global access on the device.
+int validateProgram(const silo_gpu_bitprog* program) {
+   if (program == nullptr || program->code == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: null program");
    }
-   HIP_TRY(hipSetDevice(store->device));  // a new host thread starts on device 0
    if (program->n_instructions == 0 || program->n_instructions > SILO_GPU_MAX_INSTRUCTIONS ||
        program->n_leaves > SILO_GPU_MAX_LEAVES || program->n_slots == 0 || program->n_slots > SILO_GPU_MAX_SLOTS) {
       return fail(SILO_GPU_ERR_PROGRAM_TOO_LARGE, "bit-program exceeds the instruction / leaf / slot limits");
@@ -2722,6 +2787,20 @@ int filterEvalLaunch(
          return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "bit-program leaf " + std::to_string(k) + " is null");
       }
    }
+   return SILO_GPU_OK;
+}
+
+int filterEvalLaunch(
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
+   unsigned long long* host_total_dev, void* stream
+) {
+   if (store == nullptr || program == nullptr || program->code == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
+   }
+   HIP_TRY(hipSetDevice(store->device));  // a new host thread starts on device 0
+   if (const int rc = validateProgram(program); rc != SILO_GPU_OK) {
+      return rc;
+   }
    FilterEvalArgs args{};
    args.n_instructions = program->n_instructions;
    args.sequence_count = store->sequence_count;
@@ -2746,6 +2825,136 @@ int filterEvalLaunch(
    return SILO_GPU_OK;
 }
 }  // namespace
+
+namespace {
+/// Staging of silo_gpu_filter_eval_batch: the program table in page-locked host memory and on the device, the count
+/// shards on the device and their page-locked landing area.  One per host thread; every call ends with a stream
+/// synchronisation, so a buffer is never reused while the device still reads it.  Never freed (thread exit may come
+/// after the HIP runtime has shut down).
+struct EvalBatchScratch {
+   uint8_t* host_table = nullptr;
+   uint8_t* device_table = nullptr;
+   size_t table_capacity = 0;
+   uint32_t* device_counts = nullptr;
+   uint32_t* host_counts = nullptr;
+   size_t counts_capacity = 0;  // programs
+};
+}  // namespace
+
+int silo_gpu_filter_eval_batch(
+   const silo_gpu_store* store, const silo_gpu_bitprog* programs, uint32_t n_programs, uint64_t* const* out_bitsets_dev, uint64_t* out_counts,
+   void* stream
+) {
+   if (store == nullptr || (n_programs != 0 && programs == nullptr)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval_batch: bad arguments");
+   }
+   if (n_programs == 0) {
+      return SILO_GPU_OK;
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   for (uint32_t q = 0; q < n_programs; ++q) {
+      if (const int rc = validateProgram(&programs[q]); rc != SILO_GPU_OK) {
+         return rc;
+      }
+   }
+   // programs with few slots first: a launch sizes its LDS for the hungriest program in it, so the (typical) programs
+   // with a handful of slots are not held to the occupancy of a rare wide one
+   std::vector<uint32_t> order(n_programs);
+   for (uint32_t q = 0; q < n_programs; ++q) {
+      order[q] = q;
+   }
+   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return programs[a].n_slots < programs[b].n_slots; });
+   const auto align16 = [](size_t value) { return (value + 15) / 16 * 16; };
+   size_t table_bytes = align16(static_cast<size_t>(n_programs) * sizeof(BatchProgramHeader));
+   for (uint32_t q = 0; q < n_programs; ++q) {
+      table_bytes += align16(static_cast<size_t>(programs[q].n_instructions) * 2 * sizeof(uint32_t)) + align16(static_cast<size_t>(programs[q].n_leaves) * sizeof(uint64_t*));
+   }
+   thread_local EvalBatchScratch scratch;
+   if (table_bytes > scratch.table_capacity) {
+      if (scratch.host_table != nullptr) {
+         (void)hipHostFree(scratch.host_table);
+         (void)hipFree(scratch.device_table);
+         scratch.host_table = nullptr;
+         scratch.device_table = nullptr;
+         scratch.table_capacity = 0;
+      }
+      const size_t capacity = std::max<size_t>(table_bytes * 2, size_t{64} << 10);
+      HIP_TRY(hipHostMalloc(&scratch.host_table, capacity, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&scratch.device_table, capacity));
+      scratch.table_capacity = capacity;
+   }
+   if (n_programs > scratch.counts_capacity) {
+      if (scratch.host_counts != nullptr) {
+         (void)hipHostFree(scratch.host_counts);
+         (void)hipFree(scratch.device_counts);
+         scratch.host_counts = nullptr;
+         scratch.device_counts = nullptr;
+         scratch.counts_capacity = 0;
+      }
+      const size_t capacity = std::max<size_t>(static_cast<size_t>(n_programs) * 2, 128);
+      HIP_TRY(hipHostMalloc(&scratch.host_counts, capacity * EVAL_BATCH_SHARDS * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_TRY(hipMalloc(&scratch.device_counts, capacity * EVAL_BATCH_SHARDS * sizeof(uint32_t)));
+      scratch.counts_capacity = capacity;
+   }
+   auto* headers = reinterpret_cast<BatchProgramHeader*>(scratch.host_table);
+   size_t cursor = align16(static_cast<size_t>(n_programs) * sizeof(BatchProgramHeader));
+   for (uint32_t slot = 0; slot < n_programs; ++slot) {  // table slot `slot` holds program order[slot]
+      const silo_gpu_bitprog& program = programs[order[slot]];
+      BatchProgramHeader& header = headers[slot];
+      header.n_instructions = program.n_instructions;
+      header.n_slots = program.n_slots;
+      header.code_offset = static_cast<uint32_t>(cursor);
+      memcpy(scratch.host_table + cursor, program.code, static_cast<size_t>(program.n_instructions) * 2 * sizeof(uint32_t));
+      cursor += align16(static_cast<size_t>(program.n_instructions) * 2 * sizeof(uint32_t));
+      header.leaf_offset = static_cast<uint32_t>(cursor);
+      if (program.n_leaves != 0) {
+         memcpy(scratch.host_table + cursor, program.leaves, static_cast<size_t>(program.n_leaves) * sizeof(uint64_t*));
+      }
+      cursor += align16(static_cast<size_t>(program.n_leaves) * sizeof(uint64_t*));
+      header.out = out_bitsets_dev != nullptr ? out_bitsets_dev[order[slot]] : nullptr;
+      header.reserved = 0;
+   }
+   auto hip_stream = static_cast<hipStream_t>(stream);
+   const size_t counts_bytes = static_cast<size_t>(n_programs) * EVAL_BATCH_SHARDS * sizeof(uint32_t);
+   HIP_TRY(hipMemcpyAsync(scratch.device_table, scratch.host_table, table_bytes, hipMemcpyHostToDevice, hip_stream));
+   HIP_TRY(hipMemsetAsync(scratch.device_counts, 0, counts_bytes, hip_stream));
+   static std::once_flag lds_once;
+   std::call_once(lds_once, [] {
+      // 4 waves x up to 32 slots x 1 KiB: beyond the 64 KiB a kernel may ask for by default
+      (void)hipFuncSetAttribute(
+         reinterpret_cast<const void*>(k_filter_eval_batch), hipFuncAttributeMaxDynamicSharedMemorySize,
+         (EVAL_BATCH_THREADS / 64) * SILO_GPU_MAX_SLOTS * 64 * static_cast<int>(sizeof(ulonglong2))
+      );
+   });
+   const uint32_t tiles = (store->row_words + EVAL_BATCH_THREADS * 2 - 1) / (EVAL_BATCH_THREADS * 2);
+   for (uint32_t first = 0; first < n_programs;) {  // one launch per slot class: <= 8, <= 16, <= 32 slots
+      const uint32_t class_slots = programs[order[first]].n_slots <= 8 ? 8 : (programs[order[first]].n_slots <= 16 ? 16 : SILO_GPU_MAX_SLOTS);
+      uint32_t last = first;
+      uint32_t max_slots = 1;
+      while (last < n_programs && programs[order[last]].n_slots <= class_slots) {
+         max_slots = std::max(max_slots, programs[order[last]].n_slots);
+         ++last;
+      }
+      const size_t lds_bytes = static_cast<size_t>(EVAL_BATCH_THREADS / 64) * max_slots * 64 * sizeof(ulonglong2);
+      k_filter_eval_batch<<<dim3(last - first, tiles), EVAL_BATCH_THREADS, lds_bytes, hip_stream>>>(
+         scratch.device_table, first, store->sequence_count, store->row_words, max_slots, scratch.device_counts
+      );
+      HIP_TRY(hipGetLastError());
+      first = last;
+   }
+   HIP_TRY(hipMemcpyAsync(scratch.host_counts, scratch.device_counts, counts_bytes, hipMemcpyDeviceToHost, hip_stream));
+   HIP_TRY(hipStreamSynchronize(hip_stream));
+   if (out_counts != nullptr) {
+      for (uint32_t slot = 0; slot < n_programs; ++slot) {
+         uint64_t total = 0;
+         for (uint32_t shard = 0; shard < EVAL_BATCH_SHARDS; ++shard) {
+            total += scratch.host_counts[static_cast<size_t>(slot) * EVAL_BATCH_SHARDS + shard];
+         }
+         out_counts[order[slot]] = total;
+      }
+   }
+   return SILO_GPU_OK;
+}
 
 int silo_gpu_popcount(const silo_gpu_store* store, const uint64_t* bitset_dev, uint64_t* out_count_dev, void* stream) {
    if (store == nullptr || bitset_dev == nullptr || out_count_dev == nullptr) {

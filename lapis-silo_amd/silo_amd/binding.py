@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
-    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
     "silo_gpu_comm_unique_id", "silo_gpu_comm_create", "silo_gpu_comm_destroy", "silo_gpu_comm_rank", "silo_gpu_comm_world",
@@ -160,6 +160,7 @@ def load_library():
     lib.silo_gpu_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.silo_gpu_last_scan_kernel.restype = ctypes.c_char_p
     lib.silo_gpu_last_error.restype = ctypes.c_char_p
+    lib.silo_gpu_filter_eval_batch.argtypes = [vp, ctypes.POINTER(BitProg), ctypes.c_uint32, ctypes.POINTER(vp), c_u64p, vp]
     lib.silo_gpu_comm_unique_id.argtypes = [vp]
     lib.silo_gpu_comm_create.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp)]
     lib.silo_gpu_comm_destroy.argtypes = [vp]
@@ -434,6 +435,23 @@ class GpuStore:
         ])
         prog = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
         _check(self.lib.silo_gpu_filter_eval(self.handle, ctypes.byref(prog), out_bitset, out_count, stream))
+
+    def filter_eval_batch(self, programs, out_bitsets=None, stream=None):
+        """programs: list of (code, leaves, n_slots); returns the cardinalities (one launch for all of them)."""
+        n = len(programs)
+        array = (BitProg * max(1, n))()
+        keep = []
+        for k, (code, leaves, n_slots) in enumerate(programs):
+            code = np.ascontiguousarray(code, dtype=np.uint32)
+            leaf_array = (ctypes.c_void_p * max(1, len(leaves)))(*[(l.value if isinstance(l, ctypes.c_void_p) else l) for l in leaves])
+            keep += [code, leaf_array]
+            array[k] = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
+        outs = None
+        if out_bitsets is not None:
+            outs = (ctypes.c_void_p * max(1, n))(*[(o.value if isinstance(o, ctypes.c_void_p) else o) for o in out_bitsets])
+        counts = np.zeros(max(1, n), dtype=np.uint64)
+        _check(self.lib.silo_gpu_filter_eval_batch(self.handle, array, n, outs, counts.ctypes.data_as(c_u64p), stream))
+        return [int(c) for c in counts[:n]]
 
     def count_buffer(self, stream=None):
         """Zeroed accumulator for cardinalities: COUNT_SHARDS uint64 (their sum is the count)."""

@@ -4,6 +4,10 @@ mode "cpu":  host-side sharding logic only (no GPU): the engine's position windo
              window, summed with a gloo all-reduce, must equal the unsharded oracle counts.
 mode "gpu":  the real engine on cuda:0 in every rank (a 1-GPU box), sharded by position or by
              sequence id; the engine's all-reduce callback is backed by gloo through host memory.
+             Rank 0 also runs every query through the CPU oracle on the unsharded data and reports the comparison.
+mode "batch100": BASELINE.json configs[4] in shape — ONE batch of 100 queries (a lineage filter, every other one ANDed
+             with a nucleotide predicate, each followed by Mutations or AminoAcidMutations) on sequence-id shards,
+             against the oracle.
 Prints one JSON line from rank 0.
 """
 import ctypes
@@ -20,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from oracle import dense  # noqa: E402
+from oracle import silo_oracle as so  # noqa: E402
 from oracle import synth as oracle_synth  # noqa: E402
 from silo_amd import synth  # noqa: E402
 from silo_amd.engine import Engine  # noqa: E402
@@ -53,6 +58,8 @@ def main():
     member = tree.subtree(1)
     by_position = shard == "position"
 
+    if mode == "batch100":
+        by_position = False
     if mode == "cpu":
         engine = Engine(doc)
         engine.set_sharding(rank, world, True)
@@ -122,6 +129,50 @@ def main():
     engine.append_metadata(part, "country", "indexed_string", [f"C{c}" for c in country[rows]])
     engine.append_metadata(part, "age", "int", [str(a) if a % 11 else "" for a in age[rows]])
     engine.finalize()
+
+    oracle_db = None
+    if rank == 0:  # the unsharded database in the CPU oracle (row and position order = the engine's global order)
+        oracle_db = so.Database({"main": list(ref)}, {"S": list(gene)})
+        oracle_db.set_config([("country", "indexed_string"), ("age", "int")], "country")
+        chars = {}
+        for name, is_aa in (("main", False), ("S", True)):
+            sym = oracle_synth.symbol_matrix(models[name], np.arange(N), np.arange(models[name].positions))
+            lut = np.frombuffer(b"-ACGTRYSWKMBDHVN" if not is_aa else b"-ACDEFGHIKLMNPQRSTVWYBZ*X", dtype=np.uint8)
+            chars[name] = [bytes(row).decode("latin-1") for row in lut[sym]]
+        oracle_partition = oracle_db.add_partition({"main": chars["main"]}, {"S": chars["S"]}, [tree.names[i] for i in lineage])
+        oracle_db.add_metadata(oracle_partition, [{"country": f"C{c}", "age": str(a) if a % 11 else ""} for c, a in zip(country, age)])
+
+    def oracle_answers(queries):
+        answers = []
+        for query in queries:
+            try:
+                answers.append([200, json.loads(json.dumps({"queryResult": so.execute_query(oracle_db, query)}))])
+            except so.QueryParseException as error:
+                answers.append([400, {"error": "Bad request", "message": str(error)}])
+        return answers
+
+    if mode == "batch100":
+        sizes = np.bincount(lineage, minlength=L)
+        names = [tree.names[i] for i in np.argsort(-sizes, kind="stable")[:50]]
+        queries = []
+        for k in range(100):
+            expression = {"type": "PangoLineage", "column": "pango_lineage", "value": names[k % 50], "includeSublineages": k % 3 != 0}
+            if k % 2 == 1:
+                predicate = {"type": "NucleotideEquals", "position": 1 + (37 * k) % P, "symbol": "ACGT-"[k % 5]}
+                expression = {"type": "And", "children": [expression, {"type": "Not", "child": predicate} if k % 4 == 1 else {"type": "Maybe", "child": predicate}]}
+            action = {"type": "Mutations", "minProportion": 0.05} if k % 4 < 2 else {"type": "AminoAcidMutations", "minProportion": 0.05}
+            queries.append({"action": action, "filterExpression": expression})
+        batched = engine.execute_batch(queries)
+        dist.barrier()
+        if rank == 0:
+            want = oracle_answers(queries)
+            print(json.dumps({
+                "queries": len(queries), "equal": [got == exp for got, exp in zip(json.loads(json.dumps(batched)), want)],
+                "rows": [len(document.get("queryResult", [])) for _, document in batched],
+            }), flush=True)
+        engine.close()
+        return
+
     queries = [
         {"action": {"type": "Mutations", "minProportion": 0.02}, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": True}},
         {"action": {"type": "AminoAcidMutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
@@ -155,7 +206,9 @@ def main():
         raise AssertionError(f"rank {rank}: batched results differ from one-by-one results")
     dist.barrier()
     if rank == 0:
-        print(json.dumps(results), flush=True)
+        want = oracle_answers(queries)
+        got = json.loads(json.dumps(results))
+        print(json.dumps({"results": results, "matches_oracle": [g == w for g, w in zip(got, want)]}), flush=True)
     engine.close()
 
 

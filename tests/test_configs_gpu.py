@@ -1,0 +1,226 @@
+"""Oracle-checked device runs of the BASELINE.json configurations the benchmark measures.
+
+configs[2]  the exact 32-leaf tree of bench.filter_query — And(Or(8), 3-of-8, Not(Or(8)), Maybe(And(8))) — on a synthetic
+            store the oracle can hold (count AND sequence-id set), and at the full 10 M sequences against a numpy
+            evaluation of the downloaded leaf planes (the planes themselves against the CPU twin of the generator).
+configs[3]  the 10 M-sequence Mutations scan: the compact-index scan (K1i) against the scan of the full code planes over
+            the whole genome, and both against the C port of the reference algorithm (oracle/roaring_port.c) on a sample
+            of positions — the check bench.py's cpu_baseline leg makes, as a test.
+(configs[3] / [4] across ranks: tests/test_multi_rank.py.)
+"""
+import ctypes
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import bench  # noqa: E402
+from oracle import cpu_port, dense  # noqa: E402
+from oracle import silo_oracle as so  # noqa: E402
+from oracle import synth as oracle_synth  # noqa: E402
+from silo_amd import binding, synth  # noqa: E402
+from silo_amd.engine import Engine  # noqa: E402
+
+NUC_CHARS = "-ACGTRYSWKMBDHVN"
+
+
+def bits_of(words):
+    """uint64 words (bit i of word w = row 64 w + i) -> Python int with bit r = row r, the oracle's bitmap form."""
+    return int.from_bytes(np.ascontiguousarray(words, dtype="<u8").tobytes(), "little")
+
+
+# ---- configs[2] on a store the oracle can hold ----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def small_store(built):
+    n, positions = 20_000, 1_500
+    tree = synth.make_lineage_tree(200)
+    lineage = synth.assign_lineages(n, tree, 7)
+    reference = synth.random_reference(positions, "nuc", 11)
+    model = synth.make_model(n, reference, "nuc", tree, lineage, seed=13, store_index=0)
+    model.ambiguous_threshold = 1 << 12  # IUPAC codes often enough that Maybe meets sparsely stored planes
+    genomes = {"nucleotideSequences": [{"name": "main", "sequence": "".join(NUC_CHARS[s] for s in reference)}], "genes": []}
+    engine = Engine(genomes)
+    partition = engine.add_partition(n)
+    engine.generate_synthetic(partition, "main", False, model)
+    engine.set_lineage_column_ids(partition, "pango_lineage", tree.names, lineage)
+    engine.finalize()
+    symbols = oracle_synth.symbol_matrix(model, np.arange(n), np.arange(positions))
+    lut = np.frombuffer(NUC_CHARS.encode(), dtype=np.uint8)
+    database = so.Database({"main": list(reference)}, {})
+    database.add_partition({"main": [bytes(row).decode("latin-1") for row in lut[symbols]]}, {}, [tree.names[i] for i in lineage])
+    yield engine, database, model, tree, symbols
+    engine.close()
+
+
+def config2_variants(model, tree):
+    """The benchmark's tree and the rewrites around it that the reference's compile() treats differently."""
+    tree_query = json.loads(bench.filter_query(model, tree))
+    expression = tree_query["filterExpression"]
+    or8, nof, not_or8, maybe_and8 = expression["children"]
+    leaves = maybe_and8["child"]["children"] + or8["children"] + nof["children"] + not_or8["child"]["children"]
+    assert len(leaves) == 32 and len({(leaf["position"], leaf["symbol"]) for leaf in leaves}) == 32
+    variants = {"configs[2] tree": expression, "Or(8)": or8, "3-of-8": nof, "Not(Or(8))": not_or8, "Maybe(And(8))": maybe_and8}
+    variants["exactly 3-of-8"] = dict(nof, matchExactly=True)
+    variants["Maybe(exactly 2-of-8)"] = {"type": "Maybe", "child": dict(nof, numberOfMatchers=2, matchExactly=True)}  # nof.cpp:220-258
+    variants["Not(tree)"] = {"type": "Not", "child": expression}
+    variants["Maybe(tree)"] = {"type": "Maybe", "child": expression}
+    variants["Exact(Maybe(And(8)))"] = {"type": "Exact", "child": maybe_and8}
+    variants["5-of-32 over all leaves"] = {"type": "N-Of", "numberOfMatchers": 5, "matchExactly": False, "children": leaves}
+    variants["Or(32)"] = {"type": "Or", "children": leaves}
+    variants["Maybe(Or(32))"] = {"type": "Maybe", "child": {"type": "Or", "children": leaves}}
+    variants["And(Not x 8)"] = {"type": "And", "children": [{"type": "Not", "child": leaf} for leaf in leaves[:8]]}
+    return variants
+
+
+def test_config2_tree_count_and_id_set_match_the_oracle(small_store):
+    engine, database, model, tree, _ = small_store
+    n = model.n_sequences
+    counts = {}
+    for name, expression in config2_variants(model, tree).items():
+        query = {"action": {"type": "Aggregated"}, "filterExpression": expression}
+        want_rows = so.execute_query(database, query)
+        assert engine.execute_query(query) == want_rows, name
+        want_bits = so.evaluate_filters(database, so.parse_expression(expression))[0] & ((1 << n) - 1)
+        words, cardinality = engine.evaluate_filter(expression)
+        assert bits_of(words) == want_bits, name  # the sequence-id set, bit for bit
+        assert cardinality == want_rows[0]["count"] == bin(want_bits).count("1"), name
+        counts[name] = cardinality
+    # the check is not vacuous: the tree selects some rows and not all, and its parts differ
+    assert 0 < counts["configs[2] tree"] < counts["Or(8)"] < n and 0 < counts["3-of-8"] < n and counts["Maybe(And(8))"] > 0
+    # the same queries as one batch (the multi-query filter launch) give the same documents
+    queries = [{"action": {"type": "Aggregated"}, "filterExpression": e} for e in config2_variants(model, tree).values()]
+    assert engine.execute_batch(queries) == [engine.execute_raw(q) for q in queries]
+
+
+def test_config2_tree_under_mutations_matches_the_oracle(small_store):
+    engine, database, model, tree, _ = small_store
+    expression = json.loads(bench.filter_query(model, tree))["filterExpression"]
+    for action in ({"type": "Mutations", "minProportion": 0.02}, {"type": "Mutations", "minProportion": 0.0, "orderByFields": ["mutation"], "limit": 300}):
+        query = {"action": action, "filterExpression": expression}
+        assert engine.execute_query(query) == json.loads(json.dumps(so.execute_query(database, query)))
+
+
+# ---- the full-size store: configs[2] and configs[3] at 10 M sequences ----------------------------------------------
+FULL_N = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def full_store(built):
+    engine, model, tree, lineage, window = bench.build_engine(FULL_N, 0, 1, None, 0)
+    assert window == (0, model.positions)
+    yield engine, model, tree, lineage
+    engine.close()
+
+
+def leaf_plane(engine, expression):
+    words, cardinality = engine.evaluate_filter(expression)
+    assert int(np.unpackbits(words.view(np.uint8)).sum()) == cardinality
+    return words
+
+
+def test_config2_tree_at_10m_equals_numpy_over_its_leaf_planes(full_store):
+    engine, model, tree, lineage = full_store
+    expression = json.loads(bench.filter_query(model, tree))["filterExpression"]
+    or8, nof, not_or8, maybe_and8 = expression["children"]
+    plain = [leaf_plane(engine, leaf) for leaf in or8["children"] + nof["children"] + not_or8["child"]["children"]]
+    upper = [leaf_plane(engine, {"type": "Maybe", "child": leaf}) for leaf in maybe_and8["child"]["children"]]
+
+    # the leaf planes against the CPU twin of the generator, on a sample of rows
+    rng = np.random.default_rng(5)
+    rows = np.unique(rng.integers(0, FULL_N, size=60_000))
+    ambiguity = {s: set(codes) for s, codes in enumerate([[0], [1, 5, 10, 8, 12, 13, 14, 15], [2, 6, 10, 7, 11, 13, 14, 15], [3, 5, 9, 7, 11, 12, 14, 15],
+                                                         [4, 6, 9, 8, 11, 12, 13, 15]])}  # nucleotide_symbol_equals.cpp:28-73
+    all_leaves = or8["children"] + nof["children"] + not_or8["child"]["children"] + maybe_and8["child"]["children"]
+    positions = np.array([leaf["position"] - 1 for leaf in all_leaves])
+    symbols = oracle_synth.symbol_matrix(model, rows, positions)  # [rows][32]
+    for k, leaf in enumerate(all_leaves):
+        symbol = NUC_CHARS.index(leaf["symbol"])
+        plane = plain[k] if k < 24 else upper[k - 24]
+        got = (plane[rows >> 6] >> (rows & 63).astype(np.uint64)) & np.uint64(1)
+        accepted = {symbol} if k < 24 else ambiguity[symbol]
+        want = np.isin(symbols[:, k], list(accepted))
+        assert np.array_equal(got.astype(bool), want), leaf
+
+    # the tree over the planes, in numpy
+    valid = np.zeros(len(plain[0]), dtype=np.uint64)
+    valid[: FULL_N // 64] = ~np.uint64(0)
+    if FULL_N % 64:
+        valid[FULL_N // 64] = np.uint64((1 << (FULL_N % 64)) - 1)
+    any_of = np.bitwise_or.reduce(plain[0:8])
+    matches = np.zeros(FULL_N + 64, dtype=np.uint8)[: len(valid) * 64]
+    for plane in plain[8:16]:
+        matches += np.unpackbits(plane.view(np.uint8), bitorder="little")
+    at_least_3 = np.packbits(matches >= 3, bitorder="little").view(np.uint64)
+    none_of = ~np.bitwise_or.reduce(plain[16:24]) & valid
+    all_maybe = np.bitwise_and.reduce(upper)
+    want = any_of & at_least_3 & none_of & all_maybe
+    words, cardinality = engine.evaluate_filter(expression)
+    assert np.array_equal(words, want)
+    want_count = int(np.unpackbits(want.view(np.uint8)).sum())
+    assert cardinality == want_count
+    query = {"action": {"type": "Aggregated"}, "filterExpression": expression}
+    assert engine.execute_query(query) == [{"count": want_count}]
+    assert 0 < want_count < FULL_N
+    # many of them in one batch (one multi-query launch): every answer the same count
+    assert engine.execute_batch([query] * 70) == [(200, {"queryResult": [{"count": want_count}]})] * 70
+
+
+def scan_table(lib, store, filt, begin, end):
+    n = (end - begin) * 5
+    device = ctypes.c_void_p()
+    binding._check(lib.silo_gpu_malloc(4 * n, ctypes.byref(device)))
+    binding._check(lib.silo_gpu_memset_async(device, 0, 4 * n, None))
+    binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, begin, end, device, None))
+    table = np.empty(n, dtype=np.uint32)
+    binding._check(lib.silo_gpu_memcpy_d2h(table.ctypes.data_as(ctypes.c_void_p), device, table.nbytes, None))
+    lib.silo_gpu_free(device)
+    return table.reshape(end - begin, 5)
+
+
+def test_config3_scan_at_10m_compact_index_full_planes_and_c_port_agree(full_store):
+    engine, model, tree, lineage = full_store
+    lib = binding.load_library()
+    store = engine.partition_store(0)
+    member = tree.subtree(tree.names.index(bench.QUERY_LINEAGE))
+    filt = ctypes.c_void_p()
+    binding._check(lib.silo_gpu_bitset_alloc(store.handle, ctypes.byref(filt)))
+    binding._check(lib.silo_gpu_bitset_from_lineages(store.handle, filt, member.ctypes.data_as(ctypes.c_void_p), len(member), None))
+    positions = model.positions
+    try:
+        assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 2, "the 10 M nucleotide store is expected to carry the compact scan index"
+        compact = scan_table(lib, store, filt, 0, positions)
+        previous = lib.silo_gpu_tune(4, -1)  # SILO_GPU_TUNE_COMPACT_INDEX: scan the full code planes
+        try:
+            full = scan_table(lib, store, filt, 0, positions)
+        finally:
+            lib.silo_gpu_tune(4, previous)
+        assert np.array_equal(compact, full)  # two layouts, two kernels, the whole genome
+        mask = member[lineage].astype(bool)
+        assert int(compact.sum(axis=1).max()) <= int(mask.sum())
+        # the reference's algorithm over roaring-format containers (C port) on three windows of positions
+        port_filter = cpu_port.Filter(dense.pack_bits(mask), FULL_N)
+        for begin, count in ((0, 32), (positions // 2 // 64 * 64, 64), (positions - 32, 32)):
+            port = cpu_port.PortStore(FULL_N, begin, count, "nuc", model=model)
+            want, _ = port.mutations_scan(port_filter, n_threads=0, grain=max(1, count // 8))
+            port.close()
+            assert np.array_equal(compact[begin:begin + count], want[:, :5]), (begin, count)
+        # and the engine's rows come from these counts: minProportion 0.05 of the filtered total per position
+        rows = engine.execute_query(bench.make_query())
+        by_mutation = {row["mutation"]: row for row in rows}
+        reference = model.reference
+        expected = 0
+        for position in range(positions):
+            total = int(compact[position].sum())
+            if total == 0:
+                continue
+            threshold = int(np.ceil(total * 0.05) - 1)
+            for symbol in range(5):
+                if symbol != reference[position] and compact[position][symbol] > threshold:
+                    expected += 1
+                    row = by_mutation[f"{NUC_CHARS[reference[position]]}{position + 1}{NUC_CHARS[symbol]}"]
+                    assert row["count"] == int(compact[position][symbol]) and row["proportion"] == compact[position][symbol] / total
+        assert expected == len(rows) > 100
+    finally:
+        lib.silo_gpu_free(filt)

@@ -510,3 +510,108 @@ def test_mutations_select_threshold_arithmetic_matches_host_doubles(built, n_sym
             # a list that is too short still reports the true number of selected cells
             n_short, rows_short = store.mutations_select(counts, reference, proportion, 7)
             assert n_short == n and len(rows_short) == min(n, 7)
+
+
+# ---- the reference's operator known-answer vectors through k_filter_eval ------------------------------------------------
+# tests/golden/operators/operator_vectors.json holds the sets of threshold.test.cpp:41-312, intersection.test.cpp:67-121,
+# union.test.cpp:28-97, complement.test.cpp:10-47 and bitmap_selection.test.cpp:7-43 as data.  Each vector is lowered to a
+# bit-program the way host/operators.cpp lowers the operator (n-ary leaf runs, the bit-sliced counter for Threshold) and
+# run by silo_gpu_filter_eval; ids past row_count in a few expected sets are artefacts of the reference's flip and are
+# clipped, as in tests/test_oracle_golden.py.
+def _operator_vectors():
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operators", "operator_vectors.json")
+    return json.load(open(path))
+
+
+def _run_vector(row_count, leaf_sets, code, n_slots):
+    """Evaluates `code` over leaves = the given id sets on a store of row_count rows; returns (sorted ids, count)."""
+    ref = np.ones(2, dtype=np.uint8)
+    with make_store(max(row_count, 1), [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        leaves = []
+        for ids in leaf_sets:
+            mask = np.zeros(max(row_count, 1), dtype=bool)
+            mask[[i for i in ids if i < row_count]] = True
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            leaves.append(ptr)
+        words, count = _eval(store, code, leaves, n_slots)
+        bits = dense.unpack_bits(words, store.row_words * 64)
+        assert not bits[row_count:].any()  # nothing outside [0, row_count): Complement is ~x & valid
+        ids = [int(i) for i in np.nonzero(bits[:row_count])[0]]
+        assert count == len(ids)
+        return ids
+
+
+def test_reference_threshold_vectors_on_the_device(built):
+    from silo_amd import binding as b
+
+    for vec in _operator_vectors()["threshold"]:
+        rc = vec["row_count"]
+        positive, negative = vec["non_negated"], vec["negated"]
+        k = len(positive) + len(negative)
+        bits = max(1, k.bit_length())
+        for case in vec["cases"]:
+            code = []
+            for bit in range(bits):
+                code += b.encode(b.OP_ZERO, 1 + bit)
+            if positive:
+                code += b.encode(b.OP_CNT_ADD_N, 1, 0, bits, imm=0 | (len(positive) << 16))
+            if negative:
+                code += b.encode(b.OP_CNT_ADD_NOT_N, 1, 0, bits, imm=len(positive) | (len(negative) << 16))
+            code += b.encode(b.OP_CNT_EQ if case["exact"] else b.OP_CNT_GE, 0, 1, bits, imm=case["n"])
+            got = _run_vector(rc, positive + negative, code, 1 + bits)
+            assert got == [i for i in case["expected"] if i < rc], (vec["cite"], case)
+            # the same through single-leaf CNT_ADD instructions (composite children take this form)
+            code = []
+            for bit in range(bits):
+                code += b.encode(b.OP_ZERO, 1 + bit)
+            for leaf in range(len(positive)):
+                code += b.encode(b.OP_CNT_ADD, 1, b.LEAF_OPERAND + leaf, bits)
+            for leaf in range(len(positive), k):
+                code += b.encode(b.OP_NOT, 0, b.LEAF_OPERAND + leaf) + b.encode(b.OP_CNT_ADD, 1, 0, bits)
+            code += b.encode(b.OP_CNT_EQ if case["exact"] else b.OP_CNT_GE, 0, 1, bits, imm=case["n"])
+            assert _run_vector(rc, positive + negative, code, 1 + bits) == got
+
+
+def test_reference_intersection_union_complement_vectors_on_the_device(built):
+    from silo_amd import binding as b
+
+    vectors = _operator_vectors()
+    for vec in vectors["intersection"]:
+        positive, negative = vec["non_negated"], vec["negated"]
+        code = (b.encode(b.OP_AND_N, 0, imm=0 | (len(positive) << 16)) if len(positive) > 1 else b.encode(b.OP_MOV, 0, b.LEAF_OPERAND))
+        if len(negative) > 1:
+            code += b.encode(b.OP_OR_N, 1, imm=len(positive) | (len(negative) << 16)) + b.encode(b.OP_ANDNOT, 0, 0, 1)
+        elif negative:
+            code += b.encode(b.OP_ANDNOT, 0, 0, b.LEAF_OPERAND + len(positive))
+        assert _run_vector(vec["row_count"], positive + negative, code, 2) == vec["expected"], vec["cite"]
+    for vec in vectors["union"]:
+        children = vec["children"]
+        if not children:
+            code = b.encode(b.OP_ZERO, 0)
+        elif len(children) == 1:
+            code = b.encode(b.OP_MOV, 0, b.LEAF_OPERAND)
+        else:
+            code = b.encode(b.OP_OR_N, 0, imm=0 | (len(children) << 16))
+        assert _run_vector(vec["row_count"], children, code, 1) == vec["expected"], vec["cite"]
+    for vec in vectors["complement"]:
+        assert _run_vector(vec["row_count"], [vec["child"]], b.encode(b.OP_NOT, 0, b.LEAF_OPERAND), 1) == vec["expected"], vec["cite"]
+    for vec in vectors["leaf_operators"]:
+        if vec["operator"] in ("Full", "Empty"):
+            code = b.encode(b.OP_ONES if vec["operator"] == "Full" else b.OP_ZERO, 0)
+            assert _run_vector(vec["row_count"], [], code, 1) == vec["expected"], vec["cite"]
+
+
+def test_reference_bitmap_selection_vector_on_the_device(built):
+    """bitmap_selection.test.cpp:8-26 probes ROW-wise bitmaps for a value (a position); the dense store keeps that as
+    the missing symbol's column plane: CONTAINS is the plane, NOT_CONTAINS its complement (host/operators.cpp)."""
+    from silo_amd import binding as b
+
+    for vec in _operator_vectors()["bitmap_selection"]:
+        rows = vec["rows"]
+        column = [row for row, values in enumerate(rows) if vec["value"] in values]  # the transposed view the device holds
+        assert _run_vector(len(rows), [column], b.encode(b.OP_MOV, 0, b.LEAF_OPERAND), 1) == vec["contains"]
+        assert _run_vector(len(rows), [column], b.encode(b.OP_NOT, 0, b.LEAF_OPERAND), 1) == vec["not_contains"]

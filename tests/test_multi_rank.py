@@ -52,8 +52,21 @@ def test_position_windows_and_gloo_all_reduce_cpu(built):
 def test_two_ranks_match_one_rank_gpu(built, shard):
     single = launch(1, "gpu", shard)
     double = launch(2, "gpu", shard)
-    assert [s for s, _ in single] == [200] * (10 if shard == "position" else 8)
-    assert single == double
+    assert [s for s, _ in single["results"]] == [200] * (10 if shard == "position" else 8)
+    assert single["results"] == double["results"]
+    # and not only with each other: rank 0 ran every query through the CPU oracle on the unsharded data
+    assert all(single["matches_oracle"]) and all(double["matches_oracle"]), (single["matches_oracle"], double["matches_oracle"])
+
+
+@pytest.mark.gpu
+def test_hundred_query_batch_on_sequence_shards_matches_oracle_gpu(built):
+    """BASELINE.json configs[4] in shape: ONE silo_engine_execute_batch of 100 queries (lineage filter, every other one
+    ANDed with a nucleotide predicate under Not / Maybe, Mutations and AminoAcidMutations) on two sequence-id sharded
+    ranks — filters evaluated per shard, the scans of the batch sharing plane passes, one all-reduce per count table —
+    against the oracle on the unsharded data."""
+    out = launch(2, "batch100", "sequence")
+    assert out["queries"] == 100 and all(out["equal"]), [k for k, ok in enumerate(out["equal"]) if not ok]
+    assert sum(1 for rows in out["rows"] if rows > 0) >= 80  # most of the hundred answers carry mutation rows
 
 
 @pytest.mark.gpu
