@@ -179,12 +179,15 @@ def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_position
     }
 
 
-def filter_query(model, tree):
+def filter_query(model, tree, variant=0):
     """BASELINE.json configs[2] / SURVEY.md §8d C3: And(Or(8 eq), N-Of(3 of 8 eq), Not(Or(8 eq)), Maybe(And(8 eq)))
-    over 32 distinct (position, symbol) leaves at the positions where most sequences carry a substitution."""
+    over 32 distinct (position, symbol) leaves at the positions where most sequences carry a substitution.
+    variant k > 0: the same tree over the NEXT 32 positions of that ranking (leaves distinct from every other variant's:
+    a batch of variants reads Q x 32 different columns, so its bytes really come from HBM, not from a cache)."""
     carried = model.lineage_symbol != 0xFF                      # [P][L]
     weight = carried.astype(np.float64) @ tree.weights          # share of sequences substituted per position
-    positions = np.argsort(-weight, kind="stable")[:32]
+    positions = np.argsort(-weight, kind="stable")[32 * variant:32 * variant + 32]
+    assert len(positions) == 32 and carried[positions].any(axis=1).all(), "not enough substituted positions for this variant"
     leaves = []
     for p in positions:
         lineages = np.nonzero(carried[p])[0]
@@ -237,6 +240,24 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
         t.join()
     concurrent = sum(done) / (time.perf_counter() - t0)
     w8 = 8 * ((n_sequences + 63) // 64)
+
+    # SURVEY.md §8(d) C3 "batched throughput, >= 64 in flight": 64 DIFFERENT queries of this shape (disjoint leaf sets:
+    # 2048 columns = 2.56 GB at 10 M sequences) as one silo_engine_execute_batch — parse and compile of all 64 on the
+    # host, then ONE k_filter_eval_batch launch for the 64 bit-programs, the counts back in one copy.
+    batch_size = 64
+    batch = [filter_query(model, tree, variant).encode() for variant in range(batch_size)]
+    one_by_one = [engine.execute_text(q) for q in batch]     # also decodes the 2048 one-hot leaf planes into the cache
+    if engine.execute_batch_text(batch) != one_by_one:
+        raise AssertionError("batched filter queries differ from one-by-one execution")
+    sync()
+    reps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        engine.execute_batch_text(batch)
+        reps += 1
+    batch_seconds = (time.perf_counter() - t0) / reps
+    batch_counts = [json.loads(body.decode())["queryResult"][0]["count"] for _, body in one_by_one]
+    kernel = filter_batch_kernel_time(engine, model, tree, batch, n_sequences)
     return {
         "workload": f"BASELINE.json configs[2]: And(Or(8), 3-of-8, Not(Or(8)), Maybe(And(8))) over 32 NucleotideEquals leaves "
                     f"-> Aggregated, {n_sequences} sequences",
@@ -245,6 +266,67 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
         "queries_per_s_1_client": 1.0 / sequential,
         "queries_per_s_8_clients": concurrent,
         "algorithmic_bytes_per_query": 32 * w8,
+        "batched": {
+            "workload": f"{batch_size} different queries of this shape (disjoint leaf sets) in one silo_engine_execute_batch",
+            "queries_in_flight": batch_size,
+            "ms_per_batch": batch_seconds * 1e3,
+            "queries_per_s": batch_size / batch_seconds,
+            "us_per_query": batch_seconds / batch_size * 1e6,
+            "nonzero_counts": sum(1 for c in batch_counts if c > 0),
+            "roofline": kernel,
+        },
+    }
+
+
+def filter_batch_kernel_time(engine, model, tree, batch, n_sequences, reps=20):
+    """The dominant kernel of the batched filter leg on its own: k_filter_eval_batch over the same 64 programs, lowered by
+    hand the way host/operators.cpp lowers the tree (OR_N / CNT_ADD_N / AND_N runs of 8 leaves), timed with HIP events on
+    the stream it is launched on.  Bytes: 32 leaf columns per program, nothing written (count only)."""
+    import ctypes
+
+    from silo_amd import binding as b
+
+    lib = b.load_library()
+    store = engine.partition_store(0)
+    programs = []
+    planes = []
+    symbols = "-ACGTRYSWKMBDHVN"
+    for wire in batch:
+        children = json.loads(wire.decode())["filterExpression"]["children"]
+        groups = [children[0]["children"], children[1]["children"], children[2]["child"]["children"], children[3]["child"]["children"]]
+        leaves = []
+        for group_index, group in enumerate(groups):
+            for leaf in group:
+                plane = ctypes.c_void_p()
+                b._check(lib.silo_gpu_bitset_alloc(store.handle, ctypes.byref(plane)))
+                symbol = symbols.index(leaf["symbol"])
+                b._check(lib.silo_gpu_store_sparse_plane(store.handle, 0, leaf["position"] - 1, symbol, plane, None))
+                # (the Maybe group reads the symbol's plane alone here: the IUPAC planes it ORs in are built once and
+                # cached by the engine as ONE combined column, so the launch reads 32 columns either way)
+                leaves.append(plane)
+                planes.append(plane)
+        code = (b.encode(b.OP_OR_N, 0, imm=0 | (8 << 16))
+                + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3) + b.encode(b.OP_ZERO, 4) + b.encode(b.OP_ZERO, 5)
+                + b.encode(b.OP_CNT_ADD_N, 2, 0, 4, imm=8 | (8 << 16)) + b.encode(b.OP_CNT_GE, 1, 2, 4, imm=3) + b.encode(b.OP_AND, 0, 0, 1)
+                + b.encode(b.OP_OR_N, 1, imm=16 | (8 << 16)) + b.encode(b.OP_ANDNOT, 0, 0, 1)
+                + b.encode(b.OP_AND_N, 1, imm=24 | (8 << 16)) + b.encode(b.OP_AND, 0, 0, 1))
+        programs.append((code, leaves, 6))
+    binding_counts = b.filter_eval_batch(store.handle, programs)
+    start, stop = b.GpuEvent(), b.GpuEvent()
+    start.record()
+    for _ in range(reps):
+        b.filter_eval_batch(store.handle, programs)
+    stop.record()
+    ms = start.elapsed_ms(stop) / reps
+    for plane in planes:
+        lib.silo_gpu_free(plane)
+    w8 = 8 * ((n_sequences + 63) // 64)
+    bytes_per_launch = len(programs) * 32 * w8
+    gbps = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": "k_filter_eval_batch", "programs_per_launch": len(programs), "ms_per_launch_incl_table_upload_and_count_copy": ms,
+        "bytes_per_launch": bytes_per_launch, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+        "traffic": None, "counts_nonzero": sum(1 for c in binding_counts if c > 0),
     }
 
 

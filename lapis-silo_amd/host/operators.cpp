@@ -97,6 +97,24 @@ uint32_t OperatorResult::cardinality() const {
    }
 }
 
+bool OperatorResult::prepareCount(ProgramBuilder& builder, silo_gpu_bitprog& program) const {
+   const std::lock_guard<std::mutex> lock(state->mutex);
+   if (state->count.has_value()) {
+      return false;
+   }
+   if (state->root->type() == operators::EMPTY || state->root->type() == operators::FULL) {
+      state->count = state->root->type() == operators::EMPTY ? 0 : state->rows.row_count;
+      return false;
+   }
+   program = builder.finishProgram(state->root->lower(builder));
+   return true;
+}
+
+void OperatorResult::setCount(uint32_t count) const {
+   const std::lock_guard<std::mutex> lock(state->mutex);
+   state->count = count;
+}
+
 const uint64_t* OperatorResult::bitset() const {
    materialize();
    return state->borrowed != nullptr ? state->borrowed : state->bitset.as<uint64_t>();

@@ -95,6 +95,59 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
          outcomes[i].error = std::current_exception();
       }
    }
+   // The filter -> count queries of the batch (Aggregated without groupByFields): every filter program of a partition
+   // in ONE launch (K3b) instead of one latency-bound launch per query.
+   struct CountJob {
+      size_t query;
+      size_t partition;
+      std::unique_ptr<ProgramBuilder> builder;  // owns the code and leaf arrays the program points into
+      silo_gpu_bitprog program;
+   };
+   std::vector<CountJob> jobs;
+   for (size_t i = 0; i < queries.size(); ++i) {
+      if (outcomes[i].error != nullptr || !parsed[i]->action->countsOnly()) {
+         continue;
+      }
+      const size_t first_job = jobs.size();
+      try {
+         for (size_t partition_index = 0; partition_index < pending[i]->bitmap_filter.size(); ++partition_index) {
+            const OperatorResult& filter = pending[i]->bitmap_filter[partition_index];
+            CountJob job{i, partition_index, std::make_unique<ProgramBuilder>(filter.rows()), {}};
+            if (filter.prepareCount(*job.builder, job.program)) {
+               jobs.push_back(std::move(job));
+            }
+         }
+      } catch (...) {
+         jobs.resize(first_job);
+         outcomes[i].error = std::current_exception();
+      }
+   }
+   if (jobs.size() > 1) {
+      for (size_t partition_index = 0; partition_index < database.partitions.size(); ++partition_index) {
+         std::vector<silo_gpu_bitprog> programs;
+         std::vector<const CountJob*> members;
+         for (const CountJob& job : jobs) {
+            if (job.partition == partition_index) {
+               programs.push_back(job.program);
+               members.push_back(&job);
+            }
+         }
+         if (programs.empty()) {
+            continue;
+         }
+         std::vector<uint64_t> counts(programs.size(), 0);
+         checkGpu(
+            silo_gpu_filter_eval_batch(
+               database.partitions[partition_index].store, programs.data(), static_cast<uint32_t>(programs.size()), nullptr, counts.data(), queryStream()
+            ),
+            "silo_gpu_filter_eval_batch"
+         );
+         for (size_t k = 0; k < members.size(); ++k) {
+            pending[members[k]->query]->bitmap_filter[partition_index].setCount(static_cast<uint32_t>(counts[k]));
+         }
+      }
+   }
+   jobs.clear();  // a single job takes the ordinary path in finish(): one launch with the count slot
    Trace::mark("batch_queued");
    batcher.flush();  // the scans of all queries, several filters per pass over the planes
    Trace::mark("batch_launched");

@@ -71,6 +71,8 @@ class Operator;
 /// Result of Operator::evaluate.  The reference holds a (borrowed or owned) roaring bitmap; here the
 /// evaluation is deferred: cardinality() runs the fused filter kernel in count-only mode, bitset()
 /// materialises the row bitset in HBM (both at most once).
+class ProgramBuilder;
+
 class OperatorResult {
   public:
    OperatorResult() = default;
@@ -82,6 +84,11 @@ class OperatorResult {
    [[nodiscard]] const RowSpace& rows() const;
    /// Runs the kernel now, producing both the bitset and the count in one launch.
    void materialize() const;
+   /// Batched counting (QueryEngine::executeQueries): lowers the operator tree into `builder` and hands out the
+   /// program, to be launched together with those of other queries (silo_gpu_filter_eval_batch); the caller reports
+   /// the cardinality back with setCount.  false: nothing to launch (Empty / Full / already counted).
+   [[nodiscard]] bool prepareCount(ProgramBuilder& builder, silo_gpu_bitprog& program) const;
+   void setCount(uint32_t count) const;
 
   private:
    struct State;
@@ -124,10 +131,8 @@ class ProgramBuilder {
    /// thread's count slot (no counter memset, no device-to-host copy, no stream synchronisation).
    uint32_t runCounting(uint32_t result_slot, uint64_t* out_bitset, void* stream);
 
-  private:
+   /// The finished program (result expected in `result_slot`); points into this builder, which must outlive its use.
    silo_gpu_bitprog finishProgram(uint32_t result_slot);
-
-  public:
 
    const RowSpace rows;
 
@@ -583,6 +588,9 @@ class Action {
    };
 
    virtual ~Action() = default;
+   /// The action needs nothing but the cardinality of the filter (Aggregated without groupByFields): a batch of such
+   /// queries evaluates all its filters in one launch.
+   [[nodiscard]] virtual bool countsOnly() const { return false; }
    void setOrdering(const std::vector<OrderByField>& order_by_fields, std::optional<uint32_t> limit, std::optional<uint32_t> offset);
    [[nodiscard]] virtual QueryResult executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const;
 
@@ -608,6 +616,7 @@ class Aggregated : public Action {
 
   public:
    explicit Aggregated(std::vector<std::string> group_by_fields) : group_by_fields(std::move(group_by_fields)) {}
+   [[nodiscard]] bool countsOnly() const override { return group_by_fields.empty(); }
 };
 
 /// details.cpp: the metadata of the selected rows.  The filter runs on the device; the rows are read from the host

@@ -539,9 +539,10 @@ def _run_vector(row_count, leaf_sets, code, n_slots):
             leaves.append(ptr)
         words, count = _eval(store, code, leaves, n_slots)
         bits = dense.unpack_bits(words, store.row_words * 64)
-        assert not bits[row_count:].any()  # nothing outside [0, row_count): Complement is ~x & valid
+        rows = max(row_count, 1)  # a vector over zero rows runs on a one-row store and is read clipped to no rows
+        assert not bits[rows:].any()  # nothing outside [0, row_count): Complement is ~x & valid
         ids = [int(i) for i in np.nonzero(bits[:row_count])[0]]
-        assert count == len(ids)
+        assert count == int(bits[:rows].sum())
         return ids
 
 
@@ -615,3 +616,57 @@ def test_reference_bitmap_selection_vector_on_the_device(built):
         column = [row for row, values in enumerate(rows) if vec["value"] in values]  # the transposed view the device holds
         assert _run_vector(len(rows), [column], b.encode(b.OP_MOV, 0, b.LEAF_OPERAND), 1) == vec["contains"]
         assert _run_vector(len(rows), [column], b.encode(b.OP_NOT, 0, b.LEAF_OPERAND), 1) == vec["not_contains"]
+
+
+@pytest.mark.parametrize("n", [100, 70_000, 300_001])
+def test_filter_eval_batch_matches_numpy_and_single_launches(built, n):
+    """k_filter_eval_batch: many bit-programs of one store in one launch (programs with few and with many slots go in
+    separate launches of the same call) — counts and bitsets equal to numpy and to silo_gpu_filter_eval one by one."""
+    from silo_amd import binding as b
+
+    rng = np.random.default_rng(n + 1)
+    masks = [rng.random(n) < p for p in (0.5, 0.2, 0.7, 0.05, 0.9, 0.33, 0.01, 0.6)]
+    ref = np.ones(4, dtype=np.uint8)
+    with make_store(n, [dict(name="s", alphabet="nuc", reference=ref)]) as store:
+        leaves = []
+        for m in masks:
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(m))
+            leaves.append(ptr)
+        L = b.LEAF_OPERAND
+        total = sum(m.astype(int) for m in masks)
+        programs, wants = [], []
+
+        def add(code, n_slots, want, program_leaves=None):
+            programs.append((code, leaves if program_leaves is None else program_leaves, n_slots))
+            wants.append(want)
+
+        add(b.encode(b.OP_OR_N, 0, imm=0 | (8 << 16)), 1, np.logical_or.reduce(masks))
+        add(b.encode(b.OP_AND_N, 0, imm=1 | (3 << 16)), 1, masks[1] & masks[2] & masks[3])
+        for k in range(0, 10):  # k-of-8 with a 4-bit counter in slots 1..4
+            zero = b.encode(b.OP_ZERO, 1) + b.encode(b.OP_ZERO, 2) + b.encode(b.OP_ZERO, 3) + b.encode(b.OP_ZERO, 4)
+            add(zero + b.encode(b.OP_CNT_ADD_N, 1, 0, 4, imm=0 | (8 << 16)) + b.encode(b.OP_CNT_GE, 0, 1, 4, imm=k), 5, total >= k)
+            add(zero + b.encode(b.OP_CNT_ADD_NOT_N, 1, 0, 4, imm=0 | (8 << 16)) + b.encode(b.OP_CNT_EQ, 0, 1, 4, imm=k), 5, (8 - total) == k)
+        add(b.encode(b.OP_AND, 0, L + 0, L + 1) + b.encode(b.OP_NOT, 1, L + 2) + b.encode(b.OP_OR, 0, 0, 1) + b.encode(b.OP_ANDNOT, 0, 0, L + 3), 2,
+            ((masks[0] & masks[1]) | ~masks[2]) & ~masks[3])
+        add(b.encode(b.OP_ONES, 0), 1, np.ones(n, bool))
+        add(b.encode(b.OP_ZERO, 0), 1, np.zeros(n, bool))
+        add(b.encode(b.OP_MOV, 0, L + 0), 1, masks[6], [leaves[6]])  # a program with its own (short) leaf list
+        # slot-hungry programs (second and third launch class): the value travels through slots 11 and 30
+        add(b.encode(b.OP_MOV, 11, L + 4) + b.encode(b.OP_AND, 0, 11, L + 5), 12, masks[4] & masks[5])
+        add(b.encode(b.OP_MOV, 30, L + 7) + b.encode(b.OP_NOT, 31, 30) + b.encode(b.OP_OR, 0, 31, L + 1), 32, ~masks[7] | masks[1])
+        outs = [store.bitset_alloc() for _ in programs]
+        counts = store.filter_eval_batch(programs, outs)
+        assert counts == [int(w.sum()) for w in wants]
+        for out, want, (code, program_leaves, n_slots) in zip(outs, wants, programs):
+            words = store.bitset_download(out)
+            assert np.array_equal(dense.unpack_bits(words, n), want)
+            assert not dense.unpack_bits(words, store.row_words * 64)[n:].any()
+            single_words, single_count = _eval(store, code, program_leaves, n_slots)
+            assert np.array_equal(single_words, words) and single_count == int(want.sum())
+        # count only, and the empty batch
+        assert store.filter_eval_batch(programs) == counts
+        assert store.filter_eval_batch([]) == []
+        # a bad operand is refused on the host, nothing is launched
+        with pytest.raises(b.SiloGpuError):
+            store.filter_eval_batch(programs + [(b.encode(b.OP_AND, 0, 5, 6), leaves, 2)])
