@@ -257,6 +257,28 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
         reps += 1
     batch_seconds = (time.perf_counter() - t0) / reps
     batch_counts = [json.loads(body.decode())["queryResult"][0]["count"] for _, body in one_by_one]
+
+    # the same with several request threads (the box's CPU share, at most 16), each submitting such batches on its own
+    # stream: host-side parsing and compilation (the larger part of a batch's wall time) run in parallel, the launches
+    # overlap on the device
+    n_clients = max(2, min(16, cpu_share()))
+    batches_done = []
+
+    def batch_client():
+        k = 0
+        end = time.perf_counter() + seconds
+        while time.perf_counter() < end:
+            engine.execute_batch_text(batch)
+            k += 1
+        batches_done.append(k)
+
+    threads = [threading.Thread(target=batch_client) for _ in range(n_clients)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    batched_concurrent = sum(batches_done) * batch_size / (time.perf_counter() - t0)
     kernel = filter_batch_kernel_time(engine, model, tree, batch, n_sequences)
     return {
         "workload": f"BASELINE.json configs[2]: And(Or(8), 3-of-8, Not(Or(8)), Maybe(And(8))) over 32 NucleotideEquals leaves "
@@ -272,6 +294,10 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
             "ms_per_batch": batch_seconds * 1e3,
             "queries_per_s": batch_size / batch_seconds,
             "us_per_query": batch_seconds / batch_size * 1e6,
+            "client_threads": n_clients,
+            "queries_per_s_all_clients": batched_concurrent,
+            "GBps_all_clients": batched_concurrent * 32 * w8 / 1e9,
+            "frac_of_peak_all_clients": batched_concurrent * 32 * w8 / 1e9 / HBM_PEAK_GBS,
             "nonzero_counts": sum(1 for c in batch_counts if c > 0),
             "roofline": kernel,
         },
@@ -311,11 +337,12 @@ def filter_batch_kernel_time(engine, model, tree, batch, n_sequences, reps=20):
                 + b.encode(b.OP_OR_N, 1, imm=16 | (8 << 16)) + b.encode(b.OP_ANDNOT, 0, 0, 1)
                 + b.encode(b.OP_AND_N, 1, imm=24 | (8 << 16)) + b.encode(b.OP_AND, 0, 0, 1))
         programs.append((code, leaves, 6))
-    binding_counts = b.filter_eval_batch(store.handle, programs)
+    prepared = b.PreparedPrograms(programs)  # marshalled once: the timed loop is the C call alone
+    binding_counts = prepared.launch(store.handle)
     start, stop = b.GpuEvent(), b.GpuEvent()
     start.record()
     for _ in range(reps):
-        b.filter_eval_batch(store.handle, programs)
+        prepared.launch(store.handle)
     stop.record()
     ms = start.elapsed_ms(stop) / reps
     for plane in planes:
@@ -324,7 +351,8 @@ def filter_batch_kernel_time(engine, model, tree, batch, n_sequences, reps=20):
     bytes_per_launch = len(programs) * 32 * w8
     gbps = bytes_per_launch / (ms * 1e-3) / 1e9
     return {
-        "bound": "hbm", "kernel": "k_filter_eval_batch", "programs_per_launch": len(programs), "ms_per_launch_incl_table_upload_and_count_copy": ms,
+        "bound": "hbm", "kernel": "k_filter_eval_batch", "programs_per_launch": len(programs),
+        "ms_per_launch": ms, "timed": "HIP events around silo_gpu_filter_eval_batch: program-table upload, counter memset, the kernel, count copy and its wait",
         "bytes_per_launch": bytes_per_launch, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
         "traffic": None, "counts_nonzero": sum(1 for c in binding_counts if c > 0),
     }

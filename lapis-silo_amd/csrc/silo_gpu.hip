@@ -242,6 +242,16 @@ __device__ __forceinline__ ulonglong2 loadPlane16(const uint64_t* ptr) {
    }
 }
 
+// 16-byte load through a pointer that is known to point into device memory but was itself read from memory (a table
+// of leaf pointers): without the explicit global address space the compiler has to emit flat_load, which may alias LDS —
+// every such load is then fenced against the slot accesses around it (s_waitcnt vmcnt(0) lgkmcnt(0)) and runs of
+// independent leaf loads are serialised.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 loadGlobal16(const uint64_t* ptr) {
+   const u64x2 v = *(const __attribute__((address_space(1))) u64x2*)(ptr);
+   return make_ulonglong2(v.x, v.y);
+}
+
 constexpr uint32_t SCAN_MAX_RANGES = 16;
 // the per-filter sector counters sit 256 bytes apart: atomics on one L2 channel serialise (~12 ns each), and a dense
 // filter makes every block add to its counter
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(EVAL_BATCH_THREADS) void k_filter_eval_batch(
       valid = {silo_gpu::valid_mask(w, sequence_count), silo_gpu::valid_mask(w + 1, sequence_count)};
    }
    const auto leaf = [&](uint32_t index) -> Word2 {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(leaves[index] + w_safe);
+      const ulonglong2 v = loadGlobal16(leaves[index] + w_safe);
       return {v.x, v.y};
    };
    const auto get = [&](uint32_t index) -> Word2 {

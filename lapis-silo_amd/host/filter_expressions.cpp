@@ -423,23 +423,29 @@ namespace {
 /// OR of up to 8 planes, most of them nearly empty IUPAC planes.  The database is immutable, so the combined plane
 /// is built once (one fused launch) and kept in the partition's derived-plane cache next to the materialised sparse
 /// planes; later queries read ONE column instead of up to eight.  Beyond the cache budget the plain Or is returned.
+template <typename Expand>
 std::unique_ptr<Operator> cachedUpperBoundPlane(
-   const Database& database, const DatabasePartition& partition, uint32_t seqstore_id, uint32_t position, uint32_t symbol,
-   std::unique_ptr<Operator> expanded
+   const Database& database, const DatabasePartition& partition, uint32_t seqstore_id, uint32_t position, uint32_t symbol, Expand&& expand
 ) {
    const RowSpace rows = rowsOf(partition);
-   if (database.broadcast != nullptr || expanded->type() == operators::INDEX_SCAN || expanded->type() == operators::EMPTY ||
-       expanded->type() == operators::FULL) {
-      return expanded;  // leaf exchange between ranks is in play, or there is nothing to combine
+   if (database.broadcast != nullptr) {
+      return expand();  // leaf exchange between ranks is in play: every leaf travels on its own
    }
    const uint64_t key = (uint64_t{1} << 63) | (static_cast<uint64_t>(seqstore_id) << 40) | (static_cast<uint64_t>(position) << 8) | symbol;
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
    {
       const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
       const auto found = partition.sparse_cache.find(key);
-      if (found != partition.sparse_cache.end()) {
+      if (found != partition.sparse_cache.end()) {  // the usual case: no expansion is even built
          return std::make_unique<operators::IndexScan>(found->second.as<uint64_t>(), rows);
       }
+   }
+   std::unique_ptr<Operator> expanded = expand();
+   if (expanded->type() == operators::INDEX_SCAN || expanded->type() == operators::EMPTY || expanded->type() == operators::FULL) {
+      return expanded;  // there is nothing to combine
+   }
+   {
+      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
       if ((partition.sparse_cache.size() + 1) * row_bytes > DatabasePartition::SPARSE_CACHE_BYTES) {
          return expanded;
       }
@@ -487,14 +493,16 @@ std::unique_ptr<Operator> NucleotideSymbolEquals::compile(
    }
    const Nucleotide::Symbol nucleotide_symbol = value.value_or(seq_store_partition.reference_sequence.at(position));
    if (mode == UPPER_BOUND) {
-      const auto& symbols_to_match = AMBIGUITY_NUC_SYMBOLS.at(static_cast<uint32_t>(nucleotide_symbol));
-      ExpressionVector symbol_filters;
-      for (const auto symbol : symbols_to_match) {
-         symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
-      }
+      const auto expand = [&]() {  // nucleotide_symbol_equals.cpp:137-149: the symbol or any code that may stand for it
+         const auto& symbols_to_match = AMBIGUITY_NUC_SYMBOLS.at(static_cast<uint32_t>(nucleotide_symbol));
+         ExpressionVector symbol_filters;
+         for (const auto symbol : symbols_to_match) {
+            symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
+         }
+         return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+      };
       return cachedUpperBoundPlane(
-         database, database_partition, seq_store_partition.seqstore_id, position, static_cast<uint32_t>(nucleotide_symbol),
-         Or(std::move(symbol_filters)).compile(database, database_partition, NONE)
+         database, database_partition, seq_store_partition.seqstore_id, position, static_cast<uint32_t>(nucleotide_symbol), expand
       );
    }
    return symbolPlane<Nucleotide>(database, seq_store_partition, database_partition, position, nucleotide_symbol);
@@ -910,7 +918,7 @@ std::unique_ptr<Expression> parseExpression(const json::Value& json) {  // expre
    CHECK_SILO_QUERY(
       json["type"].is_string(), "The field 'type' in all filter expressions needs to be a string, but is: " + json["type"].dump()
    )
-   const std::string expression_type = json["type"].as_string();
+   const std::string& expression_type = json["type"].as_string();
    if (expression_type == "True") {
       return std::make_unique<True>();
    }

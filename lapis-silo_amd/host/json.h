@@ -14,6 +14,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <vector>
 
 namespace silo::json {
@@ -35,7 +36,7 @@ class ObjectMembers {
    ObjectMembers(ObjectMembers&&) noexcept;
    ObjectMembers& operator=(ObjectMembers);
    ~ObjectMembers();
-   [[nodiscard]] const Value* find(const std::string& key) const;
+   [[nodiscard]] const Value* find(std::string_view key) const;
    /// Inserts or overwrites (later duplicates win, as in nlohmann).
    Value& insertOrAssign(std::string key, Value value);
    [[nodiscard]] const Member* begin() const;
@@ -78,20 +79,23 @@ class Value {
    [[nodiscard]] bool is_array() const { return kind_ == Kind::Array; }
    [[nodiscard]] bool is_object() const { return kind_ == Kind::Object; }
 
-   [[nodiscard]] bool contains(const std::string& key) const {
+   // keys are looked up as views: a lookup by literal builds no std::string (most keys of the query surface are longer
+   // than the small-string buffer)
+   [[nodiscard]] bool contains(std::string_view key) const {
       return kind_ == Kind::Object && object_->find(key) != nullptr;
    }
-   [[nodiscard]] const Value& at(const std::string& key) const {
+   [[nodiscard]] const Value& at(std::string_view key) const {
       if (kind_ != Kind::Object) {
          throw std::out_of_range("json value is not an object");
       }
       const Value* found = object_->find(key);
       if (found == nullptr) {
-         throw std::out_of_range("key '" + key + "' not found");
+         throw std::out_of_range("key '" + std::string(key) + "' not found");
       }
       return *found;
    }
-   [[nodiscard]] const Value& operator[](const std::string& key) const { return at(key); }
+   [[nodiscard]] const Value& operator[](std::string_view key) const { return at(key); }
+   [[nodiscard]] const Value& operator[](const char* key) const { return at(std::string_view(key)); }
    Value& set(const std::string& key, Value value) {
       if (kind_ != Kind::Object) {
          *this = object();
@@ -238,7 +242,7 @@ inline ObjectMembers& ObjectMembers::operator=(ObjectMembers other) {
 inline ObjectMembers::~ObjectMembers() {
    delete members_;
 }
-inline const Value* ObjectMembers::find(const std::string& key) const {
+inline const Value* ObjectMembers::find(std::string_view key) const {
    for (const Member& member : *members_) {
       if (member.first == key) {
          return &member.second;

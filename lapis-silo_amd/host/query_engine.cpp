@@ -95,6 +95,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
          outcomes[i].error = std::current_exception();
       }
    }
+   Trace::mark("batch_compiled");
    // The filter -> count queries of the batch (Aggregated without groupByFields): every filter program of a partition
    // in ONE launch (K3b) instead of one latency-bound launch per query.
    struct CountJob {
@@ -122,6 +123,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
          outcomes[i].error = std::current_exception();
       }
    }
+   Trace::mark("batch_lowered");
    if (jobs.size() > 1) {
       for (size_t partition_index = 0; partition_index < database.partitions.size(); ++partition_index) {
          std::vector<silo_gpu_bitprog> programs;

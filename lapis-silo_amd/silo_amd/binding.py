@@ -253,24 +253,32 @@ def encode(op, dst=0, a=0, b=0, imm=0):
     return [op | (dst << 8) | (a << 16) | (b << 24), imm]
 
 
+class PreparedPrograms:
+    """A batch of bit-programs marshalled once (ctypes arrays), so that repeated launches cost no Python work."""
+
+    def __init__(self, programs, out_bitsets=None):
+        self.n = len(programs)
+        self.array = (BitProg * max(1, self.n))()
+        self._keep = []
+        for k, (code, leaves, n_slots) in enumerate(programs):
+            code = np.ascontiguousarray(code, dtype=np.uint32)
+            leaf_array = (ctypes.c_void_p * max(1, len(leaves)))(*[(l.value if isinstance(l, ctypes.c_void_p) else l) for l in leaves])
+            self._keep += [code, leaf_array]
+            self.array[k] = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
+        self.outs = None
+        if out_bitsets is not None:
+            self.outs = (ctypes.c_void_p * max(1, self.n))(*[(o.value if isinstance(o, ctypes.c_void_p) else o) for o in out_bitsets])
+        self.counts = np.zeros(max(1, self.n), dtype=np.uint64)
+
+    def launch(self, store_handle, stream=None):
+        _check(load_library().silo_gpu_filter_eval_batch(store_handle, self.array, self.n, self.outs, self.counts.ctypes.data_as(c_u64p), stream))
+        return [int(c) for c in self.counts[:self.n]]
+
+
 def filter_eval_batch(store_handle, programs, out_bitsets=None, stream=None):
     """silo_gpu_filter_eval_batch on a raw store handle.  programs: list of (code, leaves, n_slots) with code a flat list of
     uint32 (2 per instruction) and leaves device pointers; returns the cardinalities (one launch for all of them)."""
-    lib = load_library()
-    n = len(programs)
-    array = (BitProg * max(1, n))()
-    keep = []
-    for k, (code, leaves, n_slots) in enumerate(programs):
-        code = np.ascontiguousarray(code, dtype=np.uint32)
-        leaf_array = (ctypes.c_void_p * max(1, len(leaves)))(*[(l.value if isinstance(l, ctypes.c_void_p) else l) for l in leaves])
-        keep += [code, leaf_array]
-        array[k] = BitProg(len(code) // 2, code.ctypes.data_as(c_u32p), len(leaves), leaf_array, n_slots)
-    outs = None
-    if out_bitsets is not None:
-        outs = (ctypes.c_void_p * max(1, n))(*[(o.value if isinstance(o, ctypes.c_void_p) else o) for o in out_bitsets])
-    counts = np.zeros(max(1, n), dtype=np.uint64)
-    _check(lib.silo_gpu_filter_eval_batch(store_handle, array, n, outs, counts.ctypes.data_as(c_u64p), stream))
-    return [int(c) for c in counts[:n]]
+    return PreparedPrograms(programs, out_bitsets).launch(store_handle, stream)
 
 
 class GpuStore:
