@@ -112,7 +112,11 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
  * and selects on the host; 0 = always the host selection.  Results are identical either way.
  * "compact_scan_index" (1 default / 0): whether silo_engine_finalize derives — and the Mutations scans read — the compact
  * scan index of the sequence stores (include/silo_gpu.h, K1i: +50 % HBM for the stores, the scan 1.5x faster for
- * nucleotides and up to 2.5x for amino acids); a process-wide setting of the device library.  Unknown name: error. */
+ * nucleotides and up to 2.5x for amino acids); a process-wide setting of the device library.
+ * "compat_remove_quirk" (1 default / 0): SILO_COMPAT_REMOVE_QUIRK — HasNucleotideMutation / HasAminoAcidMutation build their
+ * symbol lists as the reference does, with std::remove and no erase (has_mutation.cpp:58-65, has_aa_mutation.cpp:48-52):
+ * at a reference-T (amino acids: reference-STOP) position the reference symbol itself stays in the list.  0 = the list
+ * without the reference symbol, which is what that code meant.  Unknown name: error. */
 int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value);
 
 /* Executes one query.  *out_json is malloc'ed (free with silo_engine_free_string) and holds either the

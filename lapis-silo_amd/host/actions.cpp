@@ -2,6 +2,8 @@
 // Reference: src/silo/query_engine/actions/{action,aggregated,mutations}.cpp.
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <string_view>
 
 #include "query_engine.h"
 
@@ -9,81 +11,69 @@ namespace silo::query_engine::actions {
 
 // ---- Action (action.cpp:37-117) ------------------------------------------------------------------
 void Action::applySort(QueryResult& result) const {  // action.cpp:37-66
-   auto& result_vector = result.query_result;
    if (order_by_fields.empty()) {
       return;
    }
    // The reference's comparator looks every field up in the row's std::map on every comparison; here the fields are
-   // looked up once per row and the sort runs over (row index, field pointers).  Same ordering, same (partial) sort.
+   // looked up once per row and the sort runs over (row index, field pointers).  Same ordering, and like the reference
+   // only the rows the offset / limit window reaches are put in order (a partial sort).
    using Field = std::optional<std::variant<std::string, int32_t, double>>;
-   const size_t n_fields = order_by_fields.size();
-   std::vector<const Field*> keys(result_vector.size() * n_fields);
-   for (size_t row = 0; row < result_vector.size(); ++row) {
-      for (size_t field = 0; field < n_fields; ++field) {
-         keys[row * n_fields + field] = &result_vector[row].fields.at(order_by_fields[field].name);
+   std::vector<QueryResultEntry>& rows = result.query_result;
+   const size_t n_keys = order_by_fields.size();
+   std::vector<const Field*> keys(rows.size() * n_keys);
+   std::vector<uint32_t> order(rows.size());
+   for (size_t row = 0; row < rows.size(); ++row) {
+      order[row] = static_cast<uint32_t>(row);
+      for (size_t k = 0; k < n_keys; ++k) {
+         keys[row * n_keys + k] = &rows[row].fields.at(order_by_fields[k].name);
       }
    }
-   std::vector<uint32_t> order(result_vector.size());
-   for (size_t row = 0; row < order.size(); ++row) {
-      order[row] = static_cast<uint32_t>(row);
-   }
-   auto cmp = [&](uint32_t row1, uint32_t row2) {
-      for (size_t field = 0; field < n_fields; ++field) {
-         const Field& value1 = *keys[row1 * n_fields + field];
-         const Field& value2 = *keys[row2 * n_fields + field];
-         if (value1 == value2) {
-            continue;
+   const auto before = [&](uint32_t left, uint32_t right) {
+      for (size_t k = 0; k < n_keys; ++k) {
+         const Field& a = *keys[left * n_keys + k];
+         const Field& b = *keys[right * n_keys + k];
+         if (!(a == b)) {
+            return (a < b) == order_by_fields[k].ascending;
          }
-         return value1 < value2 ? order_by_fields[field].ascending : !order_by_fields[field].ascending;
       }
       return false;
    };
-   const size_t end_of_sort =
-      std::min(static_cast<size_t>(limit.value_or(result_vector.size()) + offset.value_or(0UL)), result_vector.size());
-   if (end_of_sort < result_vector.size()) {
-      std::partial_sort(order.begin(), order.begin() + static_cast<int64_t>(end_of_sort), order.end(), cmp);
+   const size_t window_end = limit.has_value() ? std::min<size_t>(rows.size(), static_cast<size_t>(*limit) + offset.value_or(0)) : rows.size();
+   if (window_end < rows.size()) {
+      std::partial_sort(order.begin(), order.begin() + static_cast<std::ptrdiff_t>(window_end), order.end(), before);
    } else {
-      std::sort(order.begin(), order.end(), cmp);
+      std::sort(order.begin(), order.end(), before);
    }
    std::vector<QueryResultEntry> sorted;
-   sorted.reserve(result_vector.size());
+   sorted.reserve(rows.size());
    for (const uint32_t row : order) {
-      sorted.push_back(std::move(result_vector[row]));
+      sorted.push_back(std::move(rows[row]));
    }
-   result_vector = std::move(sorted);
+   rows = std::move(sorted);
 }
 
 void Action::applyOffsetAndLimit(QueryResult& result) const {
-   auto& result_vector = result.query_result;
-   size_t end_of_sort =
-      std::min(static_cast<size_t>(limit.value_or(result_vector.size()) + offset.value_or(0UL)), result_vector.size());
-   if (offset.has_value() && offset.value() >= end_of_sort) {
-      result = {};
-      return;
+   // the window [offset, offset + limit) of the (sorted) rows, clipped to what there is: action.cpp:68-95
+   auto& rows = result.query_result;
+   const size_t first = std::min<size_t>(offset.value_or(0), rows.size());
+   const size_t count = limit.has_value() ? std::min<size_t>(*limit, rows.size() - first) : rows.size() - first;
+   if (first != 0) {
+      std::move(rows.begin() + static_cast<std::ptrdiff_t>(first), rows.begin() + static_cast<std::ptrdiff_t>(first + count), rows.begin());
    }
-   if (offset.has_value() && offset.value() > 0) {
-      auto begin = result_vector.begin() + offset.value();
-      auto end = end_of_sort < result_vector.size() ? result_vector.begin() + static_cast<int64_t>(end_of_sort) : result_vector.end();
-      std::copy(begin, end, result_vector.begin());
-      end_of_sort -= offset.value();
-   }
-   if (end_of_sort < result_vector.size()) {
-      result_vector.resize(end_of_sort);
-   }
+   rows.resize(count);
 }
 
-void Action::setOrdering(const std::vector<OrderByField>& order_by_fields_, std::optional<uint32_t> limit_, std::optional<uint32_t> offset_) {
-   order_by_fields = order_by_fields_;
-   limit = limit_;
-   offset = offset_;
+void Action::setOrdering(const std::vector<OrderByField>& fields, std::optional<uint32_t> row_limit, std::optional<uint32_t> row_offset) {
+   order_by_fields = fields;
+   limit = row_limit;
+   offset = row_offset;
 }
 
 QueryResult Action::orderAndLimit(QueryResult result) const {  // action.cpp:110-116
-   if (offset.has_value() && offset.value() >= result.query_result.size()) {
-      return {};
+   if (offset.value_or(0) < result.query_result.size()) {
+      applySort(result);  // sorts no further than the window needs
    }
-   applySort(result);
-   applyOffsetAndLimit(result);
+   applyOffsetAndLimit(result);  // an offset past the end leaves no row
    return result;
 }
 
@@ -256,23 +246,23 @@ QueryResult Aggregated::execute(const Database& database, std::vector<OperatorRe
 template <typename SymbolType>
 std::map<std::string, typename Mutations<SymbolType>::PrefilteredBitmaps> Mutations<SymbolType>::preFilterBitmaps(
    const Database& database, std::vector<OperatorResult>& bitmap_filter
-) {  // mutations.cpp:35-62
-   std::map<std::string, PrefilteredBitmaps> bitmaps_to_evaluate;
-   for (size_t i = 0; i < database.partitions.size(); ++i) {
-      const DatabasePartition& database_partition = database.partitions.at(i);
-      OperatorResult& filter = bitmap_filter[i];
-      filter.materialize();  // one launch yields both the bitset and its cardinality
-      const size_t cardinality = filter.cardinality();
-      if (cardinality == 0) {
+) {  // mutations.cpp:35-62: per sequence store the (filter, partition store) pairs to scan; empty filters drop out, filters
+     // that select every row of their partition go on the list that is answered from stored totals
+   std::map<std::string, PrefilteredBitmaps> per_store;
+   size_t partition_index = 0;
+   for (const DatabasePartition& partition : database.partitions) {
+      OperatorResult& selected = bitmap_filter[partition_index++];
+      selected.materialize();  // one launch yields both the bitset and its cardinality
+      const uint32_t n_selected = selected.cardinality();
+      if (n_selected == 0) {
          continue;
       }
-      const bool full = cardinality == database_partition.sequence_count;
-      for (const auto& [sequence_name, sequence_store] : database_partition.getSequenceStores<SymbolType>()) {
-         auto& target = bitmaps_to_evaluate[sequence_name];
-         (full ? target.full_bitmaps : target.bitmaps).emplace_back(filter, sequence_store);
+      for (const auto& [name, store] : partition.getSequenceStores<SymbolType>()) {
+         PrefilteredBitmaps& lists = per_store[name];
+         (n_selected == partition.sequence_count ? lists.full_bitmaps : lists.bitmaps).emplace_back(selected, store);
       }
    }
-   return bitmaps_to_evaluate;
+   return per_store;
 }
 
 template <typename SymbolType>
@@ -310,12 +300,10 @@ void Mutations<SymbolType>::calculateMutationsPerPosition(
 
 template <typename SymbolType>
 void Mutations<SymbolType>::validateOrderByFields(const Database& /*database*/) const {  // mutations.cpp:166-182
-   const std::vector<std::string> result_field_names{{MUTATION_FIELD_NAME, PROPORTION_FIELD_NAME, COUNT_FIELD_NAME}};
+   // a Mutations row can be ordered by three of its four fields (not by sequenceName)
    for (const OrderByField& field : order_by_fields) {
-      CHECK_SILO_QUERY(
-         std::any_of(result_field_names.begin(), result_field_names.end(), [&](const std::string& result_field) { return result_field == field.name; }),
-         "OrderByField " + field.name + " is not contained in the result of this operation."
-      )
+      const bool sortable = field.name == MUTATION_FIELD_NAME || field.name == PROPORTION_FIELD_NAME || field.name == COUNT_FIELD_NAME;
+      CHECK_SILO_QUERY(sortable, "OrderByField " + field.name + " is not contained in the result of this operation.")
    }
 }
 
@@ -323,39 +311,29 @@ template <typename SymbolType>
 void Mutations<SymbolType>::addMutationsToOutput(
    const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, const uint32_t* counts,
    std::vector<QueryResultEntry>& output
-) const {  // mutations.cpp:184-232
-   const size_t sequence_length = sequence_store.reference_sequence.size();
+) const {  // mutations.cpp:184-232, over the count table the device filled: counts[position][valid symbol]
    constexpr size_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
-   for (size_t pos = 0; pos < sequence_length; ++pos) {
-      const uint32_t* counts_at_position = counts + pos * n_symbols;
-      uint32_t total = 0;
-      for (size_t s = 0; s < n_symbols; ++s) {
-         total += counts_at_position[s];
+   const auto& reference = sequence_store.reference_sequence;
+   for (size_t position = 0; position < reference.size(); ++position) {
+      const uint32_t* cell = counts + position * n_symbols;
+      uint32_t covered = 0;  // rows of the filter with a valid symbol here; uint32 wrap-around like the reference's sum
+      for (size_t k = 0; k < n_symbols; ++k) {
+         covered += cell[k];
       }
-      if (total == 0) {
+      if (covered == 0) {
          continue;
       }
-      const auto threshold_count =
-         min_proportion == 0 ? 0 : static_cast<uint32_t>(std::ceil(static_cast<double>(total) * min_proportion) - 1);
-      const typename SymbolType::Symbol symbol_in_reference_genome = sequence_store.reference_sequence.at(pos);
-      for (size_t s = 0; s < n_symbols; ++s) {
-         const auto symbol = SymbolType::VALID_MUTATION_SYMBOLS[s];
-         if (symbol_in_reference_genome != symbol) {
-            const uint32_t count = counts_at_position[s];
-            if (count > threshold_count) {
-               const double proportion = static_cast<double>(count) / static_cast<double>(total);
-               // same four fields as mutations.cpp:213-224, built in place (the reference copies a temporary map)
-               QueryResultEntry& entry = output.emplace_back();
-               // keys arrive in map order: count < mutation < proportion < sequenceName
-               entry.fields.emplace_hint(entry.fields.end(), COUNT_FIELD_NAME, static_cast<int32_t>(count));
-               entry.fields.emplace_hint(
-                  entry.fields.end(), MUTATION_FIELD_NAME,
-                  SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(pos + 1) + SymbolType::symbolToChar(symbol)
-               );
-               entry.fields.emplace_hint(entry.fields.end(), PROPORTION_FIELD_NAME, proportion);
-               entry.fields.emplace_hint(entry.fields.end(), SEQUENCE_FIELD_NAME, sequence_name);
-            }
+      // a symbol is reported when count >= ceil(covered * minProportion); written as the reference writes it (IEEE double,
+      // then "count > that - 1" in uint32), because the rounding decides rows at the boundary
+      const uint32_t must_exceed = min_proportion == 0 ? 0 : static_cast<uint32_t>(std::ceil(static_cast<double>(covered) * min_proportion) - 1);
+      for (size_t k = 0; k < n_symbols; ++k) {
+         if (SymbolType::VALID_MUTATION_SYMBOLS[k] == reference[position] || cell[k] <= must_exceed) {
+            continue;
          }
+         addSelectedRowToOutput(
+            sequence_name, sequence_store, static_cast<uint32_t>(position),
+            silo_gpu_mutation_row{static_cast<uint32_t>(position), static_cast<uint32_t>(k), cell[k], covered}, output
+         );
       }
    }
 }
@@ -365,16 +343,13 @@ void Mutations<SymbolType>::addSelectedRowToOutput(
    const std::string& sequence_name, const SequenceStore<SymbolType>& sequence_store, uint32_t position, const silo_gpu_mutation_row& row,
    std::vector<QueryResultEntry>& output
 ) const {  // the four fields of mutations.cpp:213-224 for a cell that k_mutations_select let through
-   const typename SymbolType::Symbol symbol_in_reference_genome = sequence_store.reference_sequence.at(position);
-   const auto symbol = SymbolType::VALID_MUTATION_SYMBOLS.at(row.symbol_index);
-   const double proportion = static_cast<double>(row.count) / static_cast<double>(row.total);
+   const char from = SymbolType::symbolToChar(sequence_store.reference_sequence.at(position));
+   const char to = SymbolType::symbolToChar(SymbolType::VALID_MUTATION_SYMBOLS.at(row.symbol_index));
    QueryResultEntry& entry = output.emplace_back();
+   // keys arrive in map order (count < mutation < proportion < sequenceName): every insert is at the end
    entry.fields.emplace_hint(entry.fields.end(), COUNT_FIELD_NAME, static_cast<int32_t>(row.count));
-   entry.fields.emplace_hint(
-      entry.fields.end(), MUTATION_FIELD_NAME,
-      SymbolType::symbolToChar(symbol_in_reference_genome) + std::to_string(position + 1) + SymbolType::symbolToChar(symbol)
-   );
-   entry.fields.emplace_hint(entry.fields.end(), PROPORTION_FIELD_NAME, proportion);
+   entry.fields.emplace_hint(entry.fields.end(), MUTATION_FIELD_NAME, from + std::to_string(position + 1) + to);
+   entry.fields.emplace_hint(entry.fields.end(), PROPORTION_FIELD_NAME, static_cast<double>(row.count) / static_cast<double>(row.total));
    entry.fields.emplace_hint(entry.fields.end(), SEQUENCE_FIELD_NAME, sequence_name);
 }
 
@@ -474,9 +449,9 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
 
 template <typename SymbolType>
 QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScans& scans) const {
-   std::vector<QueryResultEntry> mutation_proportions;
+   std::vector<QueryResultEntry> result_rows;
    if (!scans.fetch) {
-      return QueryResult{std::move(mutation_proportions)};
+      return QueryResult{std::move(result_rows)};
    }
    const MutationTableLayout& layout = database.getMutationTableLayout<SymbolType>();
    constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
@@ -494,7 +469,7 @@ QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScan
       for (const auto& sequence_name : scans.sequence_names) {
          const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
          addMutationsToOutput(
-            sequence_name, sequence_store, table + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols, mutation_proportions
+            sequence_name, sequence_store, table + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols, result_rows
          );
       }
    } else {
@@ -506,19 +481,19 @@ QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScan
          return a.position != b.position ? a.position < b.position : a.symbol_index < b.symbol_index;
       };
       std::sort(sorted.begin(), sorted.end(), before);
-      mutation_proportions.reserve(sorted.size());
+      result_rows.reserve(sorted.size());
       for (const auto& sequence_name : scans.sequence_names) {
          const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
          const uint32_t offset = layout.position_offset.at(sequence_name);
          const auto length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
          auto row = std::lower_bound(sorted.begin(), sorted.end(), silo_gpu_mutation_row{offset, 0, 0, 0}, before);
          for (; row != sorted.end() && row->position < offset + length; ++row) {
-            addSelectedRowToOutput(sequence_name, sequence_store, row->position - offset, *row, mutation_proportions);
+            addSelectedRowToOutput(sequence_name, sequence_store, row->position - offset, *row, result_rows);
          }
       }
    }
    Trace::mark("rows_built");
-   return QueryResult{std::move(mutation_proportions)};
+   return QueryResult{std::move(result_rows)};
 }
 
 template <typename SymbolType>
@@ -558,156 +533,132 @@ OrderByField parseOrderByField(const json::Value& json) {  // action.cpp:119-142
    return {field_name, order_string == "ascending"};
 }
 
+/// A field that holds one name or an array of names (the sequenceName / column fields of Mutations, Insertions, Fasta
+/// and FastaAligned): the names in order, none when the field is absent.  The wording of the two complaints belongs to the
+/// action (the e2e fixtures assert it), so the caller supplies it.
+std::vector<std::string> parseNames(
+   const json::Value& json, std::string_view field, bool required, const std::string& wrong_type_message,
+   const std::function<std::string(const json::Value&)>& wrong_element_message
+) {
+   const bool present = json.contains(field);
+   CHECK_SILO_QUERY((present || !required) && (!present || json[field].is_string() || json[field].is_array()), wrong_type_message)
+   std::vector<std::string> names;
+   if (!present) {
+      return names;
+   }
+   if (json[field].is_string()) {
+      names.push_back(json[field].as_string());
+      return names;
+   }
+   for (const auto& element : json[field].items()) {
+      CHECK_SILO_QUERY(element.is_string(), wrong_element_message(element))
+      names.push_back(element.as_string());
+   }
+   return names;
+}
+
 template <typename SymbolType>
 std::unique_ptr<Action> parseMutations(const json::Value& json) {  // mutations.cpp:274-316
-   CHECK_SILO_QUERY(
-      !json.contains("sequenceName") || (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
-      "Mutations action can have the field sequenceName of type string or an array of strings, but no other type"
-   )
-   std::vector<std::string> sequence_names;
-   if (json.contains("sequenceName") && json["sequenceName"].is_array()) {
-      for (const auto& child : json["sequenceName"].items()) {
-         CHECK_SILO_QUERY(
-            child.is_string(),
-            "The field sequenceName of Mutations action must have type string or an array, if present. Found:" + child.dump()
-         )
-         sequence_names.emplace_back(child.as_string());
+   std::vector<std::string> sequence_names = parseNames(
+      json, "sequenceName", false, "Mutations action can have the field sequenceName of type string or an array of strings, but no other type",
+      [](const json::Value& element) {
+         return "The field sequenceName of Mutations action must have type string or an array, if present. Found:" + element.dump();
       }
-   } else if (json.contains("sequenceName") && json["sequenceName"].is_string()) {
-      sequence_names.emplace_back(json["sequenceName"].as_string());
-   }
+   );
    CHECK_SILO_QUERY(
       json.contains("minProportion") && json["minProportion"].is_number(),
       "Mutations action must contain the field minProportion of type number with limits [0.0, 1.0]. Only mutations are returned if the "
       "proportion of sequences having this mutation, is at least minProportion"
    )
    const double min_proportion = json["minProportion"].as_double();
-   if (min_proportion < 0 || min_proportion > 1) {
-      throw QueryParseException("Invalid proportion: minProportion must be in interval [0.0, 1.0]");
-   }
+   CHECK_SILO_QUERY(min_proportion >= 0 && min_proportion <= 1, "Invalid proportion: minProportion must be in interval [0.0, 1.0]")
    return std::make_unique<Mutations<SymbolType>>(std::move(sequence_names), min_proportion);
 }
 
 template <typename SymbolType>
 std::unique_ptr<Action> parseInsertions(const json::Value& json) {  // insertions.cpp:260-302
-   CHECK_SILO_QUERY(
-      !json.contains("sequenceName") || (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
-      "Insertions action can have the field sequenceName of type string or an array of strings, but no other type"
-   )
-   std::vector<std::string> sequence_names;
-   if (json.contains("sequenceName") && json["sequenceName"].is_array()) {
-      for (const auto& child : json["sequenceName"].items()) {
-         CHECK_SILO_QUERY(
-            child.is_string(), "The field sequenceName of the Insertions action must have type string or an array, if present. Found:" + child.dump()
-         )
-         sequence_names.emplace_back(child.as_string());
+   std::vector<std::string> sequence_names = parseNames(
+      json, "sequenceName", false, "Insertions action can have the field sequenceName of type string or an array of strings, but no other type",
+      [](const json::Value& element) {
+         return "The field sequenceName of the Insertions action must have type string or an array, if present. Found:" + element.dump();
       }
-   } else if (json.contains("sequenceName") && json["sequenceName"].is_string()) {
-      sequence_names.emplace_back(json["sequenceName"].as_string());
-   }
-   CHECK_SILO_QUERY(
-      !json.contains("column") || (json["column"].is_string() || json["column"].is_array()),
-      "Insertions action can have the field column of type string or an array of strings, but no other type"
-   )
-   std::vector<std::string> column_names;
-   if (json.contains("column") && json["column"].is_array()) {
-      for (const auto& child : json["column"].items()) {
-         CHECK_SILO_QUERY(
-            child.is_string(), "The field column of the Insertions action must have type string or an array, if present. Found:" + child.dump()
-         )
-         column_names.emplace_back(child.as_string());
+   );
+   std::vector<std::string> column_names = parseNames(
+      json, "column", false, "Insertions action can have the field column of type string or an array of strings, but no other type",
+      [](const json::Value& element) {
+         return "The field column of the Insertions action must have type string or an array, if present. Found:" + element.dump();
       }
-   } else if (json.contains("column") && json["column"].is_string()) {
-      column_names.emplace_back(json["column"].as_string());
-   }
+   );
    return std::make_unique<InsertionAggregation<SymbolType>>(std::move(column_names), std::move(sequence_names));
 }
+
+/// The sequenceName field of Fasta / FastaAligned (fasta.cpp:247-270, fasta_aligned.cpp:138-161): required.
+std::vector<std::string> parseRequiredSequenceNames(const json::Value& json, const std::string& action_name) {
+   const std::string wrong_type = action_name + " action must have the field sequenceName of type string or an array of strings";
+   return parseNames(json, "sequenceName", true, wrong_type, [&](const json::Value& element) {
+      return wrong_type + "; while parsing array encountered the element " + element.dump() + " which is not of type string";
+   });
+}
+
+}  // namespace
+
+namespace {
+
+std::vector<std::string> parseFieldList(const json::Value& json, std::string_view field) {
+   std::vector<std::string> names;
+   if (json.contains(field)) {
+      for (const auto& name : json[field].items()) {
+         names.push_back(name.as_string());
+      }
+   }
+   return names;
+}
+
+using ActionParser = std::unique_ptr<Action> (*)(const json::Value&);
+/// The "type" values of an action (action.cpp:144-187) and what builds each.
+constexpr std::pair<std::string_view, ActionParser> ACTION_TYPES[] = {
+   {"Aggregated", [](const json::Value& json) -> std::unique_ptr<Action> { return std::make_unique<Aggregated>(parseFieldList(json, "groupByFields")); }},
+   {"Mutations", parseMutations<Nucleotide>},
+   {"AminoAcidMutations", parseMutations<AminoAcid>},
+   {"Details", [](const json::Value& json) -> std::unique_ptr<Action> { return std::make_unique<Details>(parseFieldList(json, "fields")); }},
+   {"FastaAligned", [](const json::Value& json) -> std::unique_ptr<Action> { return std::make_unique<FastaAligned>(parseRequiredSequenceNames(json, "FastaAligned")); }},
+   {"Fasta", [](const json::Value& json) -> std::unique_ptr<Action> { return std::make_unique<Fasta>(parseRequiredSequenceNames(json, "Fasta")); }},
+   {"Insertions", parseInsertions<Nucleotide>},
+   {"AminoAcidInsertions", parseInsertions<AminoAcid>},
+};
 
 }  // namespace
 
 std::unique_ptr<Action> parseAction(const json::Value& json) {  // action.cpp:144-187
    CHECK_SILO_QUERY(json.contains("type"), "The field 'type' is required in any action")
    CHECK_SILO_QUERY(json["type"].is_string(), "The field 'type' in all actions needs to be a string, but is: " + json["type"].dump())
-   const std::string expression_type = json["type"].as_string();
+   const std::string& type = json["type"].as_string();
    std::unique_ptr<Action> action;
-   if (expression_type == "Aggregated") {
-      std::vector<std::string> group_by_fields;
-      if (json.contains("groupByFields")) {
-         for (const auto& field : json["groupByFields"].items()) {
-            group_by_fields.push_back(field.as_string());
-         }
+   for (const auto& [name, parser] : ACTION_TYPES) {
+      if (type == name) {
+         action = parser(json);
+         break;
       }
-      action = std::make_unique<Aggregated>(std::move(group_by_fields));
-   } else if (expression_type == "Mutations") {
-      action = parseMutations<Nucleotide>(json);
-   } else if (expression_type == "AminoAcidMutations") {
-      action = parseMutations<AminoAcid>(json);
-   } else if (expression_type == "Details") {  // details.cpp:221-224
-      std::vector<std::string> fields;
-      if (json.contains("fields")) {
-         for (const auto& field : json["fields"].items()) {
-            fields.push_back(field.as_string());
-         }
-      }
-      action = std::make_unique<Details>(std::move(fields));
-   } else if (expression_type == "FastaAligned") {  // fasta_aligned.cpp:138-161
-      CHECK_SILO_QUERY(
-         json.contains("sequenceName") && (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
-         "FastaAligned action must have the field sequenceName of type string or an array of strings"
-      )
-      std::vector<std::string> sequence_names;
-      if (json["sequenceName"].is_array()) {
-         for (const auto& child : json["sequenceName"].items()) {
-            CHECK_SILO_QUERY(
-               child.is_string(),
-               "FastaAligned action must have the field sequenceName of type string or an array of strings; while parsing array "
-               "encountered the element " +
-                  child.dump() + " which is not of type string"
-            )
-            sequence_names.emplace_back(child.as_string());
-         }
-      } else {
-         sequence_names.emplace_back(json["sequenceName"].as_string());
-      }
-      action = std::make_unique<FastaAligned>(std::move(sequence_names));
-   } else if (expression_type == "Insertions") {
-      action = parseInsertions<Nucleotide>(json);
-   } else if (expression_type == "AminoAcidInsertions") {
-      action = parseInsertions<AminoAcid>(json);
-   } else if (expression_type == "Fasta") {  // fasta.cpp:247-270
-      CHECK_SILO_QUERY(
-         json.contains("sequenceName") && (json["sequenceName"].is_string() || json["sequenceName"].is_array()),
-         "Fasta action must have the field sequenceName of type string or an array of strings"
-      )
-      std::vector<std::string> sequence_names;
-      if (json["sequenceName"].is_array()) {
-         for (const auto& child : json["sequenceName"].items()) {
-            CHECK_SILO_QUERY(
-               child.is_string(),
-               "Fasta action must have the field sequenceName of type string or an array of strings; while parsing array encountered the "
-               "element " +
-                  child.dump() + " which is not of type string"
-            )
-            sequence_names.emplace_back(child.as_string());
-         }
-      } else {
-         sequence_names.emplace_back(json["sequenceName"].as_string());
-      }
-      action = std::make_unique<Fasta>(std::move(sequence_names));
-   } else {
-      throw QueryParseException(expression_type + " is not a valid action");
    }
-   std::vector<OrderByField> order_by_fields;
+   if (action == nullptr) {
+      throw QueryParseException(type + " is not a valid action");
+   }
+   std::vector<OrderByField> ordering;
    if (json.contains("orderByFields")) {
       for (const auto& field : json["orderByFields"].items()) {
-         order_by_fields.push_back(parseOrderByField(field));
+         ordering.push_back(parseOrderByField(field));
       }
    }
-   CHECK_SILO_QUERY(!json.contains("limit") || json["limit"].is_number_unsigned(), "If the action contains a limit, it must be a non-negative number")
-   CHECK_SILO_QUERY(!json.contains("offset") || json["offset"].is_number_unsigned(), "If the action contains an offset, it must be a non-negative number")
-   auto limit = json.contains("limit") ? std::optional<uint32_t>(json["limit"].as_uint32()) : std::nullopt;
-   auto offset = json.contains("offset") ? std::optional<uint32_t>(json["offset"].as_uint32()) : std::nullopt;
-   action->setOrdering(order_by_fields, limit, offset);
+   const auto optionalCount = [&](std::string_view field, const char* complaint) -> std::optional<uint32_t> {
+      if (!json.contains(field)) {
+         return std::nullopt;
+      }
+      CHECK_SILO_QUERY(json[field].is_number_unsigned(), complaint)
+      return json[field].as_uint32();
+   };
+   const auto limit = optionalCount("limit", "If the action contains a limit, it must be a non-negative number");
+   const auto offset = optionalCount("offset", "If the action contains an offset, it must be a non-negative number");
+   action->setOrdering(ordering, limit, offset);
    return action;
 }
 

@@ -338,6 +338,10 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
       engine->database.mutation_row_capacity = static_cast<uint32_t>(value);
       return 0;
    }
+   if (std::strcmp(name, "compat_remove_quirk") == 0 && (value == 0 || value == 1)) {
+      engine->database.compat_remove_quirk = value == 1;  // SILO_COMPAT_REMOVE_QUIRK, see filter_expressions.cpp
+      return 0;
+   }
    if (std::strcmp(name, "compact_scan_index") == 0 && (value == 0 || value == 1)) {
       // process-wide (the device library's knob): 0 before silo_engine_finalize = no index is built (saves a third of the
       // sequence stores' HBM); 0 afterwards = built indexes are not scanned

@@ -307,6 +307,13 @@ class Database {
    /// Mutations selects its result rows on the device into a list of this many cells; a query that selects more
    /// (minProportion 0 over a large filter) fetches the whole count table instead. 0 = always fetch the table.
    uint32_t mutation_row_capacity = 4096;
+   /// SILO_COMPAT_REMOVE_QUIRK: HasNucleotideMutation / HasAminoAcidMutation keep the reference's
+   /// std::remove-without-erase behaviour (filter_expressions.cpp, dropSymbol).  Default on: parity is judged against
+   /// the reference as it is.
+#ifndef SILO_COMPAT_REMOVE_QUIRK
+#define SILO_COMPAT_REMOVE_QUIRK 1
+#endif
+   bool compat_remove_quirk = SILO_COMPAT_REMOVE_QUIRK != 0;
    AllReduceU32 all_reduce = nullptr;
    void* all_reduce_context = nullptr;
    BroadcastBytes broadcast = nullptr;

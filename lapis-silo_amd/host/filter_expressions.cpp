@@ -2,6 +2,7 @@
 // Mirrors src/silo/query_engine/filter_expressions/*.cpp of the reference (cited per function),
 // including the algebraic rewrites and the observable quirks listed in SURVEY.md §8(a).
 #include <algorithm>
+#include <iterator>
 
 #include <cmath>
 #include <regex>
@@ -131,131 +132,175 @@ std::unique_ptr<Operator> False::compile(const Database& /*database*/, const Dat
    return std::make_unique<operators::Empty>(rowsOf(database_partition));
 }
 
-// ---- And (and.cpp:101-227; Selection predicates are outside this path) -----------------------------
-std::string And::toString(const Database& database) const {
-   std::vector<std::string> child_strings;
-   for (const auto& child : children) {
-      child_strings.push_back(child->toString(database));
+// ---- Boolean combinators: And, Or, N-Of -------------------------------------------------------------
+// The reference rewrites each of the three with its own case analysis (and.cpp:101-227, or.cpp:41-94, nof.cpp:35-280).
+// Here all three go through ONE normal form and four constructors.  The compiled children of a combinator are sorted
+// into a Literals record; "every literal", "some literal", "no literal" and "k of the literals" are then built from
+// it.  The sets that come out are the reference's (the e2e goldens, the operator vectors and the randomised trees
+// against the oracle pin that); the operator trees need not be, and the device lowers whatever tree it gets into one
+// bit-program anyway.
+namespace {
+
+/// The compiled children of a combinator.  A child that compiled to a Complement is kept WITHOUT its complement in
+/// `inverted`; children that hold for every row are only counted, children that hold for no row only flagged.
+struct Literals {
+   OperatorVector plain;
+   OperatorVector inverted;
+   std::vector<operators::Predicate> predicates;  // metadata comparisons lifted out of Selection children (And only)
+   int always = 0;
+   bool never = false;
+
+   [[nodiscard]] int size() const { return static_cast<int>(plain.size() + inverted.size()); }
+};
+
+enum class Flatten { CONJUNCTIONS, DISJUNCTIONS, NOTHING };
+
+/// Files one compiled child.  An And splices the literals of a nested Intersection and lifts the predicates of a
+/// nested Selection (and.cpp:124-151); an Or splices a nested Union (or.cpp:56-62); an N-Of keeps children whole.
+void file(Literals& literals, std::unique_ptr<Operator> child, Flatten flatten) {
+   switch (child->type()) {
+      case operators::FULL:
+         ++literals.always;
+         return;
+      case operators::EMPTY:
+         literals.never = true;
+         return;
+      case operators::COMPLEMENT:
+         literals.inverted.push_back(child->negate());
+         return;
+      case operators::INTERSECTION:
+         if (flatten == Flatten::CONJUNCTIONS) {
+            auto& nested = static_cast<operators::Intersection&>(*child);
+            std::move(nested.children.begin(), nested.children.end(), std::back_inserter(literals.plain));
+            std::move(nested.negated_children.begin(), nested.negated_children.end(), std::back_inserter(literals.inverted));
+            return;
+         }
+         break;
+      case operators::UNION:
+         if (flatten == Flatten::DISJUNCTIONS) {
+            auto& nested = static_cast<operators::Union&>(*child);
+            std::move(nested.children.begin(), nested.children.end(), std::back_inserter(literals.plain));
+            return;
+         }
+         break;
+      case operators::SELECTION:
+         if (flatten == Flatten::CONJUNCTIONS) {
+            auto& nested = static_cast<operators::Selection&>(*child);
+            literals.predicates.insert(literals.predicates.end(), nested.predicates.begin(), nested.predicates.end());
+            if (nested.child != nullptr) {
+               file(literals, std::move(nested.child), flatten);
+            }
+            return;
+         }
+         break;
+      default:
+         break;
    }
-   return "And(" + join(child_strings, " & ") + ")";
+   literals.plain.push_back(std::move(child));
 }
 
-std::tuple<OperatorVector, OperatorVector, std::vector<operators::Predicate>> And::compileChildren(
-   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-) const {
-   OperatorVector all_child_operators;
-   for (const auto& expression : children) {
-      all_child_operators.push_back(expression->compile(database, database_partition, mode));
+Literals compileLiterals(
+   const ExpressionVector& children, const Database& database, const DatabasePartition& partition, Expression::AmbiguityMode mode, Flatten flatten
+) {
+   Literals literals;
+   for (const auto& child : children) {
+      file(literals, child->compile(database, partition, mode), flatten);
    }
-   OperatorVector non_negated_child_operators;
-   OperatorVector negated_child_operators;
-   std::vector<operators::Predicate> predicates;
-   // by index: the child of a Selection is appended to the list while it is walked (and.cpp:138-151)
-   for (size_t index = 0; index < all_child_operators.size(); ++index) {
-      auto& child = all_child_operators[index];
-      if (child->type() == operators::FULL) {
-         continue;
+   return literals;
+}
+
+/// Rows where every plain literal holds and no inverted one does.
+std::unique_ptr<Operator> everyLiteral(OperatorVector&& plain, OperatorVector&& inverted, RowSpace rows) {
+   if (plain.empty()) {
+      if (inverted.empty()) {
+         return std::make_unique<operators::Full>(rows);
       }
-      if (child->type() == operators::EMPTY) {
-         OperatorVector empty;
-         empty.emplace_back(std::make_unique<operators::Empty>(rowsOf(database_partition)));
-         return {std::move(empty), OperatorVector(), std::vector<operators::Predicate>{}};
-      }
-      if (child->type() == operators::INTERSECTION) {
-         auto* intersection_child = dynamic_cast<operators::Intersection*>(child.get());
-         for (auto& grandchild : intersection_child->children) {
-            non_negated_child_operators.push_back(std::move(grandchild));
-         }
-         for (auto& grandchild : intersection_child->negated_children) {
-            negated_child_operators.push_back(std::move(grandchild));
-         }
-      } else if (child->type() == operators::COMPLEMENT) {
-         negated_child_operators.emplace_back(child->negate());
-      } else if (child->type() == operators::SELECTION) {
-         auto* selection_child = dynamic_cast<operators::Selection*>(child.get());
-         predicates.insert(predicates.end(), selection_child->predicates.begin(), selection_child->predicates.end());
-         if (selection_child->child != nullptr) {
-            std::unique_ptr<Operator> grandchild = std::move(selection_child->child);
-            all_child_operators.push_back(std::move(grandchild));  // may reallocate: `child` is not used afterwards
-         }
-      } else {
-         non_negated_child_operators.push_back(std::move(child));
-      }
+      std::unique_ptr<Operator> excluded =
+         inverted.size() == 1 ? std::move(inverted.front()) : std::make_unique<operators::Union>(std::move(inverted), rows);
+      return std::make_unique<operators::Complement>(std::move(excluded), rows);
    }
-   return {std::move(non_negated_child_operators), std::move(negated_child_operators), std::move(predicates)};
+   if (plain.size() == 1 && inverted.empty()) {
+      return std::move(plain.front());
+   }
+   return std::make_unique<operators::Intersection>(std::move(plain), std::move(inverted), rows);
+}
+
+/// Rows where some plain literal holds or some inverted one does not: De Morgan of everyLiteral with the roles swapped.
+std::unique_ptr<Operator> someLiteral(OperatorVector&& plain, OperatorVector&& inverted, RowSpace rows) {
+   if (inverted.empty()) {
+      if (plain.empty()) {
+         return std::make_unique<operators::Empty>(rows);
+      }
+      return plain.size() == 1 ? std::move(plain.front()) : std::make_unique<operators::Union>(std::move(plain), rows);
+   }
+   return std::make_unique<operators::Complement>(everyLiteral(std::move(inverted), std::move(plain), rows), rows);
+}
+
+/// Rows where at least (or exactly) `wanted` of the literals hold; literals that always hold have been taken off
+/// `wanted` by the caller, literals that never hold are gone.
+std::unique_ptr<Operator> countLiterals(Literals&& literals, int wanted, bool exactly, RowSpace rows) {
+   const int available = literals.size();
+   if (wanted > available || (exactly && wanted < 0)) {
+      return std::make_unique<operators::Empty>(rows);
+   }
+   if (wanted <= 0 && !exactly) {
+      return std::make_unique<operators::Full>(rows);
+   }
+   if (wanted == available) {  // all of them (for "exactly 0 of 0": every row)
+      return everyLiteral(std::move(literals.plain), std::move(literals.inverted), rows);
+   }
+   if (wanted == 0) {  // exactly none
+      return everyLiteral(std::move(literals.inverted), std::move(literals.plain), rows);
+   }
+   if (wanted == 1 && !exactly) {
+      return someLiteral(std::move(literals.plain), std::move(literals.inverted), rows);
+   }
+   return std::make_unique<operators::Threshold>(std::move(literals.plain), std::move(literals.inverted), static_cast<uint32_t>(wanted), exactly, rows);
+}
+
+std::string describe(const ExpressionVector& children, const Database& database, const char* separator) {
+   std::string text;
+   for (const auto& child : children) {
+      text += (text.empty() ? "" : separator) + child->toString(database);
+   }
+   return text;
+}
+
+}  // namespace
+
+std::string And::toString(const Database& database) const {
+   return "And(" + describe(children, database, " & ") + ")";
 }
 
 std::unique_ptr<Operator> And::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   auto [non_negated_child_operators, negated_child_operators, predicates] = compileChildren(database, database_partition, mode);
    const RowSpace rows = rowsOf(database_partition);
-   if (non_negated_child_operators.empty() && negated_child_operators.empty()) {
-      if (predicates.empty()) {
-         return std::make_unique<operators::Full>(rows);
-      }
-      return std::make_unique<operators::Selection>(std::move(predicates), rows);
+   Literals literals = compileLiterals(children, database, database_partition, mode, Flatten::CONJUNCTIONS);
+   if (literals.never) {
+      return std::make_unique<operators::Empty>(rows);
    }
-   std::unique_ptr<Operator> index_arithmetic_operator;
-   if (non_negated_child_operators.size() == 1 && negated_child_operators.empty()) {
-      index_arithmetic_operator = std::move(non_negated_child_operators[0]);
-   } else if (negated_child_operators.size() == 1 && non_negated_child_operators.empty()) {
-      index_arithmetic_operator = std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
-   } else if (non_negated_child_operators.empty()) {
-      auto union_ret = std::make_unique<operators::Union>(std::move(negated_child_operators), rows);
-      index_arithmetic_operator = std::make_unique<operators::Complement>(std::move(union_ret), rows);
-   } else {
-      index_arithmetic_operator =
-         std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
+   if (literals.predicates.empty()) {
+      return everyLiteral(std::move(literals.plain), std::move(literals.inverted), rows);
    }
-   if (predicates.empty()) {
-      return index_arithmetic_operator;
+   if (literals.size() == 0) {
+      return std::make_unique<operators::Selection>(std::move(literals.predicates), rows);
    }
-   return std::make_unique<operators::Selection>(std::move(index_arithmetic_operator), std::move(predicates), rows);
+   // the comparisons filter what the index arithmetic leaves (and.cpp:203-227)
+   return std::make_unique<operators::Selection>(
+      everyLiteral(std::move(literals.plain), std::move(literals.inverted), rows), std::move(literals.predicates), rows
+   );
 }
 
-// ---- Or (or.cpp:41-94) ---------------------------------------------------------------------------
 std::string Or::toString(const Database& database) const {
-   std::vector<std::string> child_strings;
-   for (const auto& child : children) {
-      child_strings.push_back(child->toString(database));
-   }
-   return "Or(" + join(child_strings, " | ") + ")";
+   return "Or(" + describe(children, database, " | ") + ")";
 }
 
 std::unique_ptr<Operator> Or::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
    const RowSpace rows = rowsOf(database_partition);
-   OperatorVector all_child_operators;
-   for (const auto& expression : children) {
-      all_child_operators.push_back(expression->compile(database, database_partition, mode));
+   Literals literals = compileLiterals(children, database, database_partition, mode, Flatten::DISJUNCTIONS);
+   if (literals.always > 0) {
+      return std::make_unique<operators::Full>(rows);
    }
-   OperatorVector filtered_child_operators;
-   for (auto& child : all_child_operators) {
-      if (child->type() == operators::EMPTY) {
-         continue;
-      }
-      if (child->type() == operators::FULL) {
-         return std::make_unique<operators::Full>(rows);
-      }
-      if (child->type() == operators::UNION) {
-         auto* or_child = dynamic_cast<operators::Union*>(child.get());
-         for (auto& grandchild : or_child->children) {
-            filtered_child_operators.push_back(std::move(grandchild));
-         }
-      } else {
-         filtered_child_operators.push_back(std::move(child));
-      }
-   }
-   if (filtered_child_operators.empty()) {
-      return std::make_unique<operators::Empty>(rows);
-   }
-   if (filtered_child_operators.size() == 1) {
-      return std::move(filtered_child_operators[0]);
-   }
-   if (std::any_of(filtered_child_operators.begin(), filtered_child_operators.end(), [](const auto& child) {
-          return child->type() == operators::COMPLEMENT;
-       })) {
-      return operators::Complement::fromDeMorgan(std::move(filtered_child_operators), rows);
-   }
-   return std::make_unique<operators::Union>(std::move(filtered_child_operators), rows);
+   return someLiteral(std::move(literals.plain), std::move(literals.inverted), rows);
 }
 
 // ---- Negation / Maybe / Exact ----------------------------------------------------------------------
@@ -263,8 +308,8 @@ std::string Negation::toString(const Database& database) const {
    return "!(" + child->toString(database) + ")";
 }
 std::unique_ptr<Operator> Negation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   auto child_operator = child->compile(database, database_partition, invertMode(mode));  // negation.cpp:27-34
-   return child_operator->negate();
+   // an upper bound of the child is a lower bound of its complement: negation.cpp:27-34
+   return child->compile(database, database_partition, invertMode(mode))->negate();
 }
 std::string Maybe::toString(const Database& database) const {
    return "Maybe (" + child->toString(database) + ")";
@@ -279,142 +324,33 @@ std::unique_ptr<Operator> Exact::compile(const Database& database, const Databas
    return child->compile(database, database_partition, AmbiguityMode::LOWER_BOUND);  // exact.cpp:26-32
 }
 
-// ---- N-Of (nof.cpp) ------------------------------------------------------------------------------
-namespace {
-
-std::unique_ptr<Operator> handleTrivialCases(  // nof.cpp:35-88
-   const int updated_number_of_matchers, OperatorVector& non_negated_child_operators, OperatorVector& negated_child_operators,
-   bool match_exactly, RowSpace rows
-) {
-   const int child_operator_count = static_cast<int>(non_negated_child_operators.size() + negated_child_operators.size());
-   if (updated_number_of_matchers > child_operator_count) {
-      return std::make_unique<operators::Empty>(rows);
-   }
-   if (updated_number_of_matchers < 0) {
-      if (match_exactly) {
-         return std::make_unique<operators::Empty>(rows);
-      }
-      return std::make_unique<operators::Full>(rows);
-   }
-   if (updated_number_of_matchers == 0) {
-      if (!match_exactly) {
-         return std::make_unique<operators::Full>(rows);
-      }
-      if (child_operator_count == 0) {
-         return std::make_unique<operators::Full>(rows);
-      }
-      if (child_operator_count == 1) {
-         if (non_negated_child_operators.empty()) {
-            return std::move(negated_child_operators[0]);
-         }
-         return std::make_unique<operators::Complement>(std::move(non_negated_child_operators[0]), rows);
-      }
-      if (negated_child_operators.empty()) {
-         auto union_ret = std::make_unique<operators::Union>(std::move(non_negated_child_operators), rows);
-         return std::make_unique<operators::Complement>(std::move(union_ret), rows);
-      }
-      return std::make_unique<operators::Intersection>(std::move(negated_child_operators), std::move(non_negated_child_operators), rows);
-   }
-   if (updated_number_of_matchers == 1 && child_operator_count == 1) {
-      if (negated_child_operators.empty()) {
-         return std::move(non_negated_child_operators[0]);
-      }
-      return std::make_unique<operators::Complement>(std::move(negated_child_operators[0]), rows);
-   }
-   return nullptr;
-}
-
-std::unique_ptr<Operator> toOperator(  // nof.cpp:90-154
-   const int updated_number_of_matchers, OperatorVector&& non_negated_child_operators, OperatorVector&& negated_child_operators,
-   bool match_exactly, RowSpace rows
-) {
-   auto tmp = handleTrivialCases(updated_number_of_matchers, non_negated_child_operators, negated_child_operators, match_exactly, rows);
-   if (tmp) {
-      return tmp;
-   }
-   const int child_operator_count = static_cast<int>(non_negated_child_operators.size() + negated_child_operators.size());
-   if (updated_number_of_matchers == child_operator_count) {  // handleAndCase
-      if (non_negated_child_operators.empty()) {
-         auto union_ret = std::make_unique<operators::Union>(std::move(negated_child_operators), rows);
-         return std::make_unique<operators::Complement>(std::move(union_ret), rows);
-      }
-      return std::make_unique<operators::Intersection>(std::move(non_negated_child_operators), std::move(negated_child_operators), rows);
-   }
-   if (updated_number_of_matchers == 1 && !match_exactly) {  // handleOrCase
-      if (negated_child_operators.empty()) {
-         return std::make_unique<operators::Union>(std::move(non_negated_child_operators), rows);
-      }
-      auto intersection_ret = std::make_unique<operators::Intersection>(
-         std::move(negated_child_operators), std::move(non_negated_child_operators), rows
-      );
-      return std::make_unique<operators::Complement>(std::move(intersection_ret), rows);
-   }
-   return std::make_unique<operators::Threshold>(
-      std::move(non_negated_child_operators), std::move(negated_child_operators), updated_number_of_matchers, match_exactly, rows
-   );
-}
-
-}  // namespace
-
+// ---- N-Of ------------------------------------------------------------------------------------------
 std::string NOf::toString(const Database& database) const {
-   std::string res = match_exactly ? "[exactly-" + std::to_string(number_of_matchers) + "-of:" : "[" + std::to_string(number_of_matchers) + "-of:";
+   std::string text = match_exactly ? "[exactly-" : "[";
+   text += std::to_string(number_of_matchers) + "-of:";
    for (const auto& child : children) {
-      res += child->toString(database);
-      res += ", ";
+      text += child->toString(database) + ", ";
    }
-   return res + "]";
-}
-
-std::tuple<OperatorVector, OperatorVector, int> NOf::mapChildExpressions(  // nof.cpp:185-218
-   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-) const {
-   OperatorVector non_negated_child_operators;
-   OperatorVector negated_child_operators;
-   int updated_number_of_matchers = number_of_matchers;
-   for (const auto& child_expression : children) {
-      auto child_operator = child_expression->compile(database, database_partition, mode);
-      if (child_operator->type() == operators::EMPTY) {
-         continue;
-      }
-      if (child_operator->type() == operators::FULL) {
-         updated_number_of_matchers--;
-      } else if (child_operator->type() == operators::COMPLEMENT) {
-         negated_child_operators.emplace_back(child_operator->negate());
-      } else {
-         non_negated_child_operators.push_back(std::move(child_operator));
-      }
-   }
-   return {std::move(non_negated_child_operators), std::move(negated_child_operators), updated_number_of_matchers};
-}
-
-std::unique_ptr<Operator> NOf::rewriteNonExact(  // nof.cpp:220-258
-   const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-) const {
-   const RowSpace rows = rowsOf(database_partition);
-   OperatorVector at_least_k;
-   {
-      auto [non_negated, negated, updated] = mapChildExpressions(database, database_partition, mode);
-      at_least_k.emplace_back(toOperator(updated, std::move(non_negated), std::move(negated), false, rows));
-   }
-   OperatorVector at_least_k_plus_one;
-   {
-      auto [non_negated, negated, updated] = mapChildExpressions(database, database_partition, mode);
-      at_least_k_plus_one.emplace_back(toOperator(updated + 1, std::move(non_negated), std::move(negated), false, rows));
-   }
-   return toOperator(2, std::move(at_least_k), std::move(at_least_k_plus_one), false, rows);
+   return text + "]";
 }
 
 std::unique_ptr<Operator> NOf::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   auto [non_negated_child_operators, negated_child_operators, updated_number_of_matchers] =
-      mapChildExpressions(database, database_partition, mode);
-   // nof.cpp:268-271
-   if (mode != NONE && match_exactly && number_of_matchers < static_cast<int>(children.size())) {
-      return rewriteNonExact(database, database_partition, mode);
+   const RowSpace rows = rowsOf(database_partition);
+   const auto atLeastOrExactly = [&](int wanted, bool exactly) {
+      Literals literals = compileLiterals(children, database, database_partition, mode, Flatten::NOTHING);
+      // a literal that holds for every row is one match already (nof.cpp:202-203)
+      return countLiterals(std::move(literals), wanted - literals.always, exactly, rows);
+   };
+   // "exactly k" has no monotone bound of its own: under Maybe / Exact it is "at least k" without "at least k + 1", both
+   // bounded the same way (nof.cpp:220-258, 268-271)
+   if (match_exactly && mode != NONE && number_of_matchers < static_cast<int>(children.size())) {
+      OperatorVector reached;
+      OperatorVector exceeded;
+      reached.push_back(atLeastOrExactly(number_of_matchers, false));
+      exceeded.push_back(atLeastOrExactly(number_of_matchers + 1, false));
+      return std::make_unique<operators::Intersection>(std::move(reached), std::move(exceeded), rows);
    }
-   return toOperator(
-      updated_number_of_matchers, std::move(non_negated_child_operators), std::move(negated_child_operators), match_exactly,
-      rowsOf(database_partition)
-   );
+   return atLeastOrExactly(number_of_matchers, match_exactly);
 }
 
 namespace {
@@ -469,6 +405,37 @@ std::unique_ptr<Operator> cachedUpperBoundPlane(
 
 }  // namespace
 
+namespace {
+
+/// The nucleotide sequence a leaf names, or the database's default one; unknown names are the caller's mistake (400).
+const std::string& nucleotideSequenceOf(const Database& database, const std::optional<std::string>& requested) {
+   const std::string& name = requested.has_value() ? *requested : database.database_config.default_nucleotide_sequence;
+   CHECK_SILO_QUERY(database.nuc_sequences.count(name) != 0, "Database does not contain the nucleotide sequence with name: '" + name + "'")
+   return name;
+}
+
+/// "One of these symbols at the position": the Or of the per-symbol leaves, compiled without ambiguity.
+template <typename Leaf, typename Symbols>
+std::unique_ptr<Operator> anyOfSymbols(
+   const Database& database, const DatabasePartition& partition, const std::string& sequence_name, uint32_t position, const Symbols& symbols
+) {
+   ExpressionVector leaves;
+   for (const auto symbol : symbols) {
+      leaves.push_back(std::make_unique<Leaf>(sequence_name, position, symbol));
+   }
+   return Or(std::move(leaves)).compile(database, partition, Expression::NONE);
+}
+
+/// "Not the reference symbol", the upper bound of "has a mutation" (has_mutation.cpp:51-56, has_aa_mutation.cpp:40-45).
+template <typename Leaf, typename Symbol>
+std::unique_ptr<Operator> notTheReference(
+   const Database& database, const DatabasePartition& partition, const std::string& sequence_name, uint32_t position, Symbol reference
+) {
+   return Negation(std::make_unique<Leaf>(sequence_name, position, reference)).compile(database, partition, Expression::NONE);
+}
+
+}  // namespace
+
 // ---- NucleotideSymbolEquals (nucleotide_symbol_equals.cpp:94-189) -----------------------------------
 std::string NucleotideSymbolEquals::toString(const Database& /*database*/) const {
    const std::string prefix = nuc_sequence_name ? nuc_sequence_name.value() + ":" : "";
@@ -479,33 +446,23 @@ std::string NucleotideSymbolEquals::toString(const Database& /*database*/) const
 std::unique_ptr<Operator> NucleotideSymbolEquals::compile(
    const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
 ) const {
-   const std::string nuc_sequence_name_or_default = nuc_sequence_name.value_or(database.database_config.default_nucleotide_sequence);
+   const std::string& sequence_name = nucleotideSequenceOf(database, nuc_sequence_name);
+   const auto& store = database_partition.nuc_sequences.at(sequence_name);
+   const size_t genome_length = store.reference_sequence.size();
    CHECK_SILO_QUERY(
-      database.nuc_sequences.count(nuc_sequence_name_or_default) != 0,
-      "Database does not contain the nucleotide sequence with name: '" + nuc_sequence_name_or_default + "'"
+      position < genome_length,
+      "NucleotideEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" + std::to_string(genome_length) + "'"
    )
-   const auto& seq_store_partition = database_partition.nuc_sequences.at(nuc_sequence_name_or_default);
-   if (position >= seq_store_partition.reference_sequence.size()) {
-      throw QueryParseException(
-         "NucleotideEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" +
-         std::to_string(seq_store_partition.reference_sequence.size()) + "'"
-      );
+   const Nucleotide::Symbol wanted = value.has_value() ? *value : store.reference_sequence[position];  // "." asks for the reference symbol
+   if (mode != UPPER_BOUND) {
+      return symbolPlane<Nucleotide>(database, store, database_partition, position, wanted);
    }
-   const Nucleotide::Symbol nucleotide_symbol = value.value_or(seq_store_partition.reference_sequence.at(position));
-   if (mode == UPPER_BOUND) {
-      const auto expand = [&]() {  // nucleotide_symbol_equals.cpp:137-149: the symbol or any code that may stand for it
-         const auto& symbols_to_match = AMBIGUITY_NUC_SYMBOLS.at(static_cast<uint32_t>(nucleotide_symbol));
-         ExpressionVector symbol_filters;
-         for (const auto symbol : symbols_to_match) {
-            symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
-         }
-         return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
-      };
-      return cachedUpperBoundPlane(
-         database, database_partition, seq_store_partition.seqstore_id, position, static_cast<uint32_t>(nucleotide_symbol), expand
+   // the symbol or any ambiguity code that may stand for it (nucleotide_symbol_equals.cpp:137-149)
+   return cachedUpperBoundPlane(database, database_partition, store.seqstore_id, position, static_cast<uint32_t>(wanted), [&]() {
+      return anyOfSymbols<NucleotideSymbolEquals>(
+         database, database_partition, sequence_name, position, AMBIGUITY_NUC_SYMBOLS.at(static_cast<uint32_t>(wanted))
       );
-   }
-   return symbolPlane<Nucleotide>(database, seq_store_partition, database_partition, position, nucleotide_symbol);
+   });
 }
 
 // ---- AASymbolEquals (aa_symbol_equals.cpp:41-92; the ambiguity mode is ignored, :44) ----------------
@@ -517,18 +474,37 @@ std::string AASymbolEquals::toString(const Database& /*database*/) const {
 std::unique_ptr<Operator> AASymbolEquals::compile(
    const Database& database, const DatabasePartition& database_partition, AmbiguityMode /*mode*/
 ) const {
-   const auto& aa_store_partition = database_partition.aa_sequences.at(aa_sequence_name);  // out_of_range -> 500, as in the reference
-   if (position >= aa_store_partition.reference_sequence.size()) {
-      throw QueryParseException(
-         "AminoAcidEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" +
-         std::to_string(aa_store_partition.reference_sequence.size()) + "'"
-      );
-   }
-   const AminoAcid::Symbol aa_symbol = value.value_or(aa_store_partition.reference_sequence.at(position));
+   const auto& store = database_partition.aa_sequences.at(aa_sequence_name);  // unknown gene: std::out_of_range -> 500, as in the reference
+   const size_t gene_length = store.reference_sequence.size();
+   CHECK_SILO_QUERY(
+      position < gene_length,
+      "AminoAcidEquals position is out of bounds '" + std::to_string(position + 1) + "' > '" + std::to_string(gene_length) + "'"
+   )
    // The reference's rewrite for a deleted STOP symbol recurses forever; the dense
    // store simply returns the intended set.
-   return symbolPlane<AminoAcid>(database, aa_store_partition, database_partition, position, aa_symbol);
+   return symbolPlane<AminoAcid>(
+      database, store, database_partition, position, value.has_value() ? *value : store.reference_sequence[position]
+   );
 }
+
+// ---- SILO_COMPAT_REMOVE_QUIRK ------------------------------------------------------------------------
+// HasMutation / HasAAMutation list "every symbol but the reference (and the missing symbol)" and OR the listed symbols.
+// The reference takes a symbol off the list with std::remove WITHOUT the erase that has to follow it
+// (has_mutation.cpp:58-65, has_aa_mutation.cpp:48-52): the kept entries are shifted to the front, the list keeps its
+// length and its tail keeps what was there — so the last entry survives, duplicated or not.  Observable effect: where
+// the reference symbol is the LAST entry (T among A C G T; STOP among the amino-acid symbols) it stays in the list, and
+// HasNucleotideMutation at a reference-T position also matches the rows that carry T.  Parity is judged against the
+// reference as it is, so this is what the engine does by default; Database::compat_remove_quirk = false (compile-time
+// default SILO_COMPAT_REMOVE_QUIRK, run-time option "compat_remove_quirk") gives the list the code meant to build.
+namespace {
+template <typename Symbol>
+void dropSymbol(std::vector<Symbol>& symbols, Symbol unwanted, bool as_the_reference_does) {
+   const auto kept_end = std::remove(symbols.begin(), symbols.end(), unwanted);
+   if (!as_the_reference_does) {
+      symbols.erase(kept_end, symbols.end());
+   }
+}
+}  // namespace
 
 // ---- HasMutation (has_mutation.cpp:35-78) ----------------------------------------------------------
 std::string HasMutation::toString(const Database& /*database*/) const {
@@ -537,25 +513,14 @@ std::string HasMutation::toString(const Database& /*database*/) const {
 }
 
 std::unique_ptr<Operator> HasMutation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   const std::string nuc_sequence_name_or_default = nuc_sequence_name.value_or(database.database_config.default_nucleotide_sequence);
-   CHECK_SILO_QUERY(
-      database.nuc_sequences.count(nuc_sequence_name_or_default) != 0,
-      "Database does not contain the nucleotide sequence with name: '" + nuc_sequence_name_or_default + "'"
-   )
-   const Nucleotide::Symbol ref_symbol = database.nuc_sequences.at(nuc_sequence_name_or_default).reference_sequence.at(position);
+   const std::string& sequence_name = nucleotideSequenceOf(database, nuc_sequence_name);
+   const Nucleotide::Symbol reference = database.nuc_sequences.at(sequence_name).reference_sequence.at(position);  // position 0 wrapped: 500
    if (mode == UPPER_BOUND) {
-      auto expression = std::make_unique<Negation>(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, ref_symbol));
-      return expression->compile(database, database_partition, NONE);
+      return notTheReference<NucleotideSymbolEquals>(database, database_partition, sequence_name, position, reference);
    }
-   std::vector<Nucleotide::Symbol> symbols = {NS::A, NS::C, NS::G, NS::T};
-   // SILO_COMPAT_REMOVE_QUIRK: the reference calls std::remove without erase (has_mutation.cpp:58-65),
-   // so the list keeps four entries; at reference-T positions T itself stays in it.
-   (void)std::remove(symbols.begin(), symbols.end(), ref_symbol);
-   ExpressionVector symbol_filters;
-   for (const auto symbol : symbols) {
-      symbol_filters.push_back(std::make_unique<NucleotideSymbolEquals>(nuc_sequence_name_or_default, position, symbol));
-   }
-   return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+   std::vector<Nucleotide::Symbol> substitutions = {NS::A, NS::C, NS::G, NS::T};  // a gap is not a mutation here
+   dropSymbol(substitutions, reference, database.compat_remove_quirk);  // has_mutation.cpp:58-65
+   return anyOfSymbols<NucleotideSymbolEquals>(database, database_partition, sequence_name, position, substitutions);
 }
 
 // ---- HasAAMutation (has_aa_mutation.cpp:33-63) -----------------------------------------------------
@@ -564,20 +529,14 @@ std::string HasAAMutation::toString(const Database& /*database*/) const {
 }
 
 std::unique_ptr<Operator> HasAAMutation::compile(const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode) const {
-   const AminoAcid::Symbol ref_symbol = database.aa_sequences.at(aa_sequence_name).reference_sequence.at(position);
+   const AminoAcid::Symbol reference = database.aa_sequences.at(aa_sequence_name).reference_sequence.at(position);
    if (mode == UPPER_BOUND) {
-      auto expression = std::make_unique<Negation>(std::make_unique<AASymbolEquals>(aa_sequence_name, position, ref_symbol));
-      return expression->compile(database, database_partition, NONE);
+      return notTheReference<AASymbolEquals>(database, database_partition, aa_sequence_name, position, reference);
    }
-   std::vector<AminoAcid::Symbol> symbols(AminoAcid::SYMBOLS.begin(), AminoAcid::SYMBOLS.end());
-   // SILO_COMPAT_REMOVE_QUIRK: both removes are without erase (has_aa_mutation.cpp:48-52)
-   (void)std::remove(symbols.begin(), symbols.end(), AminoAcid::Symbol::X);
-   (void)std::remove(symbols.begin(), symbols.end(), ref_symbol);
-   ExpressionVector symbol_filters;
-   for (const auto symbol : symbols) {
-      symbol_filters.push_back(std::make_unique<AASymbolEquals>(aa_sequence_name, position, symbol));
-   }
-   return Or(std::move(symbol_filters)).compile(database, database_partition, NONE);
+   std::vector<AminoAcid::Symbol> substitutions(AminoAcid::SYMBOLS.begin(), AminoAcid::SYMBOLS.end());
+   dropSymbol(substitutions, AminoAcid::Symbol::X, database.compat_remove_quirk);  // has_aa_mutation.cpp:48-52
+   dropSymbol(substitutions, reference, database.compat_remove_quirk);
+   return anyOfSymbols<AASymbolEquals>(database, database_partition, aa_sequence_name, position, substitutions);
 }
 
 // ---- PangoLineageFilter (pango_lineage_filter.cpp:37-59) ---------------------------------------------

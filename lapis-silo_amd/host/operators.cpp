@@ -498,19 +498,6 @@ uint32_t BitmapSelection::lower(ProgramBuilder& builder) const {
 }
 
 // ---- Complement (complement.cpp) ----------------------------------------------------------------
-std::unique_ptr<Complement> Complement::fromDeMorgan(OperatorVector disjunction, RowSpace rows) {  // complement.cpp:22-40
-   OperatorVector non_negated_child_operators;
-   OperatorVector negated_child_operators;
-   for (auto& disjunction_child : disjunction) {
-      if (disjunction_child->type() == COMPLEMENT) {
-         negated_child_operators.emplace_back(disjunction_child->negate());
-      } else {
-         non_negated_child_operators.push_back(std::move(disjunction_child));
-      }
-   }
-   auto intersection = std::make_unique<Intersection>(std::move(negated_child_operators), std::move(non_negated_child_operators), rows);
-   return std::make_unique<Complement>(std::move(intersection), rows);
-}
 std::unique_ptr<Operator> Complement::copy() const {
    return std::make_unique<Complement>(child->copy(), rows);
 }

@@ -28,17 +28,24 @@ Query::Query(const std::string& query_string) {  // query.cpp:13-28
 
 namespace {
 
-class BlockTimer {  // include/silo/common/block_timer.h:5-23
-  public:
-   explicit BlockTimer(int64_t& output) : output(output), start(std::chrono::steady_clock::now()) {}
-   ~BlockTimer() {
-      output = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - start).count();
-   }
+/// Microseconds `work` takes, as the reference's BlockTimer reports them (block_timer.h:5-23, query_engine.cpp:63-65).
+template <typename Work>
+int64_t microsecondsOf(Work&& work) {
+   const auto begin = std::chrono::steady_clock::now();
+   work();
+   return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
+}
 
-  private:
-   int64_t& output;
-   std::chrono::steady_clock::time_point start;
-};
+/// Expression::compile + Operator::evaluate per partition (query_engine.cpp:40-49).  evaluate() is lazy here: the fused
+/// kernel is launched by the action, in the mode it needs (count only for Aggregated, bitset + count for Mutations).
+std::vector<OperatorResult> compileFilter(const Database& database, const filter_expressions::Expression& filter) {
+   std::vector<OperatorResult> per_partition;
+   per_partition.reserve(database.partitions.size());
+   for (const DatabasePartition& partition : database.partitions) {
+      per_partition.push_back(filter.compile(database, partition, filter_expressions::Expression::AmbiguityMode::NONE)->evaluate());
+   }
+   return per_partition;
+}
 
 }  // namespace
 
@@ -46,30 +53,14 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
    Trace::reset();
    const Query query(query_string);
    Trace::mark("parsed");
-
-   std::vector<OperatorResult> partition_filters(database.partitions.size());
-   int64_t filter_time = 0;
-   {
-      const BlockTimer timer(filter_time);
-      for (size_t partition_index = 0; partition_index != database.partitions.size(); partition_index++) {
-         std::unique_ptr<operators::Operator> part_filter = query.filter->compile(
-            database, database.partitions[partition_index], filter_expressions::Expression::AmbiguityMode::NONE
-         );
-         // evaluate() is lazy: the fused kernel is launched by the action, in the mode it needs
-         // (count only for Aggregated, bitset + count for Mutations).
-         partition_filters[partition_index] = part_filter->evaluate();
-      }
-   }
+   std::vector<OperatorResult> filters;
+   const int64_t filter_time = microsecondsOf([&] { filters = compileFilter(database, *query.filter); });
    Trace::mark("compiled");
-   QueryResult query_result;
-   int64_t action_time = 0;
-   {
-      const BlockTimer timer(action_time);
-      query_result = query.action->executeAndOrder(database, std::move(partition_filters));
-   }
+   QueryResult rows;
+   const int64_t action_time = microsecondsOf([&] { rows = query.action->executeAndOrder(database, std::move(filters)); });
    Trace::mark("action_done");
    Database::lastTimings() = {filter_time, action_time};
-   return query_result;
+   return rows;
 }
 
 std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries) const {
@@ -82,14 +73,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
       const actions::ScanBatcher::Checkpoint mark = batcher.checkpoint();
       try {
          parsed[i] = std::make_unique<Query>(queries[i]);
-         std::vector<OperatorResult> partition_filters(database.partitions.size());
-         for (size_t partition_index = 0; partition_index != database.partitions.size(); partition_index++) {
-            partition_filters[partition_index] =
-               parsed[i]
-                  ->filter->compile(database, database.partitions[partition_index], filter_expressions::Expression::AmbiguityMode::NONE)
-                  ->evaluate();
-         }
-         pending[i] = parsed[i]->action->begin(database, std::move(partition_filters));
+         pending[i] = parsed[i]->action->begin(database, compileFilter(database, *parsed[i]->filter));
       } catch (...) {
          batcher.rollback(mark);  // scans recorded by the failed query point into buffers that are gone
          outcomes[i].error = std::current_exception();

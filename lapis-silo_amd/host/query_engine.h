@@ -244,7 +244,6 @@ class BitmapSelection : public Operator {
 class Complement : public Operator {
   public:
    Complement(std::unique_ptr<Operator> child, RowSpace rows) : Operator(rows), child(std::move(child)) {}
-   static std::unique_ptr<Complement> fromDeMorgan(OperatorVector disjunction, RowSpace rows);
    Type type() const override { return COMPLEMENT; }
    std::string toString() const override { return "!" + child->toString(); }
    std::unique_ptr<Operator> copy() const override;
@@ -382,11 +381,6 @@ struct And : public Expression {
    explicit And(ExpressionVector&& children) : children(std::move(children)) {}
    SILO_DECLARE_EXPRESSION_METHODS
    ExpressionVector children;
-
-  private:
-   std::tuple<operators::OperatorVector, operators::OperatorVector, std::vector<operators::Predicate>> compileChildren(
-      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-   ) const;
 };
 struct Or : public Expression {
    explicit Or(ExpressionVector&& children) : children(std::move(children)) {}
@@ -415,14 +409,6 @@ struct NOf : public Expression {
    ExpressionVector children;
    int number_of_matchers;
    bool match_exactly;
-
-  private:
-   std::tuple<operators::OperatorVector, operators::OperatorVector, int> mapChildExpressions(
-      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-   ) const;
-   std::unique_ptr<operators::Operator> rewriteNonExact(
-      const Database& database, const DatabasePartition& database_partition, AmbiguityMode mode
-   ) const;
 };
 struct NucleotideSymbolEquals : public Expression {
    NucleotideSymbolEquals(std::optional<std::string> nuc_sequence_name, uint32_t position, std::optional<Nucleotide::Symbol> value)

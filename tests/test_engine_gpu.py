@@ -502,3 +502,33 @@ def test_column_unit_test_vectors(built):
             with _keyed_engine(vec["row_count"], []) as engine:
                 expression = {"type": "True"} if vec["operator"] == "Full" else {"type": "False"}
                 assert _selected_rows(engine, expression) == vec["expected"], vec["cite"]
+
+
+def test_compat_remove_quirk_is_a_named_switch(engines):
+    """SILO_COMPAT_REMOVE_QUIRK (SURVEY.md §8 a7): with std::remove and no erase (has_mutation.cpp:58-65) the reference keeps
+    T in the list at a reference-T position, so HasNucleotideMutation there also matches the rows that carry T.  Default
+    on = the reference's behaviour (the oracle restates it); switched off, exactly those rows drop out.  No reference
+    fixture pins the reference-T case (secondSequenceHasMutation.json sits on a reference-C position): oracle <-> device."""
+    engine, oracle_db = engines
+    genomes = json.load(open(dataset.GOLDEN + "/exampleDataset/reference_genomes.json"))
+    reference = next(g["sequence"] for g in genomes["nucleotideSequences"] if g["name"] == "main")
+    checked = 0
+    for position in (241, 3037, 23403, 28881, 210, 26767, 27638, 22917):
+        has_mutation = {"action": {"type": "Aggregated"}, "filterExpression": {"type": "HasNucleotideMutation", "position": position}}
+        carries = lambda symbol: engine.execute_query(  # noqa: E731
+            {"action": {"type": "Aggregated"}, "filterExpression": {"type": "NucleotideEquals", "position": position, "symbol": symbol}})[0]["count"]
+        with_quirk = engine.execute_query(has_mutation)
+        assert with_quirk == so.execute_query(oracle_db, has_mutation)
+        try:
+            engine.set_option("compat_remove_quirk", 0)
+            without_quirk = engine.execute_query(has_mutation)[0]["count"]
+        finally:
+            engine.set_option("compat_remove_quirk", 1)
+        others = sum(carries(s) for s in "ACGT" if s != reference[position - 1])
+        assert without_quirk == others
+        if reference[position - 1] == "T":
+            assert with_quirk[0]["count"] == others + carries("T")  # the reference symbol itself counts as a "mutation"
+            checked += 1
+        else:
+            assert with_quirk[0]["count"] == others
+    assert checked >= 2, "no reference-T position among the probed ones"
