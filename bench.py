@@ -597,7 +597,9 @@ def main():
             binding._check(lib.silo_gpu_stream_synchronize(None))
 
     t0 = time.time()
-    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank, use_dist)
+    # N = 1: ONE database with the nucleotide genome AND the 12 genes resident together (BASELINE.json configs[3] on one GPU);
+    # N > 1: the nucleotide genome, position-range sharded
+    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank, use_dist, with_genes=(world == 1 and not use_dist))
     log(f"[rank {rank}] store ready in {time.time() - t0:.1f}s: {args.sequences} sequences, positions {window}, "
         f"{engine.partition_store(0).device_bytes / 1e9:.1f} GB in HBM")
     query = make_query()
@@ -619,9 +621,10 @@ def main():
     # physical bytes: the plane rows, the filter and the escape keys this launch reads; algorithmic bytes: the layout-
     # independent figure of SURVEY.md §8(d) — 5 one-hot symbol columns per position plus the filter.
     scan_planes = int(lib.silo_gpu_store_scan_planes(store.handle, 0))
+    scan_rows = int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, n_local))  # plane rows of the adaptive layout, all positions
     scan_escapes = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
     alg_bytes = n_local * 5 * w8 + w8
-    physical_bytes = n_local * scan_planes * w8 + w8 + 8 * scan_escapes
+    physical_bytes = scan_rows * w8 + w8 + 8 * scan_escapes
     physical_gbps = physical_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM traffic per launch is a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     # the microarchitecture guide prescribes); counters cannot be read from inside this process, so the value is the one
@@ -632,7 +635,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
-            if name.startswith(f"k_scan_sliced<{scan_planes},") and entry.get("sequences") == args.sequences and entry.get("rows") == n_local * scan_planes:
+            if name.startswith(f"k_scan_sliced<{scan_planes},") and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
                 traffic = entry["hbm_bytes"]
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
     except (OSError, ValueError, KeyError):
@@ -680,8 +683,10 @@ def main():
             "algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "byte_reduction": alg_bytes / physical_bytes,
             "scan_planes_per_position": scan_planes,
+            "plane_rows": scan_rows,
             "escape_keys": scan_escapes,
-            "layout": ("2 code planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) + the other rows as escape keys"
+            "layout": ("adaptive code planes: 2 planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) with the other "
+                       "rows as escape keys; positions where that does not pay keep 3 identity planes"
                        if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes"),
         },
     }
@@ -695,7 +700,39 @@ def main():
             raise
         except Exception as error:  # the baseline is informational; a failure to build it must not hide the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
+    aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
+                           "filterExpression": json.loads(query)["filterExpression"]})
+    genes = load_reference_genomes(True)["genes"]
+    aa_positions = sum(len(g["sequence"]) for g in genes)
+
+    def aa_rows(engine):
+        """Plane rows the scan reads per gene (adaptive layout: 2, 3 or 5 per position)."""
+        handle = engine.partition_store(0).handle
+        return {g["name"]: int(lib.silo_gpu_store_scan_rows(handle, engine.seqstore_id(0, g["name"], True), 0, len(g["sequence"]))) for g in genes}
+
+    def aa_escapes(engine):
+        handle = engine.partition_store(0).handle
+        return sum(int(lib.silo_gpu_store_scan_escapes(handle, engine.seqstore_id(0, g["name"], True))) for g in genes)
+
     if rank == 0 and world == 1 and not use_dist and not args.no_also:
+        # BASELINE.json configs[3] on ONE GPU: the amino-acid leg on the SAME database (nucleotide genome + 12 genes resident)
+        elapsed_aa_full, rows_aa_full = run_steps(engine, aa_query, args.steps, args.warmup, sync)
+        rows_per_gene = aa_rows(engine)
+        aa_physical = sum(rows_per_gene.values()) * w8 + 12 * w8 + 8 * aa_escapes(engine)
+        result["also_amino_acid_full"] = {
+            "workload": f"AminoAcidMutations over all 12 genes (BASELINE.json configs[3], amino-acid leg) on the same {args.sequences}-sequence database, same filter",
+            "value": args.sequences * aa_positions / (elapsed_aa_full / args.steps),
+            "unit": "positions*sequences/s",
+            "ms_per_step": elapsed_aa_full / args.steps * 1e3,
+            "algorithmic_GBps_whole_query": aa_positions * 22 * w8 / (elapsed_aa_full / args.steps) / 1e9,
+            "plane_rows_per_gene": rows_per_gene,
+            "plane_rows_per_position": sum(rows_per_gene.values()) / aa_positions,
+            "escape_keys": aa_escapes(engine),
+            "physical_GBps_whole_query": aa_physical / (elapsed_aa_full / args.steps) / 1e9,
+            "mutation_rows": len(rows_aa_full),
+        }
+        result["config"]["database"] = (f"one database on one GPU: nucleotide genome ({scan_rows} plane rows) + 12 genes ({sum(rows_per_gene.values())} plane rows) "
+                                        f"+ the missing-symbol planes, {engine.partition_store(0).device_bytes / 1e9:.1f} GB of HBM")
         if not args.no_client_threads:
             result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
         result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)
@@ -705,33 +742,6 @@ def main():
     engine.close()
 
     if rank == 0 and world == 1 and not args.no_also and args.sequences != 1_000_000:
-        # amino-acid leg of BASELINE.json configs[3] at the full sequence count: all 12 genes (9 814 positions x 22 symbols);
-        # the nucleotide store is cut to a stub so that this engine is built after the first one has been released
-        aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
-                               "filterExpression": json.loads(query)["filterExpression"]})
-        aa_positions = sum(len(g["sequence"]) for g in load_reference_genomes(True)["genes"])
-
-        def aa_planes(engine):
-            """Plane rows per position the scan reads for every gene: 2 with a compact scan index (K1i), else 5."""
-            handle = engine.partition_store(0).handle
-            return {g["name"]: int(lib.silo_gpu_store_scan_planes(handle, engine.seqstore_id(0, g["name"], True))) for g in load_reference_genomes(True)["genes"]}
-
-        engine_aa = build_engine(args.sequences, 0, 1, None, local_rank, with_genes=True, nuc_positions=64)[0]
-        elapsed_aa_full, rows_aa_full = run_steps(engine_aa, aa_query, args.steps, args.warmup, sync)
-        w8_full = 8 * ((args.sequences + 63) // 64)
-        result["also_amino_acid_full"] = {
-            "workload": f"AminoAcidMutations over all 12 genes (BASELINE.json configs[3], amino-acid leg), {args.sequences} sequences, same filter",
-            "value": args.sequences * aa_positions / (elapsed_aa_full / args.steps),
-            "unit": "positions*sequences/s",
-            "ms_per_step": elapsed_aa_full / args.steps * 1e3,
-            "algorithmic_GBps_whole_query": aa_positions * 22 * w8_full / (elapsed_aa_full / args.steps) / 1e9,
-            "scan_planes_per_gene": aa_planes(engine_aa),
-            "physical_GBps_whole_query": sum(len(g["sequence"]) * aa_planes(engine_aa)[g["name"]] for g in load_reference_genomes(True)["genes"])
-                                         * w8_full / (elapsed_aa_full / args.steps) / 1e9,
-            "mutation_rows": len(rows_aa_full),
-        }
-        engine_aa.close()
-
         # BASELINE.json configs[1]: 1 M sequences, same query
         engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank, with_genes=True, with_metadata=True)  # no collective
         elapsed1, rows1 = run_steps(engine1, query, args.steps, args.warmup, sync)
@@ -744,8 +754,7 @@ def main():
             "unit": "positions*sequences/s",
             "ms_per_step": elapsed_aa / args.steps * 1e3,
             "algorithmic_GBps_whole_query": aa_bytes / (elapsed_aa / args.steps) / 1e9,
-            "physical_GBps_whole_query": sum(len(g["sequence"]) * aa_planes(engine1)[g["name"]] for g in load_reference_genomes(True)["genes"])
-                                         * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
+            "physical_GBps_whole_query": sum(aa_rows(engine1).values()) * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
             "mutation_rows": len(rows_aa),
         }
         kernel_ms1, _, _, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
@@ -756,7 +765,7 @@ def main():
             "value": 1_000_000 * positions / (elapsed1 / args.steps),
             "ms_per_step": elapsed1 / args.steps * 1e3,
             "kernel_ms": kernel_ms1,
-            "roofline_frac": (positions * int(lib.silo_gpu_store_scan_planes(engine1.partition_store(0).handle, 0)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_frac": (int(lib.silo_gpu_store_scan_rows(engine1.partition_store(0).handle, 0, 0, positions)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "algorithmic_GBps": alg1 / (kernel_ms1 * 1e-3) / 1e9,
             "mutation_rows": len(rows1),
         }

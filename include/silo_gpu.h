@@ -336,6 +336,14 @@ int silo_gpu_mutations_scan(
  * silo_gpu_store_scan_escapes: number of exception keys (0 without the index). */
 uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqstore_id);
 uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqstore_id);
+/* Plane rows (of Wp words each) the Mutations scan reads for positions [pos_begin, pos_end) of a sequence store: the
+ * physical bytes of a scan are this x 8 Wp, plus the filter and 8 bytes per escape key. */
+uint64_t silo_gpu_store_scan_rows(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t pos_begin, uint32_t pos_end);
+/* Finalizes ONE sequence store (silo_gpu_store_finalize does all that are left): its build-time planes are re-encoded into
+ * the adaptive code planes and released.  A loader that fills the stores of a partition one after the other calls this
+ * after each, so that their build-time planes are never resident together (10 M sequences: 112 GB for the nucleotide
+ * genome alone).  No sequences can be appended to a finalized store. */
+int silo_gpu_store_finalize_seqstore(silo_gpu_store* store, uint32_t seqstore_id);
 
 /* K1 over several position ranges at once — the 12 genes of an AminoAcidMutations query, the segments of a segmented
  * genome, the sequence stores of several batched queries: every filter is applied to every range;

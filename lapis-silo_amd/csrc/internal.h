@@ -9,6 +9,9 @@
 /// Records `message` as this thread's silo_gpu_last_error() and returns `code`.
 int silo_gpu_internal_fail(int code, const std::string& message);
 
+/// Sorts n 64-bit keys in device memory ascending, in place (silo_gpu_sort.hip); synchronises the null stream.
+int silo_gpu_internal_sort_keys(uint64_t* keys_dev, size_t n);
+
 #define SILO_HIP_TRY(expr)                                                                                  \
    do {                                                                                                     \
       hipError_t err_ = (expr);                                                                             \

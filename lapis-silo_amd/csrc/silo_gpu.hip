@@ -98,13 +98,28 @@ uint32_t missingSymbol(uint32_t alphabet) {
 // ------------------------------------------------------------------------------------------------
 enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
 
+// Layout of a position in the adaptive code planes (code_map[p][0]): the number of code planes, and whether the codes are
+// the identity (code = index of the valid mutation symbol + 1, no escapes: the position keeps its full planes).
+constexpr uint8_t LAYOUT_IDENTITY = 0x80;
+constexpr uint32_t CODE_MAP_STRIDE = 8;  // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
+
 struct SeqStoreDev {
-   // Bit-sliced scan planes [P][n_bits][Wp]: bit b of the CODE of every row's symbol at the position, where the code of
-   // the k-th valid mutation symbol is k + 1 and 0 stands for "none of them" (missing, ambiguity code, row padding).
-   // n_bits = 3 for the 5 nucleotide symbols, 5 for the 22 amino-acid symbols: the Mutations scan streams
-   // 3 (5) planes per position instead of 5 (22) one-hot planes.
+   // BUILD-TIME bit-sliced planes [P][n_bits][Wp]: bit b of the CODE of every row's symbol at the position, where the code
+   // of the k-th valid mutation symbol is k + 1 and 0 stands for "none of them" (missing, ambiguity code, row padding).
+   // n_bits = 3 for the 5 nucleotide symbols, 5 for the 22 amino-acid symbols.  append / generate write here;
+   // finalize re-encodes them into the adaptive planes below and frees them (scan == nullptr from then on) unless the
+   // store keeps them as they are (short rows, compact layouts switched off): then planes == scan.
    uint64_t* scan;
    uint64_t* extra;  // [n_extra][P][Wp]
+   // ADAPTIVE code planes, what every consumer reads after finalize.  Position p owns plane rows
+   // [row_of[p], row_of[p + 1]) of `planes`: B = 2 or 3 planes carrying the codes 1..2^B-1 of the position's most frequent
+   // valid symbols (code_map), every other valid symbol of a row listed in `escapes`; or the n_bits identity planes.
+   // While a store is being built row_of / code_map are null: position p then sits at row p * n_bits with identity codes.
+   const uint64_t* planes;
+   const uint32_t* row_of;         // [P + 1]
+   const uint8_t* code_map;        // [P][CODE_MAP_STRIDE]
+   const uint64_t* escapes;        // position << 37 | scan symbol index << 32 | sequence, ascending
+   const uint32_t* escape_first;   // [P + 1] first key of a position
    uint32_t positions;
    uint32_t n_symbols;  // alphabet size
    uint32_t n_scan;
@@ -116,8 +131,8 @@ struct SeqStoreDev {
    uint8_t index[SILO_GPU_MAX_SYMBOLS];
 };
 
-/// One-hot plane of a symbol that has one: the extra symbols.  Valid mutation symbols live in the bit-sliced scan planes
-/// (decodeScanWord / silo_gpu_store_sparse_plane materialise their one-hot plane on demand).
+/// One-hot plane of a symbol that has one: the extra symbols.  Valid mutation symbols live in the code planes
+/// (decodeCodeWord / silo_gpu_store_sparse_plane materialise their one-hot plane on demand).
 __host__ __device__ inline uint64_t* planePtr(const SeqStoreDev& s, uint32_t position, uint32_t symbol) {
    const uint8_t kind = s.kind[symbol];
    if (kind == PLANE_EXTRA) {
@@ -126,20 +141,48 @@ __host__ __device__ inline uint64_t* planePtr(const SeqStoreDev& s, uint32_t pos
    return nullptr;
 }
 
+/// The build-time planes of a position (append / generate / the re-encoding at finalize).
 __host__ __device__ inline const uint64_t* scanPlanes(const SeqStoreDev& s, uint32_t position) {
    return s.scan + static_cast<size_t>(position) * s.n_bits * s.row_words;
 }
 
-/// Word `word` of the one-hot plane of valid mutation symbol `symbol` at `position`, decoded from the bit planes.
-__device__ __forceinline__ uint64_t decodeScanWord(const SeqStoreDev& s, uint32_t position, uint32_t symbol, uint32_t word) {
-   const uint32_t code = static_cast<uint32_t>(s.index[symbol]) + 1u;
-   const uint64_t* base = scanPlanes(s, position) + word;
+/// Where a position sits in the adaptive planes and how its codes read.
+struct PositionLayout {
+   const uint64_t* rows;  // first plane row
+   uint32_t bits;         // code planes
+   bool identity;
+   const uint8_t* map;    // code -> scan symbol index (unused when identity)
+};
+__device__ __forceinline__ PositionLayout layoutOf(const SeqStoreDev& s, uint32_t position) {
+   if (s.code_map == nullptr) {
+      return {s.planes + static_cast<size_t>(position) * s.n_bits * s.row_words, s.n_bits, true, nullptr};
+   }
+   const uint8_t* map = s.code_map + static_cast<size_t>(position) * CODE_MAP_STRIDE;
+   return {s.planes + static_cast<size_t>(s.row_of[position]) * s.row_words, map[0] & 0x7Fu, (map[0] & LAYOUT_IDENTITY) != 0, map};
+}
+
+/// The code (0 = none) that stands for scan symbol index `scan_index` at a position, or 0xFFFFFFFF when the symbol has
+/// no code there (its rows are escape keys).
+__device__ __forceinline__ uint32_t codeOfSymbol(const PositionLayout& layout, uint32_t scan_index) {
+   if (layout.identity) {
+      return scan_index + 1u;
+   }
+   for (uint32_t code = 1; code < (1u << layout.bits); ++code) {
+      if (layout.map[code] == scan_index) {
+         return code;
+      }
+   }
+   return 0xFFFFFFFFu;
+}
+
+/// Word `word` of the rows whose code at the position is `code`, decoded from the position's planes.
+__device__ __forceinline__ uint64_t decodeCodeWord(const PositionLayout& layout, uint32_t row_words, uint32_t code, uint32_t word) {
    uint64_t match = ~0ull;
-   for (uint32_t bit = 0; bit < s.n_bits; ++bit) {
-      const uint64_t plane_word = base[static_cast<size_t>(bit) * s.row_words];
+   for (uint32_t bit = 0; bit < layout.bits; ++bit) {
+      const uint64_t plane_word = layout.rows[static_cast<size_t>(bit) * row_words + word];
       match &= ((code >> bit) & 1u) != 0 ? plane_word : ~plane_word;
    }
-   return match;  // padding bits have code 0, every valid symbol has a code >= 1
+   return match;  // padding bits have code 0, every coded symbol a code >= 1
 }
 
 struct SeqStoreHost {
@@ -157,14 +200,27 @@ struct SeqStoreHost {
    // cardinalities for a full filter (mutations.cpp:98-136); computed by one scan on first use
    uint32_t* d_totals = nullptr;
    bool totals_ready = false;
-   // K1i, the compact scan index: see buildCompactIndex
-   struct CompactIndex {
-      uint64_t* planes = nullptr;        // [positions][2][row_words]
-      uint8_t* code_map = nullptr;       // [positions][4]
-      uint64_t* escapes = nullptr;       // position << 37 | scan symbol index << 32 | sequence, grouped by (position, symbol)
-      std::vector<uint32_t> escape_first;  // [positions + 1], host copy of the prefix
-      bool ready = false;
-   } compact;
+   // The adaptive code planes of the finalized store (see SeqStoreDev and buildLayout).
+   struct Run {  // consecutive positions of one layout: a scan launch takes runs of ONE layout
+      uint32_t begin;
+      uint32_t end;
+      uint8_t bits;
+      bool identity;
+   };
+   struct Layout {
+      bool built = false;
+      uint64_t* planes = nullptr;       // owned; nullptr when the store keeps its build-time planes (dev.planes == dev.scan)
+      uint32_t* d_row_of = nullptr;
+      uint8_t* d_code_map = nullptr;
+      uint64_t* d_escapes = nullptr;
+      uint32_t* d_escape_first = nullptr;
+      std::vector<uint32_t> row_of;               // [P + 1]
+      std::vector<uint8_t> code_map;              // [P][CODE_MAP_STRIDE]
+      std::vector<uint32_t> escape_first;         // [P + 1]
+      std::vector<uint32_t> escape_first_symbol;  // [P * n_scan + 1]: first key of a (position, scan symbol)
+      std::vector<Run> runs;
+      uint64_t device_bytes = 0;
+   } layout;
 };
 
 }  // namespace
@@ -191,7 +247,7 @@ struct silo_gpu_store {
 
 namespace {
 
-int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore);  // K1i, defined next to the scan launchers
+int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore);  // the adaptive code planes, defined next to the scan launchers
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -272,8 +328,8 @@ struct ScanBatchArgs {
    uint32_t n_positions[SCAN_MAX_RANGES];
    uint32_t first_unit[SCAN_MAX_RANGES + 1];   // prefix sums of the blocks / waves per range
    uint32_t* counts[SCAN_MAX_RANGES][SILO_GPU_MAX_SCAN_BATCH];  // counts[range][filter], at the first position of the range
-   // compact scan index (K1i, BITS == 2): per position of the range 4 bytes, [c] = the scan symbol that code c stands for
-   // at this position (0xFF = none); out_symbols = symbols per position of the count tables (5 / 22)
+   // mapped layouts (2 or 3 code planes): per position of the range CODE_MAP_STRIDE bytes, [c] = the scan symbol that
+   // code c stands for at this position (0xFF = none); out_symbols = symbols per position of the count tables (5 / 22)
    const uint8_t* code_map[SCAN_MAX_RANGES];
    uint32_t out_symbols;
 };
@@ -292,7 +348,7 @@ constexpr int scanMinBlocks() {
    return Q == 1 ? (BITS * WPT <= 12 ? 4 : (BITS * WPT <= 18 ? 4 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2))) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
 }
 
-template <int BITS, int NSYM, int WPT, int Q>
+template <int BITS, int NSYM, int WPT, int Q, bool MAPPED>
 __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void k_scan_sliced(
    const ScanBatchArgs batch, uint32_t row_words, uint32_t positions_per_block, uint32_t n_tiles
 ) {
@@ -392,8 +448,8 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
                }
             }
             uint64_t high[BITS <= 3 ? 2 : 8];
+            static_assert(NSYM < (1 << BITS), "every counted code needs a bit pattern of its own, 0 is 'none'");
             if constexpr (BITS == 2) {
-               static_assert(NSYM == 3, "two code planes carry three codes");
                high[0] = ~0ull;  // the codes ARE the low pair
                high[1] = 0;
             } else if constexpr (BITS == 3) {
@@ -448,9 +504,11 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             total += s_partial[buffer][w][position][rest];
          }
          if (total != 0) {
-            if constexpr (BITS == 2) {  // compact index: code -> the symbol it stands for at this position
-               const uint32_t symbol = batch.code_map[range][static_cast<size_t>(batch_first_position + position) * 4 + 1 + rest % NSYM];
-               atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * batch.out_symbols + symbol], total);
+            if constexpr (MAPPED) {  // code -> the symbol it stands for at this position
+               const uint32_t symbol = batch.code_map[range][static_cast<size_t>(batch_first_position + position) * CODE_MAP_STRIDE + 1 + rest % NSYM];
+               if (symbol < batch.out_symbols) {  // an unused code (0xFF) has no rows: never taken, never out of bounds
+                  atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * batch.out_symbols + symbol], total);
+               }
             } else {
                atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * NSYM + rest % NSYM], total);
             }
@@ -582,8 +640,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
 
 // One WAVE per group of POSG consecutive positions (no LDS, no block-level reduction: a sparse filter may have fewer
 // non-zero words than a block has lanes); lanes stride over the words of the listed sectors, POSG * BITS gathers in flight each.
-template <int BITS, int NSYM, int POSG>
-__global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
+template <int BITS, int NSYM, int POSG, bool MAPPED>
+__global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_scan_gather(
    const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity, uint32_t row_words
 ) {
    const uint32_t q = blockIdx.y;
@@ -639,8 +697,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
          low[3] = bits[g][1] & bits[g][0] & filter_word;
          uint64_t high[BITS <= 3 ? 2 : 8];
          if constexpr (BITS == 2) {
-            static_assert(NSYM == 3, "two code planes carry three codes");
-            high[0] = ~0ull;  // compact scan index: the codes are the low pair
+            high[0] = ~0ull;  // the codes are the low pair
             high[1] = 0;
          } else if constexpr (BITS == 3) {
             high[0] = ~bits[g][2];
@@ -666,9 +723,11 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
       for (int symbol = 0; symbol < NSYM; ++symbol) {
          const uint32_t total = waveSumToLane63(acc[g][symbol]);
          if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
-            if constexpr (BITS == 2) {  // code -> the symbol it stands for at this position
-               const uint32_t mapped = batch.code_map[range][static_cast<size_t>(pos_begin + g) * 4 + 1 + symbol];
-               atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * batch.out_symbols + mapped], total);
+            if constexpr (MAPPED) {  // code -> the symbol it stands for at this position
+               const uint32_t mapped = batch.code_map[range][static_cast<size_t>(pos_begin + g) * CODE_MAP_STRIDE + 1 + symbol];
+               if (mapped < batch.out_symbols) {
+                  atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * batch.out_symbols + mapped], total);
+               }
             } else {
                atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * NSYM + symbol], total);
             }
@@ -678,51 +737,95 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? 5 : 4)) void k_scan_gather(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1i: the compact scan index.  At almost every position of real alignments three symbols cover all but a handful of
-// rows (the reference symbol, the gap or a lineage's substitution, one more), so finalize() derives a SECOND, smaller
-// representation for the scan alone: two code planes per position — code c in 1..3 = the c-th most frequent valid symbol
-// at that position (code_map), 0 = anything else — plus the few rows whose valid symbol is none of the three, as
-// explicit keys ("escapes", grouped by position).  The Mutations scan then streams 2 planes instead of 3 (nucleotides)
-// or 5 (amino acids) and adds the escapes with one small pass; every other consumer (filter leaves, FastaAligned, the
-// sparse-filter gather, the totals) keeps reading the full code planes, which also remain the fallback: the index is
-// only built when the escapes stay below 1/512 (nucleotides; 1/170 for amino acids) of the cells and the memory is there.
+// The adaptive code planes.  At almost every position of a real alignment three symbols cover all but a handful of rows
+// (the reference symbol, the gap or a lineage's substitution, one more), so a finalized store does not keep the
+// ceil(log2(|valid| + 1)) code planes of the build (3 nucleotide, 5 amino-acid) everywhere: finalize() picks, per
+// POSITION, the cheapest of
+//    2 planes: codes 1..3 = the three most frequent valid symbols of the position,
+//    3 planes: codes 1..7 = the seven most frequent (amino acids only: for nucleotides that is the full set),
+//    the full identity planes,
+// where the rows whose valid symbol got no code become explicit keys ("escapes": position << 37 | scan symbol << 32 |
+// sequence, sorted).  Cost model, in bytes the Mutations scan has to move: planes x row bytes + KEY_COST_BYTES per escape
+// (a key costs what ~40 plane bytes cost: 7.6 M keys in 46 us against 6.7 TB/s, profiles/r01_compact_index.md), the
+// 22-symbol decode of the full amino-acid planes weighted by what it costs in VALU time.  The build-time planes are
+// freed afterwards: at 10 M sequences the nucleotide store shrinks from 112 GB to 75 GB of code planes (+ 37 GB for the
+// missing-symbol plane) and every consumer — the scan, the sparse-filter gather, filter leaves, FastaAligned — reads the
+// adaptive planes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_choose_codes(
-   const uint32_t* __restrict__ totals, uint32_t n_scan, uint32_t positions, uint8_t* __restrict__ code_map, uint32_t* __restrict__ escape_count
+constexpr uint32_t KEY_COST_BYTES = 40;
+
+__global__ __launch_bounds__(256) void k_choose_layout(
+   const uint32_t* __restrict__ totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint32_t row_bytes, uint8_t* __restrict__ code_map,
+   uint32_t* __restrict__ escape_count
 ) {
    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= positions) {
       return;
    }
-   uint32_t best_count[3] = {0, 0, 0};
-   uint32_t best_symbol[3] = {0xFFu, 0xFFu, 0xFFu};
+   const uint32_t* count = totals + static_cast<size_t>(p) * n_scan;
+   // the seven most frequent valid symbols, most frequent first; ties keep the lower symbol index in front
+   uint32_t best_symbol[7];
+   uint64_t best_sum[8];  // best_sum[k] = rows carried by the k most frequent
+   uint32_t taken = 0;    // bit s: symbol s is among the chosen
+   uint64_t total = 0;
    for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-      const uint32_t count = totals[static_cast<size_t>(p) * n_scan + symbol];
-      if (count > best_count[0]) {  // strictly greater: ties keep the lower symbol index in front
-         best_count[2] = best_count[1], best_symbol[2] = best_symbol[1];
-         best_count[1] = best_count[0], best_symbol[1] = best_symbol[0];
-         best_count[0] = count, best_symbol[0] = symbol;
-      } else if (count > best_count[1]) {
-         best_count[2] = best_count[1], best_symbol[2] = best_symbol[1];
-         best_count[1] = count, best_symbol[1] = symbol;
-      } else if (count > best_count[2]) {
-         best_count[2] = count, best_symbol[2] = symbol;
+      total += count[symbol];
+   }
+   best_sum[0] = 0;
+   for (int k = 0; k < 7; ++k) {
+      uint32_t pick = 0xFFu;
+      uint32_t pick_count = 0;
+      for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+         if (((taken >> symbol) & 1u) == 0 && count[symbol] > pick_count) {
+            pick = symbol;
+            pick_count = count[symbol];
+         }
+      }
+      best_symbol[k] = pick;
+      best_sum[k + 1] = best_sum[k] + pick_count;
+      if (pick != 0xFFu) {
+         taken |= 1u << pick;
       }
    }
-   code_map[static_cast<size_t>(p) * 4 + 0] = 0xFFu;
-   for (int c = 0; c < 3; ++c) {
-      code_map[static_cast<size_t>(p) * 4 + 1 + c] = static_cast<uint8_t>(best_symbol[c]);
+   const uint64_t escapes2 = total - best_sum[3];
+   const uint64_t escapes3 = total - best_sum[7];
+   const uint64_t cost2 = 2ull * row_bytes + KEY_COST_BYTES * escapes2;
+   const uint64_t cost3 = 3ull * row_bytes + KEY_COST_BYTES * escapes3;
+   // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped
+   // layouts (profiles/README.md): weigh its bytes accordingly
+   const uint64_t cost_full = n_bits > 3 ? static_cast<uint64_t>(n_bits) * row_bytes * 115 / 100 : static_cast<uint64_t>(n_bits) * row_bytes;
+   uint32_t coded = 0;  // number of symbols that get a code; 0 = identity
+   uint32_t bits = n_bits;
+   if (cost2 <= cost_full && (n_bits <= 3 || cost2 <= cost3)) {
+      coded = 3;
+      bits = 2;
+   } else if (n_bits > 3 && cost3 < cost_full) {
+      coded = 7;
+      bits = 3;
+   }
+   uint8_t* map = code_map + static_cast<size_t>(p) * CODE_MAP_STRIDE;
+   map[0] = static_cast<uint8_t>(coded == 0 ? (bits | LAYOUT_IDENTITY) : bits);
+   for (uint32_t code = 1; code < CODE_MAP_STRIDE; ++code) {
+      map[code] = coded == 0 ? static_cast<uint8_t>(code - 1 < n_scan && code < (1u << n_bits) ? code - 1 : 0xFFu)
+                             : static_cast<uint8_t>(code <= coded ? best_symbol[code - 1] : 0xFFu);
    }
    // rows that become escape keys, per (position, symbol): exactly the totals of the symbols that got no code
+   uint32_t coded_mask = 0;
+   for (uint32_t k = 0; k < coded; ++k) {
+      if (best_symbol[k] != 0xFFu) {
+         coded_mask |= 1u << best_symbol[k];
+      }
+   }
    for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-      const bool coded = symbol == best_symbol[0] || symbol == best_symbol[1] || symbol == best_symbol[2];
-      escape_count[static_cast<size_t>(p) * n_scan + symbol] = coded ? 0u : totals[static_cast<size_t>(p) * n_scan + symbol];
+      escape_count[static_cast<size_t>(p) * n_scan + symbol] = coded == 0 || ((coded_mask >> symbol) & 1u) != 0 ? 0u : count[symbol];
    }
 }
 
+/// Re-encodes the build-time planes of every position into its adaptive layout; rows without a code go, with an atomic
+/// cursor per (position, symbol), into that counter's exactly sized slice of the key list (sorted afterwards).
 template <int BITS>
-__global__ __launch_bounds__(256) void k_encode_compact(
-   const uint64_t* __restrict__ scan, uint32_t row_words, uint32_t n_scan, const uint8_t* __restrict__ code_map,
+__global__ __launch_bounds__(256) void k_encode_adaptive(
+   const uint64_t* __restrict__ scan, uint32_t row_words, uint32_t n_scan, const uint8_t* __restrict__ code_map, const uint32_t* __restrict__ row_of,
    const uint32_t* __restrict__ escape_first, uint32_t* __restrict__ escape_cursor, uint64_t* __restrict__ planes, uint64_t* __restrict__ escapes
 ) {
    const uint32_t p = blockIdx.y;
@@ -737,33 +840,52 @@ __global__ __launch_bounds__(256) void k_encode_compact(
       bits[bit] = scan[(static_cast<size_t>(p) * BITS + bit) * row_words + w];
       valid |= bits[bit];
    }
-   uint64_t match[3];
-#pragma unroll
-   for (int c = 0; c < 3; ++c) {
-      const uint32_t symbol = code_map[static_cast<size_t>(p) * 4 + 1 + c];
-      const uint32_t code = symbol + 1u;
-      uint64_t m = symbol == 0xFFu ? 0 : ~0ull;
+   const uint8_t* map = code_map + static_cast<size_t>(p) * CODE_MAP_STRIDE;
+   uint64_t* out = planes + static_cast<size_t>(row_of[p]) * row_words + w;
+   if ((map[0] & LAYOUT_IDENTITY) != 0) {
 #pragma unroll
       for (int bit = 0; bit < BITS; ++bit) {
-         m &= ((code >> bit) & 1u) != 0 ? bits[bit] : ~bits[bit];
+         out[static_cast<size_t>(bit) * row_words] = bits[bit];
       }
-      match[c] = m;
+      return;
    }
-   planes[(static_cast<size_t>(p) * 2 + 0) * row_words + w] = match[0] | match[2];  // codes 1 (01) and 3 (11)
-   planes[(static_cast<size_t>(p) * 2 + 1) * row_words + w] = match[1] | match[2];  // codes 2 (10) and 3 (11)
-   uint64_t escaped = valid & ~(match[0] | match[1] | match[2]);
+   const uint32_t out_bits = map[0] & 0x7Fu;  // 2 or 3
+   uint64_t out_plane[3] = {0, 0, 0};
+   uint64_t coded = 0;
+   for (uint32_t code = 1; code < (1u << out_bits); ++code) {
+      const uint32_t symbol = map[code];
+      if (symbol == 0xFFu) {
+         continue;
+      }
+      const uint32_t full_code = symbol + 1u;
+      uint64_t match = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < BITS; ++bit) {
+         match &= ((full_code >> bit) & 1u) != 0 ? bits[bit] : ~bits[bit];
+      }
+      coded |= match;
+#pragma unroll
+      for (uint32_t bit = 0; bit < 3; ++bit) {
+         if (((code >> bit) & 1u) != 0) {
+            out_plane[bit] |= match;
+         }
+      }
+   }
+   for (uint32_t bit = 0; bit < out_bits; ++bit) {
+      out[static_cast<size_t>(bit) * row_words] = out_plane[bit];
+   }
+   uint64_t escaped = valid & ~coded;
    while (escaped != 0) {
       const uint32_t row_bit = static_cast<uint32_t>(__builtin_ctzll(escaped));
       escaped &= escaped - 1;
-      uint32_t code = 0;
+      uint32_t full_code = 0;
 #pragma unroll
       for (int bit = 0; bit < BITS; ++bit) {
-         code |= static_cast<uint32_t>((bits[bit] >> row_bit) & 1ull) << bit;
+         full_code |= static_cast<uint32_t>((bits[bit] >> row_bit) & 1ull) << bit;
       }
-      // the keys of one (position, symbol) sit together: k_scan_escapes then needs one atomic per wave and counter
-      const size_t counter = static_cast<size_t>(p) * n_scan + (code - 1u);
+      const size_t counter = static_cast<size_t>(p) * n_scan + (full_code - 1u);
       const uint32_t slot = escape_first[counter] + atomicAdd(escape_cursor + counter, 1u);
-      escapes[slot] = (static_cast<uint64_t>(p) << 37) | (static_cast<uint64_t>(code - 1u) << 32) | (static_cast<uint64_t>(w) * 64u + row_bit);
+      escapes[slot] = (static_cast<uint64_t>(p) << 37) | (static_cast<uint64_t>(full_code - 1u) << 32) | (static_cast<uint64_t>(w) * 64u + row_bit);
    }
 }
 
@@ -1297,13 +1419,16 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
    const uint32_t word = sequence >> 6;
    const uint32_t bit = sequence & 63u;
    uint32_t found = 0xFFu;
-   uint32_t code = 0;  // the row's code in the bit-sliced scan planes: valid mutation symbol index + 1, or 0
-   for (uint32_t plane_bit = 0; plane_bit < store.n_bits; ++plane_bit) {
-      code |= static_cast<uint32_t>((scanPlanes(store, position)[static_cast<size_t>(plane_bit) * store.row_words + word] >> bit) & 1u) << plane_bit;
+   // the row's code in the position's planes, and the valid mutation symbol that code stands for there (0 = none coded)
+   const PositionLayout layout = layoutOf(store, position);
+   uint32_t code = 0;
+   for (uint32_t plane_bit = 0; plane_bit < layout.bits; ++plane_bit) {
+      code |= static_cast<uint32_t>((layout.rows[static_cast<size_t>(plane_bit) * store.row_words + word] >> bit) & 1u) << plane_bit;
    }
+   const uint32_t coded_index = code == 0 ? 0xFFu : (layout.identity ? code - 1u : layout.map[code]);
    for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
       if (store.kind[symbol] == PLANE_SCAN) {
-         if (code != 0 && store.index[symbol] + 1u == code) {
+         if (store.index[symbol] == coded_index) {
             found = symbol;
          }
          continue;
@@ -1313,22 +1438,32 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
          found = symbol;
       }
    }
+   const auto listed = [&](const uint64_t* keys, uint32_t lo, uint32_t hi, uint64_t key) {  // binary search in keys[lo, hi)
+      const uint32_t end = hi;
+      while (lo < hi) {
+         const uint32_t mid = lo + (hi - lo) / 2;
+         if (keys[mid] < key) {
+            lo = mid + 1;
+         } else {
+            hi = mid;
+         }
+      }
+      return lo < end && keys[lo] == key;
+   };
+   if (found == 0xFFu && store.escapes != nullptr) {  // a valid symbol that has no code at this position: an escape key
+      const uint32_t first = store.escape_first[position];
+      const uint32_t last = store.escape_first[position + 1];
+      for (uint32_t symbol = 0; symbol < store.n_symbols && found == 0xFFu && first < last; ++symbol) {
+         if (store.kind[symbol] == PLANE_SCAN &&
+             listed(store.escapes, first, last, (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(store.index[symbol]) << 32) | sequence)) {
+            found = symbol;
+         }
+      }
+   }
    if (found == 0xFFu) {
       for (uint32_t symbol = 0; symbol < store.n_symbols && found == 0xFFu; ++symbol) {
-         if (store.kind[symbol] != PLANE_SPARSE) {
-            continue;
-         }
-         const uint64_t key = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32) | sequence;
-         uint32_t lo = 0, hi = n_sparse;
-         while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if (sparse_keys[mid] < key) {
-               lo = mid + 1;
-            } else {
-               hi = mid;
-            }
-         }
-         if (lo < n_sparse && sparse_keys[lo] == key) {
+         if (store.kind[symbol] == PLANE_SPARSE &&
+             listed(sparse_keys, 0, n_sparse, (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(symbol) << 32) | sequence)) {
             found = symbol;
          }
       }
@@ -1336,11 +1471,14 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
    out[static_cast<size_t>(blockIdx.y) * store.positions + position] = found == 0xFFu ? '?' : symbol_chars[found];
 }
 
-// One-hot plane of a valid mutation symbol out of the bit-sliced scan planes (n_bits reads per word).
+// One-hot plane of a valid mutation symbol out of the position's code planes (2, 3 or n_bits reads per word); a symbol
+// that has no code at the position yields zeros (its rows are escape keys: the caller scatters them on top).
 __global__ __launch_bounds__(256) void k_decode_plane(const SeqStoreDev store, uint32_t position, uint32_t symbol, uint64_t* __restrict__ out) {
    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
    if (word < store.row_words) {
-      out[word] = decodeScanWord(store, position, symbol, word);
+      const PositionLayout layout = layoutOf(store, position);
+      const uint32_t code = codeOfSymbol(layout, store.index[symbol]);
+      out[word] = code == 0xFFFFFFFFu ? 0ull : decodeCodeWord(layout, store.row_words, code, word);
    }
 }
 
@@ -1388,6 +1526,32 @@ int growSparse(SeqStoreHost& seqstore, uint32_t needed) {
    }
    seqstore.d_sparse = bigger;
    seqstore.sparse_capacity = capacity;
+   return SILO_GPU_OK;
+}
+
+/// The build-time planes of a sequence store, allocated (zeroed) when its first sequences arrive.
+int ensureBuildPlanes(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   if (seqstore.layout.built) {
+      return fail(
+         SILO_GPU_ERR_INVALID_ARGUMENT, "the sequence store is finalized: its build-time planes were re-encoded and released, no sequences can be added"
+      );
+   }
+   SeqStoreDev& dev = seqstore.dev;
+   if (dev.scan != nullptr || dev.extra != nullptr) {
+      return SILO_GPU_OK;
+   }
+   const size_t scan_bytes = static_cast<size_t>(dev.positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
+   const size_t extra_bytes = static_cast<size_t>(dev.positions) * dev.n_extra * dev.row_words * sizeof(uint64_t);
+   if (scan_bytes > 0) {
+      HIP_TRY(hipMalloc(&dev.scan, scan_bytes));
+      HIP_TRY(hipMemset(dev.scan, 0, scan_bytes));
+   }
+   if (extra_bytes > 0) {
+      HIP_TRY(hipMalloc(&dev.extra, extra_bytes));
+      HIP_TRY(hipMemset(dev.extra, 0, extra_bytes));
+   }
+   dev.planes = dev.scan;
+   store->device_bytes += scan_bytes + extra_bytes;
    return SILO_GPU_OK;
 }
 
@@ -1486,21 +1650,9 @@ int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out)
          dev.kind[in.extra_symbols[s]] = PLANE_EXTRA;
          dev.index[in.extra_symbols[s]] = static_cast<uint8_t>(s);
       }
-      const size_t scan_bytes = static_cast<size_t>(in.positions) * dev.n_bits * row_words * sizeof(uint64_t);
-      const size_t extra_bytes = static_cast<size_t>(in.positions) * dev.n_extra * row_words * sizeof(uint64_t);
+      // the planes are allocated when the first sequences arrive (ensureBuildPlanes) and re-encoded at finalize: stores
+      // that are filled and finalized one after the other never hold their build-time planes at the same time
       hipError_t err = hipSuccess;
-      if (scan_bytes > 0) {
-         err = hipMalloc(&dev.scan, scan_bytes);
-         if (err == hipSuccess) {
-            err = hipMemset(dev.scan, 0, scan_bytes);
-         }
-      }
-      if (err == hipSuccess && extra_bytes > 0) {
-         err = hipMalloc(&dev.extra, extra_bytes);
-         if (err == hipSuccess) {
-            err = hipMemset(dev.extra, 0, extra_bytes);
-         }
-      }
       if (err == hipSuccess) {
          err = hipMalloc(&seqstore.d_reference, in.positions);
       }
@@ -1519,7 +1671,6 @@ int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out)
             std::string("allocating planes: ") + hipGetErrorString(err)
          ));
       }
-      store->device_bytes += scan_bytes + extra_bytes;
    }
    hipError_t err = hipMalloc(&store->d_ones, static_cast<size_t>(row_words) * sizeof(uint64_t));
    if (err == hipSuccess) {
@@ -1552,9 +1703,11 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_sparse);
       (void)hipFree(seqstore.d_sparse_count);
       (void)hipFree(seqstore.d_totals);
-      (void)hipFree(seqstore.compact.planes);
-      (void)hipFree(seqstore.compact.code_map);
-      (void)hipFree(seqstore.compact.escapes);
+      (void)hipFree(seqstore.layout.planes);
+      (void)hipFree(seqstore.layout.d_row_of);
+      (void)hipFree(seqstore.layout.d_code_map);
+      (void)hipFree(seqstore.layout.d_escapes);
+      (void)hipFree(seqstore.layout.d_escape_first);
    }
    (void)hipFree(store->d_ones);
    (void)hipFree(store->d_lineage);
@@ -1594,9 +1747,11 @@ int silo_gpu_store_append_sequences(
    std::lock_guard<std::mutex> lock(store->mutex);
    HIP_TRY(hipSetDevice(store->device));
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {
+      return rc;
+   }
    seqstore.finalized = false;
    seqstore.totals_ready = false;
-   seqstore.compact.ready = false;
    const uint32_t positions = seqstore.dev.positions;
    const uint32_t pitch = positions;  // rows stay contiguous: ONE host-to-device copy per batch
 
@@ -1693,9 +1848,11 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    std::lock_guard<std::mutex> lock(store->mutex);
    HIP_TRY(hipSetDevice(store->device));
    SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {
+      return rc;
+   }
    seqstore.finalized = false;
    seqstore.totals_ready = false;
-   seqstore.compact.ready = false;
    const uint32_t n = store->sequence_count;
    const uint32_t positions = seqstore.dev.positions;
 
@@ -1814,6 +1971,33 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    return SILO_GPU_OK;
 }
 
+namespace {
+/// Sorts the sparse keys of one sequence store and re-encodes its build-time planes into the adaptive code planes.
+int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   if (seqstore.layout.built) {
+      return SILO_GPU_OK;
+   }
+   if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {  // a store that never received a sequence: all-zero planes
+      return rc;
+   }
+   uint32_t count = 0;
+   HIP_TRY(hipMemcpy(&count, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+   count = std::min(count, seqstore.sparse_capacity);
+   seqstore.sparse_sorted.resize(count);
+   if (count > 0) {
+      HIP_TRY(hipMemcpy(seqstore.sparse_sorted.data(), seqstore.d_sparse, static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      std::sort(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end());
+      // a replayed batch may have appended duplicates
+      seqstore.sparse_sorted.erase(std::unique(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end()), seqstore.sparse_sorted.end());
+      count = static_cast<uint32_t>(seqstore.sparse_sorted.size());
+      HIP_TRY(hipMemcpy(seqstore.d_sparse, seqstore.sparse_sorted.data(), static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
+   }
+   seqstore.finalized = true;
+   return buildLayout(store, seqstore);
+}
+}  // namespace
+
 int silo_gpu_store_finalize(silo_gpu_store* store) {
    if (store == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_finalize: null store");
@@ -1821,28 +2005,20 @@ int silo_gpu_store_finalize(silo_gpu_store* store) {
    std::lock_guard<std::mutex> lock(store->mutex);
    HIP_TRY(hipSetDevice(store->device));
    for (SeqStoreHost& seqstore : store->seqstores) {
-      uint32_t count = 0;
-      HIP_TRY(hipMemcpy(&count, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
-      count = std::min(count, seqstore.sparse_capacity);
-      seqstore.sparse_sorted.resize(count);
-      if (count > 0) {
-         HIP_TRY(hipMemcpy(seqstore.sparse_sorted.data(), seqstore.d_sparse, static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-         std::sort(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end());
-         // a replayed batch may have appended duplicates
-         seqstore.sparse_sorted.erase(
-            std::unique(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end()), seqstore.sparse_sorted.end()
-         );
-         count = static_cast<uint32_t>(seqstore.sparse_sorted.size());
-         HIP_TRY(hipMemcpy(seqstore.d_sparse, seqstore.sparse_sorted.data(), static_cast<size_t>(count) * sizeof(uint64_t), hipMemcpyHostToDevice));
-         HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
-      }
-      seqstore.finalized = true;
-      const int rc = buildCompactIndex(store, seqstore);
-      if (rc != SILO_GPU_OK) {
+      if (const int rc = finalizeSeqStore(store, seqstore); rc != SILO_GPU_OK) {
          return rc;
       }
    }
    return SILO_GPU_OK;
+}
+
+int silo_gpu_store_finalize_seqstore(silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size()) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_finalize_seqstore: bad arguments");
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   HIP_TRY(hipSetDevice(store->device));
+   return finalizeSeqStore(store, store->seqstores[seqstore_id]);
 }
 
 int silo_gpu_malloc(size_t bytes, void** out_dev) {
@@ -1863,29 +2039,75 @@ namespace {
 
 /// A position range of one sequence store with the count tables of every filter of the launch.
 struct ScanRange {
-   const SeqStoreDev* dev;
+   const SeqStoreHost* seqstore;
    uint32_t pos_begin;
    uint32_t pos_end;
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];
-   const SeqStoreHost::CompactIndex* compact;  // the compact scan index of the store (K1i), or nullptr
 };
 
-/// Launches k_scan_sliced for the `q_count` filters and the ranges already entered in `batch` (planes, n_positions, counts).
-template <int BITS, int NSYM>
+/// The part of a range that lies in ONE run of its store's layout: what a launch takes.
+struct ScanPiece {
+   const uint64_t* planes;    // first plane row of the piece
+   const uint8_t* code_map;   // of the piece's first position (mapped layouts), else nullptr
+   uint32_t n_positions;
+   uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];  // tables at the piece's first position
+};
+
+/// The four plane layouts the scan kernels are instantiated for.
+enum ScanLayout { SCAN_2_PLANES = 0, SCAN_3_PLANES_MAPPED, SCAN_FULL_NUCLEOTIDE, SCAN_FULL_AMINO_ACID, N_SCAN_LAYOUTS };
+
+ScanLayout layoutOfRun(const SeqStoreDev& dev, uint32_t bits, bool identity) {
+   if (!identity) {
+      return bits == 2 ? SCAN_2_PLANES : SCAN_3_PLANES_MAPPED;
+   }
+   return dev.n_bits == 3 ? SCAN_FULL_NUCLEOTIDE : SCAN_FULL_AMINO_ACID;
+}
+
+/// Cuts the ranges along the runs of their stores; pieces[layout] collects what one kind of launch takes.
+void cutIntoPieces(const std::vector<ScanRange>& ranges, uint32_t q_count, std::vector<ScanPiece> (&pieces)[N_SCAN_LAYOUTS]) {
+   for (const ScanRange& range : ranges) {
+      const SeqStoreHost& seqstore = *range.seqstore;
+      const SeqStoreDev& dev = seqstore.dev;
+      const auto add = [&](uint32_t begin, uint32_t end, uint32_t bits, bool identity) {
+         begin = std::max(begin, range.pos_begin);
+         end = std::min(end, range.pos_end);
+         if (begin >= end) {
+            return;
+         }
+         ScanPiece piece{};
+         const bool encoded = seqstore.layout.built && seqstore.layout.d_row_of != nullptr;
+         const size_t first_row = encoded ? seqstore.layout.row_of[begin] : static_cast<size_t>(begin) * dev.n_bits;
+         piece.planes = dev.planes + first_row * dev.row_words;
+         piece.code_map = identity ? nullptr : seqstore.layout.d_code_map + static_cast<size_t>(begin) * CODE_MAP_STRIDE;
+         piece.n_positions = end - begin;
+         for (uint32_t q = 0; q < q_count; ++q) {
+            piece.counts[q] = range.counts[q] + static_cast<size_t>(begin - range.pos_begin) * dev.n_scan;
+         }
+         pieces[layoutOfRun(dev, bits, identity)].push_back(piece);
+      };
+      if (seqstore.layout.runs.empty()) {  // still the build-time planes (the totals scan inside finalize)
+         add(0, dev.positions, dev.n_bits, true);
+      }
+      for (const SeqStoreHost::Run& run : seqstore.layout.runs) {
+         add(run.begin, run.end, run.bits, run.identity);
+      }
+   }
+}
+
+/// Launches k_scan_sliced for the `q_count` filters and the pieces already entered in `batch` (planes, n_positions, counts).
+template <int BITS, int NSYM, bool MAPPED>
 int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
-   // words per thread: 8 for one nucleotide filter (3 planes x 4 chunks per position and buffer), 4 otherwise (amino
-   // acids: 5 planes; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
+   // words per thread: 8 for one filter over a layout of at most 5 counted symbols (2 or 3 planes x 4 chunks per position and
+   // buffer), 4 otherwise (7 or 22 symbols; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
    const int variant = g_tune_scan_variant.load();
-   bool wide = BITS <= 3 && q_count == 1 && row_words >= SCAN_THREADS * 8;
+   constexpr bool CAN_BE_WIDE = BITS <= 3 && NSYM <= 5;
+   bool wide = CAN_BE_WIDE && q_count == 1 && row_words >= SCAN_THREADS * 8;
    if (variant == 10) {
       wide = false;
-   } else if (variant == 12 && BITS <= 3 && q_count == 1) {
+   } else if (variant == 12 && CAN_BE_WIDE && q_count == 1) {
       wide = true;
    }
-   const bool medium = variant == 14 && BITS <= 3 && q_count == 1;  // experiment: 6 words per thread
-   const bool narrow = variant == 16 && BITS == 5 && q_count == 1;  // experiment: 2 words per thread (amino acids, more waves per SIMD)
-   const int extra_wide = BITS == 2 && q_count == 1 && variant == 18 ? 12 : 0;  // experiment: 12 words per thread
-   const uint32_t tile_words = SCAN_THREADS * (extra_wide != 0 ? extra_wide : (narrow ? 2 : (medium ? 6 : (wide ? 8 : 4))));
+   const uint32_t tile_words = SCAN_THREADS * (wide ? 8 : 4);
    int positions_per_block = g_tune_rows_per_block.load();
    const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
    uint64_t total_positions = 0;
@@ -1893,8 +2115,8 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
       total_positions += batch.n_positions[r];
    }
    if (positions_per_block <= 0) {
-      // nucleotides: 128 positions (384 plane rows) per block while that still leaves >= 4096 blocks, else 64; amino
-      // acids 12 (60 plane rows) — profiles/r01_scan_variants.md
+      // 2 or 3 planes per position: 128 positions per block while that still leaves >= 4096 blocks, else 64; the 5 identity
+      // planes of amino acids: 12 (60 plane rows) — profiles/r01_scan_variants.md
       positions_per_block = BITS <= 3 ? (static_cast<uint64_t>(n_tiles) * ((total_positions + 127) / 128) >= 4096 ? 128 : 64) : 12;
    }
    positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
@@ -1904,21 +2126,9 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    }
    const dim3 grid(batch.first_unit[batch.n_ranges]);
 #define SILO_LAUNCH_SLICED(WPT, Q) \
-   k_scan_sliced<BITS, NSYM, WPT, Q><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
-   if (extra_wide != 0) {
-      if constexpr (BITS == 2) {
-         SILO_LAUNCH_SLICED(12, 1);
-      }
-   } else if (narrow) {
-      if constexpr (BITS == 5) {
-         SILO_LAUNCH_SLICED(2, 1);
-      }
-   } else if (medium) {
-      if constexpr (BITS <= 3) {
-         SILO_LAUNCH_SLICED(6, 1);
-      }
-   } else if (wide) {
-      if constexpr (BITS <= 3) {
+   k_scan_sliced<BITS, NSYM, WPT, Q, MAPPED><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
+   if (wide) {
+      if constexpr (CAN_BE_WIDE) {
          SILO_LAUNCH_SLICED(8, 1);
       }
    } else {
@@ -1928,7 +2138,7 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
          case 3: SILO_LAUNCH_SLICED(4, 3); break;
          case 4: SILO_LAUNCH_SLICED(4, 4); break;
          default:
-            if constexpr (BITS <= 3) {  // 5..8 filters: nucleotides only (amino-acid batches go in groups of 4)
+            if constexpr (NSYM <= 5) {  // 5..8 filters: layouts of at most 5 counted symbols (the others go in groups of 4)
                switch (q_count) {
                   case 5: SILO_LAUNCH_SLICED(4, 5); break;
                   case 6: SILO_LAUNCH_SLICED(4, 6); break;
@@ -1936,7 +2146,7 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
                   default: SILO_LAUNCH_SLICED(4, 8); break;
                }
             } else {
-               return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "launchSlicedScan: more than 4 amino-acid filters in one pass");
+               return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "launchSlicedScan: more than 4 filters in one pass over a 7- or 22-symbol layout");
             }
       }
    }
@@ -1945,15 +2155,15 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    return SILO_GPU_OK;
 }
 
-/// Launches k_scan_gather (one wave per POSG positions) for the ranges in `batch`; grid.y = filter.
-template <int BITS, int NSYM, int POSG>
+/// Launches k_scan_gather (one wave per POSG positions) for the pieces in `batch`; grid.y = filter.
+template <int BITS, int NSYM, int POSG, bool MAPPED>
 int launchGatherScan(ScanBatchArgs& batch, const uint32_t* sector_index, uint32_t stride, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
    batch.first_unit[0] = 0;
    for (uint32_t r = 0; r < batch.n_ranges; ++r) {
       batch.first_unit[r + 1] = batch.first_unit[r] + (batch.n_positions[r] + POSG - 1) / POSG;
    }
    const uint32_t waves = batch.first_unit[batch.n_ranges];
-   k_scan_gather<BITS, NSYM, POSG><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(batch, sector_index, stride, row_words);
+   k_scan_gather<BITS, NSYM, POSG, MAPPED><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(batch, sector_index, stride, row_words);
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }
@@ -2011,99 +2221,107 @@ void releaseSparseScratch(SparseScratch* block, hipStream_t stream) {
 }
 
 
-/// The dense kernels for `q_count` filters over `ranges` (all of one layout), at most SCAN_MAX_RANGES ranges and — for
-/// amino acids — 4 filters per launch.  `routing` carries the sparse-filter counters (or nullptr).
-int scanRangesDense(
-   const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, const uint32_t* sparse_sectors,
-   uint32_t sparse_capacity, hipStream_t hip_stream
-) {
-   const SeqStoreDev& layout = *ranges.front().dev;
-   // ranges with a compact scan index (two code planes per position + escapes) and ranges without go in separate launches
-   const bool allow_compact = g_tune_compact_index.load() >= 0;
-   const bool compact = allow_compact && ranges.front().compact != nullptr;
-   if (std::any_of(ranges.begin(), ranges.end(), [&](const ScanRange& range) { return (allow_compact && range.compact != nullptr) != compact; })) {
-      std::vector<ScanRange> with_index, without_index;
-      for (const ScanRange& range : ranges) {
-         (allow_compact && range.compact != nullptr ? with_index : without_index).push_back(range);
+
+/// Fills the piece-dependent part of a launch descriptor from pieces[first, first + n).
+void enterPieces(ScanBatchArgs& batch, const std::vector<ScanPiece>& pieces, size_t first, uint32_t n, uint32_t first_filter, uint32_t n_filters) {
+   batch.n_ranges = n;
+   for (uint32_t r = 0; r < n; ++r) {
+      const ScanPiece& piece = pieces[first + r];
+      batch.planes[r] = piece.planes;
+      batch.code_map[r] = piece.code_map;
+      batch.n_positions[r] = piece.n_positions;
+      for (uint32_t q = 0; q < n_filters; ++q) {
+         batch.counts[r][q] = piece.counts[first_filter + q];
       }
-      const int rc = scanRangesDense(with_index, filters, q_count, sparse_sectors, sparse_capacity, hip_stream);
-      return rc != SILO_GPU_OK ? rc : scanRangesDense(without_index, filters, q_count, sparse_sectors, sparse_capacity, hip_stream);
    }
-   const uint32_t filters_per_pass = compact || layout.n_bits == 3 ? SILO_GPU_MAX_SCAN_BATCH : 4;
-   for (size_t first_range = 0; first_range < ranges.size(); first_range += SCAN_MAX_RANGES) {
-      const uint32_t n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, ranges.size() - first_range));
-      for (uint32_t first = 0; first < q_count; first += filters_per_pass) {
-         const uint32_t n = std::min<uint32_t>(filters_per_pass, q_count - first);
-         ScanBatchArgs batch{};
-         batch.n_ranges = n_ranges;
-         batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first * SPARSE_COUNTER_STRIDE : nullptr;
-         batch.sparse_capacity = sparse_capacity;
-         batch.out_symbols = layout.n_scan;
-         for (uint32_t q = 0; q < n; ++q) {
-            batch.filters[q] = filters[first + q];
-         }
-         for (uint32_t r = 0; r < n_ranges; ++r) {
-            const ScanRange& range = ranges[first_range + r];
-            batch.planes[r] = compact ? range.compact->planes + static_cast<size_t>(range.pos_begin) * 2 * layout.row_words
-                                      : scanPlanes(*range.dev, range.pos_begin);
-            batch.code_map[r] = compact ? range.compact->code_map + static_cast<size_t>(range.pos_begin) * 4 : nullptr;
-            batch.n_positions[r] = range.pos_end - range.pos_begin;
+}
+
+/// The dense kernels for `q_count` filters over the pieces of every layout: at most SCAN_MAX_RANGES pieces and 8 (layouts
+/// of 3 or 5 counted symbols) or 4 (7 or 22) filters per launch.  sparse_sectors carries the routing counters (or nullptr).
+int scanPiecesDense(
+   const std::vector<ScanPiece> (&pieces)[N_SCAN_LAYOUTS], const SeqStoreDev& any_store, const uint64_t* const* filters, uint32_t q_count,
+   const uint32_t* sparse_sectors, uint32_t sparse_capacity, hipStream_t hip_stream
+) {
+   for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
+      const std::vector<ScanPiece>& list = pieces[layout];
+      const uint32_t filters_per_pass = layout == SCAN_2_PLANES || layout == SCAN_FULL_NUCLEOTIDE ? SILO_GPU_MAX_SCAN_BATCH : 4;
+      for (size_t first_piece = 0; first_piece < list.size(); first_piece += SCAN_MAX_RANGES) {
+         const uint32_t n_pieces = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, list.size() - first_piece));
+         for (uint32_t first = 0; first < q_count; first += filters_per_pass) {
+            const uint32_t n = std::min<uint32_t>(filters_per_pass, q_count - first);
+            ScanBatchArgs batch{};
+            batch.sparse_sectors = sparse_sectors != nullptr ? sparse_sectors + first * SPARSE_COUNTER_STRIDE : nullptr;
+            batch.sparse_capacity = sparse_capacity;
+            batch.out_symbols = any_store.n_scan;
             for (uint32_t q = 0; q < n; ++q) {
-               batch.counts[r][q] = range.counts[first + q];
+               batch.filters[q] = filters[first + q];
             }
-         }
-         const int rc = compact ? launchSlicedScan<2, 3>(batch, layout.row_words, n, hip_stream)
-                                : (layout.n_bits == 3 ? launchSlicedScan<3, 5>(batch, layout.row_words, n, hip_stream)
-                                                      : launchSlicedScan<5, 22>(batch, layout.row_words, n, hip_stream));
-         if (rc != SILO_GPU_OK) {
-            return rc;
-         }
-         for (uint32_t r = 0; compact && r < n_ranges; ++r) {  // the rows the two planes do not carry
-            const ScanRange& range = ranges[first_range + r];
-            const uint32_t begin = range.compact->escape_first[range.pos_begin];
-            const uint32_t count = range.compact->escape_first[range.pos_end] - begin;
-            if (count == 0) {
-               continue;
+            enterPieces(batch, list, first_piece, n_pieces, first, n);
+            int rc = SILO_GPU_OK;
+            switch (layout) {
+               case SCAN_2_PLANES: rc = launchSlicedScan<2, 3, true>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_3_PLANES_MAPPED: rc = launchSlicedScan<3, 7, true>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_FULL_NUCLEOTIDE: rc = launchSlicedScan<3, 5, false>(batch, any_store.row_words, n, hip_stream); break;
+               default: rc = launchSlicedScan<5, 22, false>(batch, any_store.row_words, n, hip_stream); break;
             }
-            ScanBatchArgs escapes = batch;
-            for (uint32_t q = 0; q < n; ++q) {
-               escapes.counts[0][q] = batch.counts[r][q];
+            if (rc != SILO_GPU_OK) {
+               return rc;
             }
-            k_scan_escapes<<<dim3((count + 255) / 256, n), 256, 0, hip_stream>>>(range.compact->escapes + begin, count, escapes, range.pos_begin);
-            HIP_TRY(hipGetLastError());
          }
       }
    }
    return SILO_GPU_OK;
 }
 
-/// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores with one layout (all
-/// nucleotide or all amino-acid), with the sparse-filter routing (K1s) around the dense kernels: every filter is
-/// compacted ONCE for all ranges, the dense kernels skip the sparse ones, the gather kernel serves them.  All
-/// decisions are taken on the device.
+/// The rows the code planes do not carry: one pass over the escape keys of every range, for all filters (dense and
+/// sparse alike: the gather reads the same planes).
+int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream) {
+   for (const ScanRange& range : ranges) {
+      const SeqStoreHost::Layout& layout = range.seqstore->layout;
+      if (!layout.built || layout.d_escapes == nullptr) {
+         continue;
+      }
+      const uint32_t begin = layout.escape_first[range.pos_begin];
+      const uint32_t count = layout.escape_first[range.pos_end] - begin;
+      if (count == 0) {
+         continue;
+      }
+      ScanBatchArgs escapes{};
+      escapes.out_symbols = range.seqstore->dev.n_scan;
+      for (uint32_t q = 0; q < q_count; ++q) {
+         escapes.filters[q] = filters[q];
+         escapes.counts[0][q] = range.counts[q];
+      }
+      k_scan_escapes<<<dim3((count + 255) / 256, q_count), 256, 0, hip_stream>>>(layout.d_escapes + begin, count, escapes, range.pos_begin);
+      HIP_TRY(hipGetLastError());
+   }
+   return SILO_GPU_OK;
+}
+
+/// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores of one alphabet, with the
+/// sparse-filter routing (K1s) around the dense kernels: every filter is compacted ONCE for all ranges, the dense
+/// kernels skip the sparse ones, the gather kernel serves them.  All decisions are taken on the device.
 int scanRanges(
    const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream
 ) {
-   const SeqStoreDev& layout = *ranges.front().dev;
-   const bool nucleotide = layout.n_bits == 3 && layout.n_scan == 5;
-   if (!nucleotide && !(layout.n_bits == 5 && layout.n_scan == 22)) {
+   const SeqStoreDev& any_store = ranges.front().seqstore->dev;
+   const bool nucleotide = any_store.n_bits == 3 && any_store.n_scan == 5;
+   if (!nucleotide && !(any_store.n_bits == 5 && any_store.n_scan == 22)) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
    }
-   if (layout.row_words < SCAN_THREADS * 4) {
-      // short rows: one wave per position, one filter and one range at a time
+   if (any_store.row_words < SCAN_THREADS * 4) {
+      // short rows: one wave per position over the identity planes (such stores keep them), one filter and one range at a time
       for (const ScanRange& range : ranges) {
+         const SeqStoreDev& dev = range.seqstore->dev;
          const uint32_t n_positions = range.pos_end - range.pos_begin;
          const uint32_t waves = std::min<uint32_t>(n_positions, 256u * 32u);
          const uint32_t blocks = (waves + 3) / 4;
+         const uint64_t* planes = dev.planes + static_cast<size_t>(range.pos_begin) * dev.n_bits * dev.row_words;
          for (uint32_t q = 0; q < q_count; ++q) {
             if (nucleotide) {
-               k_scan_sliced_rowwave<3, 5><<<blocks, 256, 0, hip_stream>>>(
-                  scanPlanes(*range.dev, range.pos_begin), filters[q], range.counts[q], layout.row_words, n_positions
-               );
+               k_scan_sliced_rowwave<3, 5><<<blocks, 256, 0, hip_stream>>>(planes, filters[q], range.counts[q], dev.row_words, n_positions);
             } else {
-               k_scan_sliced_rowwave<5, 22><<<blocks, 256, 0, hip_stream>>>(
-                  scanPlanes(*range.dev, range.pos_begin), filters[q], range.counts[q], layout.row_words, n_positions
-               );
+               k_scan_sliced_rowwave<5, 22><<<blocks, 256, 0, hip_stream>>>(planes, filters[q], range.counts[q], dev.row_words, n_positions);
             }
          }
       }
@@ -2112,11 +2330,14 @@ int scanRanges(
       return SILO_GPU_OK;
    }
    g_last_scan_kernel = q_count == 1 ? "k_scan_sliced" : "k_scan_sliced_batch";
+   std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
+   cutIntoPieces(ranges, q_count, pieces);
    const int divisor = g_tune_sparse_divisor.load();
    if (divisor < 0) {
-      return scanRangesDense(ranges, filters, q_count, nullptr, 0, hip_stream);
+      const int rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
+      return rc != SILO_GPU_OK ? rc : scanEscapes(ranges, filters, q_count, hip_stream);
    }
-   const uint32_t capacity = std::max<uint32_t>(4, layout.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
+   const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
    const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
    if (acquired != SILO_GPU_OK) {
@@ -2131,76 +2352,71 @@ int scanRanges(
       for (uint32_t q = 0; q < q_count; ++q) {
          compact.filters[q] = filters[q];
       }
-      k_compact_filter<<<dim3((layout.row_words + COMPACT_THREADS - 1) / COMPACT_THREADS, q_count), COMPACT_THREADS, 0, hip_stream>>>(
-         compact, layout.row_words, stride, scratch->sparse_sectors, scratch->sector_index
+      k_compact_filter<<<dim3((any_store.row_words + COMPACT_THREADS - 1) / COMPACT_THREADS, q_count), COMPACT_THREADS, 0, hip_stream>>>(
+         compact, any_store.row_words, stride, scratch->sparse_sectors, scratch->sector_index
       );
-      rc = scanRangesDense(ranges, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
+      rc = scanPiecesDense(pieces, any_store, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
    }
-   // the gather over the sectors of the sparse filters: ranges with a compact scan index read its two planes (their escape
-   // keys were added for every filter above), the others the full planes
-   const bool allow_compact = g_tune_compact_index.load() >= 0;
-   for (const bool indexed : {true, false}) {
-      std::vector<const ScanRange*> group;
-      for (const ScanRange& range : ranges) {
-         if ((allow_compact && range.compact != nullptr) == indexed) {
-            group.push_back(&range);
-         }
-      }
-      for (size_t first_range = 0; rc == SILO_GPU_OK && first_range < group.size(); first_range += SCAN_MAX_RANGES) {
+   if (rc == SILO_GPU_OK) {
+      rc = scanEscapes(ranges, filters, q_count, hip_stream);
+   }
+   // the gather over the sectors of the sparse filters, over the same pieces of the same planes
+   for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
+      const std::vector<ScanPiece>& list = pieces[layout];
+      for (size_t first_piece = 0; rc == SILO_GPU_OK && first_piece < list.size(); first_piece += SCAN_MAX_RANGES) {
          ScanBatchArgs batch{};
-         batch.n_ranges = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, group.size() - first_range));
          batch.sparse_sectors = scratch->sparse_sectors;
          batch.sparse_capacity = capacity;
-         batch.out_symbols = layout.n_scan;
+         batch.out_symbols = any_store.n_scan;
          for (uint32_t q = 0; q < q_count; ++q) {
             batch.filters[q] = filters[q];
          }
-         for (uint32_t r = 0; r < batch.n_ranges; ++r) {
-            const ScanRange& range = *group[first_range + r];
-            batch.planes[r] = indexed ? range.compact->planes + static_cast<size_t>(range.pos_begin) * 2 * layout.row_words
-                                      : scanPlanes(*range.dev, range.pos_begin);
-            batch.code_map[r] = indexed ? range.compact->code_map + static_cast<size_t>(range.pos_begin) * 4 : nullptr;
-            batch.n_positions[r] = range.pos_end - range.pos_begin;
-            for (uint32_t q = 0; q < q_count; ++q) {
-               batch.counts[r][q] = range.counts[q];
-            }
+         enterPieces(batch, list, first_piece, static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, list.size() - first_piece)), 0, q_count);
+         switch (layout) {
+            case SCAN_2_PLANES: rc = launchGatherScan<2, 3, 4, true>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_3_PLANES_MAPPED: rc = launchGatherScan<3, 7, 4, true>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_FULL_NUCLEOTIDE: rc = launchGatherScan<3, 5, 4, false>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            default: rc = launchGatherScan<5, 22, 2, false>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
          }
-         rc = indexed      ? launchGatherScan<2, 3, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
-              : nucleotide ? launchGatherScan<3, 5, 4>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream)
-                           : launchGatherScan<5, 22, 2>(batch, scratch->sector_index, stride, layout.row_words, q_count, hip_stream);
       }
    }
    releaseSparseScratch(scratch, hip_stream);
    return rc;
 }
 
-/// finalize(): derive the compact scan index of one sequence store (see K1i above) — or leave the store without one
-/// when it would not pay (short rows), would not be compact (too many escapes) or would not fit.
-int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
-   const SeqStoreDev& dev = seqstore.dev;
-   SeqStoreHost::CompactIndex& compact = seqstore.compact;
-   compact.ready = false;
-   (void)hipFree(compact.planes);
-   (void)hipFree(compact.code_map);
-   (void)hipFree(compact.escapes);
-   compact.planes = nullptr;
-   compact.code_map = nullptr;
-   compact.escapes = nullptr;
-   const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
-   if ((!nucleotide && !(dev.n_bits == 5 && dev.n_scan == 22)) || dev.row_words < SCAN_THREADS * 4 || dev.positions == 0 ||
-       store->sequence_count == 0 || g_tune_compact_index.load() < 0) {
+/// finalize(): derive the adaptive code planes of one sequence store (see k_choose_layout) and release its build-time
+/// planes — or keep those as they are when re-encoding would not pay (short rows), is switched off
+/// (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit next to them.
+int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   SeqStoreDev& dev = seqstore.dev;
+   SeqStoreHost::Layout& layout = seqstore.layout;
+   const uint32_t positions = dev.positions;
+   const auto keepBuildPlanes = [&]() {  // every position: the n_bits identity planes, where they are
+      layout.runs.assign(1, SeqStoreHost::Run{0, positions, static_cast<uint8_t>(dev.n_bits), true});
+      dev.planes = dev.scan;
+      dev.row_of = nullptr;
+      dev.code_map = nullptr;
+      dev.escapes = nullptr;
+      dev.escape_first = nullptr;
+      layout.built = true;
       return SILO_GPU_OK;
+   };
+   const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
+   if ((!nucleotide && !(dev.n_bits == 5 && dev.n_scan == 22)) || dev.row_words < SCAN_THREADS * 4 || positions == 0 || store->sequence_count == 0 ||
+       g_tune_compact_index.load() < 0) {
+      return keepBuildPlanes();
    }
    // the unfiltered totals decide the codes (and are what a full filter adds later on)
-   const size_t n_totals = static_cast<size_t>(dev.positions) * dev.n_scan;
+   const size_t n_counters = static_cast<size_t>(positions) * dev.n_scan;
    if (seqstore.d_totals == nullptr) {
-      HIP_TRY(hipMalloc(&seqstore.d_totals, n_totals * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&seqstore.d_totals, n_counters * sizeof(uint32_t)));
    }
    if (!seqstore.totals_ready) {
-      HIP_TRY(hipMemsetAsync(seqstore.d_totals, 0, n_totals * sizeof(uint32_t), nullptr));
-      ScanRange all{&dev, 0, dev.positions, {}, nullptr};
+      HIP_TRY(hipMemsetAsync(seqstore.d_totals, 0, n_counters * sizeof(uint32_t), nullptr));
+      ScanRange all{&seqstore, 0, positions, {}};
       all.counts[0] = seqstore.d_totals;
       const uint64_t* ones = store->d_ones;
+      layout.runs.clear();  // scan the build-time planes
       const int rc = scanRanges(store, {all}, &ones, 1, nullptr);
       if (rc != SILO_GPU_OK) {
          return rc;
@@ -2208,82 +2424,125 @@ int buildCompactIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
       HIP_TRY(hipStreamSynchronize(nullptr));
       seqstore.totals_ready = true;
    }
+   uint8_t* d_code_map = nullptr;
    uint32_t* d_count = nullptr;  // escapes per (position, symbol), later the cursors of the encoder
-   const size_t n_counters = n_totals;
-   HIP_TRY(hipMalloc(&compact.code_map, static_cast<size_t>(dev.positions) * 4));
-   HIP_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
-   k_choose_codes<<<(dev.positions + 255) / 256, 256>>>(seqstore.d_totals, dev.n_scan, dev.positions, compact.code_map, d_count);
-   std::vector<uint32_t> counts(n_counters);
-   hipError_t status = hipMemcpy(counts.data(), d_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-   uint64_t total = 0;
-   std::vector<uint32_t> counter_first(n_counters + 1, 0);  // slot of the first key of every (position, symbol)
-   compact.escape_first.assign(dev.positions + 1, 0);
-   for (size_t k = 0; k < n_counters; ++k) {
-      if (k % dev.n_scan == 0) {
-         compact.escape_first[k / dev.n_scan] = static_cast<uint32_t>(total);
-      }
-      counter_first[k] = static_cast<uint32_t>(total);
-      total += counts[k];
-   }
-   counter_first[n_counters] = static_cast<uint32_t>(total);
-   compact.escape_first[dev.positions] = static_cast<uint32_t>(total);
-   const size_t plane_bytes = static_cast<size_t>(dev.positions) * 2 * dev.row_words * sizeof(uint64_t);
-   const size_t escape_bytes = std::max<uint64_t>(total, 1) * sizeof(uint64_t);
-   size_t free_bytes = 0, total_bytes = 0;
-   if (status == hipSuccess) {
-      status = hipMemGetInfo(&free_bytes, &total_bytes);
-   }
-   const size_t reserve = std::min<size_t>(size_t{40} << 30, total_bytes / 4);  // derived-plane cache, query buffers, the next store
-   // the budget grows with the planes the index saves per position: 1 of 3 (nucleotides), 3 of 5 (amino acids)
-   const uint64_t divisor = COMPACT_ESCAPE_DIVISOR / (dev.n_bits - 2);
-   const bool worth_it = total * divisor <= static_cast<uint64_t>(store->sequence_count) * dev.positions && total < (uint64_t{1} << 32);
-   if (status != hipSuccess || !worth_it || free_bytes < plane_bytes + escape_bytes + reserve) {
-      (void)hipFree(d_count);
-      (void)hipFree(compact.code_map);
-      compact.code_map = nullptr;
-      compact.escape_first.clear();
-      HIP_TRY(status);
-      return SILO_GPU_OK;  // the full code planes serve the scan
-   }
    uint32_t* d_first = nullptr;
-   status = hipMalloc(&compact.planes, plane_bytes);
-   if (status == hipSuccess) {
-      status = hipMalloc(&compact.escapes, escape_bytes);
-   }
-   if (status == hipSuccess) {
-      status = hipMalloc(&d_first, counter_first.size() * sizeof(uint32_t));
-   }
-   if (status == hipSuccess) {
-      status = hipMemcpy(d_first, counter_first.data(), counter_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-   }
-   if (status == hipSuccess) {
-      status = hipMemset(d_count, 0, n_counters * sizeof(uint32_t));
-   }
-   if (status == hipSuccess) {
-      const dim3 grid((dev.row_words + 255) / 256, dev.positions);
-      if (nucleotide) {
-         k_encode_compact<3><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
-      } else {
-         k_encode_compact<5><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, compact.code_map, d_first, d_count, compact.planes, compact.escapes);
+   uint32_t* d_row_of = nullptr;
+   uint32_t* d_escape_first = nullptr;
+   uint64_t* d_planes = nullptr;
+   uint64_t* d_escapes = nullptr;
+   const auto discard = [&]() {
+      (void)hipFree(d_code_map);
+      (void)hipFree(d_count);
+      (void)hipFree(d_first);
+      (void)hipFree(d_row_of);
+      (void)hipFree(d_escape_first);
+      (void)hipFree(d_planes);
+      (void)hipFree(d_escapes);
+   };
+#define SILO_LAYOUT_TRY(expr)                                                       \
+   do {                                                                             \
+      const hipError_t status_ = (expr);                                            \
+      if (status_ != hipSuccess) {                                                  \
+         discard();                                                                 \
+         HIP_TRY(status_);                                                          \
+      }                                                                             \
+   } while (0)
+   SILO_LAYOUT_TRY(hipMalloc(&d_code_map, static_cast<size_t>(positions) * CODE_MAP_STRIDE));
+   SILO_LAYOUT_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
+   k_choose_layout<<<(positions + 255) / 256, 256>>>(
+      seqstore.d_totals, dev.n_scan, dev.n_bits, positions, dev.row_words * static_cast<uint32_t>(sizeof(uint64_t)), d_code_map, d_count
+   );
+   std::vector<uint8_t> code_map(static_cast<size_t>(positions) * CODE_MAP_STRIDE);
+   std::vector<uint32_t> counts(n_counters);
+   SILO_LAYOUT_TRY(hipMemcpy(code_map.data(), d_code_map, code_map.size(), hipMemcpyDeviceToHost));
+   SILO_LAYOUT_TRY(hipMemcpy(counts.data(), d_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   std::vector<uint32_t> row_of(positions + 1, 0);
+   std::vector<uint32_t> escape_first(positions + 1, 0);
+   std::vector<uint32_t> escape_first_symbol(n_counters + 1, 0);
+   std::vector<SeqStoreHost::Run> runs;
+   uint64_t total_escapes = 0;
+   uint64_t total_rows = 0;
+   bool any_encoded = false;
+   for (uint32_t p = 0; p < positions; ++p) {
+      const uint8_t bits = code_map[static_cast<size_t>(p) * CODE_MAP_STRIDE] & 0x7Fu;
+      const bool identity = (code_map[static_cast<size_t>(p) * CODE_MAP_STRIDE] & LAYOUT_IDENTITY) != 0;
+      any_encoded = any_encoded || !identity;
+      row_of[p] = static_cast<uint32_t>(total_rows);
+      total_rows += bits;
+      escape_first[p] = static_cast<uint32_t>(total_escapes);
+      for (uint32_t symbol = 0; symbol < dev.n_scan; ++symbol) {
+         escape_first_symbol[static_cast<size_t>(p) * dev.n_scan + symbol] = static_cast<uint32_t>(total_escapes);
+         total_escapes += counts[static_cast<size_t>(p) * dev.n_scan + symbol];
       }
-      status = hipGetLastError();
+      if (runs.empty() || runs.back().bits != bits || runs.back().identity != identity) {
+         runs.push_back(SeqStoreHost::Run{p, p + 1, bits, identity});
+      } else {
+         runs.back().end = p + 1;
+      }
    }
-   if (status == hipSuccess) {
-      status = hipDeviceSynchronize();
+   row_of[positions] = static_cast<uint32_t>(total_rows);
+   escape_first[positions] = static_cast<uint32_t>(total_escapes);
+   escape_first_symbol[n_counters] = static_cast<uint32_t>(total_escapes);
+   const size_t plane_bytes = static_cast<size_t>(total_rows) * dev.row_words * sizeof(uint64_t);
+   const size_t escape_bytes = std::max<uint64_t>(total_escapes, 1) * sizeof(uint64_t);
+   size_t free_bytes = 0, total_bytes = 0;
+   SILO_LAYOUT_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+   // both representations are resident until the re-encoding is done; the sort of the keys needs as much again as the keys
+   if (!any_encoded || total_rows >= (uint64_t{1} << 32) || total_escapes >= (uint64_t{1} << 32) ||
+       free_bytes < plane_bytes + 3 * escape_bytes + (size_t{1} << 30)) {
+      discard();
+      return keepBuildPlanes();
    }
+   SILO_LAYOUT_TRY(hipMalloc(&d_planes, plane_bytes));
+   SILO_LAYOUT_TRY(hipMalloc(&d_escapes, escape_bytes));
+   SILO_LAYOUT_TRY(hipMalloc(&d_first, escape_first_symbol.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&d_row_of, row_of.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&d_escape_first, escape_first.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMemcpy(d_first, escape_first_symbol.data(), escape_first_symbol.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(d_row_of, row_of.data(), row_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(d_escape_first, escape_first.data(), escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemset(d_count, 0, n_counters * sizeof(uint32_t)));
+   {
+      const dim3 grid((dev.row_words + 255) / 256, positions);
+      if (nucleotide) {
+         k_encode_adaptive<3><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, d_code_map, d_row_of, d_first, d_count, d_planes, d_escapes);
+      } else {
+         k_encode_adaptive<5><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, d_code_map, d_row_of, d_first, d_count, d_planes, d_escapes);
+      }
+      SILO_LAYOUT_TRY(hipGetLastError());
+      SILO_LAYOUT_TRY(hipDeviceSynchronize());
+   }
+   if (const int rc = silo_gpu_internal_sort_keys(d_escapes, total_escapes); rc != SILO_GPU_OK) {  // ascending: (position, symbol, sequence)
+      discard();
+      return rc;
+   }
+#undef SILO_LAYOUT_TRY
    (void)hipFree(d_first);
    (void)hipFree(d_count);
-   if (status != hipSuccess) {
-      (void)hipFree(compact.planes);
-      (void)hipFree(compact.escapes);
-      (void)hipFree(compact.code_map);
-      compact.planes = nullptr;
-      compact.escapes = nullptr;
-      compact.code_map = nullptr;
-      HIP_TRY(status);
-   }
-   store->device_bytes += plane_bytes + escape_bytes + static_cast<size_t>(dev.positions) * 4;
-   compact.ready = true;
+   // the adaptive planes take over; the build-time planes go
+   const size_t build_bytes = static_cast<size_t>(positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
+   (void)hipFree(dev.scan);
+   dev.scan = nullptr;
+   store->device_bytes -= build_bytes;
+   layout.planes = d_planes;
+   layout.d_row_of = d_row_of;
+   layout.d_code_map = d_code_map;
+   layout.d_escapes = d_escapes;
+   layout.d_escape_first = d_escape_first;
+   layout.row_of = std::move(row_of);
+   layout.code_map = std::move(code_map);
+   layout.escape_first = std::move(escape_first);
+   layout.escape_first_symbol = std::move(escape_first_symbol);
+   layout.runs = std::move(runs);
+   layout.device_bytes = plane_bytes + escape_bytes + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8);
+   store->device_bytes += layout.device_bytes;
+   dev.planes = d_planes;
+   dev.row_of = d_row_of;
+   dev.code_map = d_code_map;
+   dev.escapes = d_escapes;
+   dev.escape_first = d_escape_first;
+   layout.built = true;
    return SILO_GPU_OK;
 }
 
@@ -2334,7 +2593,10 @@ int silo_gpu_mutations_scan_ranges(
                continue;
             }
             const SeqStoreHost& seqstore = store->seqstores[ranges[r].seqstore_id];
-            ScanRange range{&dev, ranges[r].pos_begin, ranges[r].pos_end, {}, seqstore.compact.ready ? &seqstore.compact : nullptr};
+            if (dev.planes == nullptr) {
+               return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_scan_ranges: the sequence store holds no sequences yet");
+            }
+            ScanRange range{&seqstore, ranges[r].pos_begin, ranges[r].pos_end, {}};
             for (uint32_t q = 0; q < q_count; ++q) {
                range.counts[q] = counts_out_dev[static_cast<size_t>(r) * n_filters + first + q];
             }
@@ -2367,14 +2629,41 @@ uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqsto
       return 0;
    }
    const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
-   return seqstore.compact.ready && g_tune_compact_index.load() >= 0 ? 2 : seqstore.dev.n_bits;
+   uint64_t positions_with[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // by number of code planes
+   for (const SeqStoreHost::Run& run : seqstore.layout.runs) {
+      positions_with[run.bits & 7u] += run.end - run.begin;
+   }
+   uint32_t most_common = seqstore.dev.n_bits;
+   uint64_t most = 0;
+   for (uint32_t bits = 1; bits < 8; ++bits) {
+      if (positions_with[bits] > most) {
+         most = positions_with[bits];
+         most_common = bits;
+      }
+   }
+   return most_common;
+}
+
+uint64_t silo_gpu_store_scan_rows(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t pos_begin, uint32_t pos_end) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size()) {
+      return 0;
+   }
+   const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   pos_end = std::min(pos_end, seqstore.dev.positions);
+   if (pos_begin >= pos_end) {
+      return 0;
+   }
+   if (seqstore.layout.row_of.empty()) {
+      return static_cast<uint64_t>(pos_end - pos_begin) * seqstore.dev.n_bits;
+   }
+   return seqstore.layout.row_of[pos_end] - seqstore.layout.row_of[pos_begin];
 }
 
 uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqstore_id) {
-   if (store == nullptr || seqstore_id >= store->seqstores.size() || !store->seqstores[seqstore_id].compact.ready) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || store->seqstores[seqstore_id].layout.escape_first.empty()) {
       return 0;
    }
-   return store->seqstores[seqstore_id].compact.escape_first.back();
+   return store->seqstores[seqstore_id].layout.escape_first.back();
 }
 
 int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream) {
@@ -2607,9 +2896,18 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
    }
    HIP_TRY(hipSetDevice(store->device));
    auto hip_stream = static_cast<hipStream_t>(stream);
-   if (seqstore.dev.kind[symbol] == PLANE_SCAN) {  // a valid mutation symbol: decode its one-hot plane from the bit planes
+   if (seqstore.dev.kind[symbol] == PLANE_SCAN) {  // a valid mutation symbol: decode its one-hot plane from the position's code planes
       k_decode_plane<<<(store->row_words + 255) / 256, 256, 0, hip_stream>>>(seqstore.dev, position, symbol, dst_dev);
       HIP_TRY(hipGetLastError());
+      if (!seqstore.layout.escape_first_symbol.empty()) {  // rows of the symbol that are listed as escape keys (it has no code here)
+         const size_t counter = static_cast<size_t>(position) * seqstore.dev.n_scan + seqstore.dev.index[symbol];
+         const uint32_t begin = seqstore.layout.escape_first_symbol[counter];
+         const uint32_t end = seqstore.layout.escape_first_symbol[counter + 1];
+         if (end > begin) {
+            k_scatter_sparse<<<(end - begin + 255) / 256, 256, 0, hip_stream>>>(seqstore.layout.d_escapes, begin, end, dst_dev);
+            HIP_TRY(hipGetLastError());
+         }
+      }
       return SILO_GPU_OK;
    }
    if (seqstore.dev.kind[symbol] == PLANE_EXTRA) {  // already a plane: copy it

@@ -1,0 +1,32 @@
+// silo_gpu_sort.hip — device radix sort of 64-bit keys (rocPRIM through hipCUB), kept in its own translation unit so
+// that the kernel file does not pay for the template instantiation on every rebuild.  Used once per sequence store at
+// finalize: the escape keys position << 37 | symbol << 32 | sequence of the adaptive code planes are put in ascending
+// order, which groups them by (position, symbol) for the scan's escape pass and makes a (position, symbol, sequence)
+// lookup a binary search (FastaAligned).
+#include <hipcub/hipcub.hpp>
+
+#include "internal.h"
+
+int silo_gpu_internal_sort_keys(uint64_t* keys_dev, size_t n) {
+   if (n < 2) {
+      return SILO_GPU_OK;
+   }
+   uint64_t* sorted = nullptr;
+   void* scratch = nullptr;
+   size_t scratch_bytes = 0;
+   SILO_HIP_TRY(hipMalloc(&sorted, n * sizeof(uint64_t)));
+   hipError_t status = hipcub::DeviceRadixSort::SortKeys(nullptr, scratch_bytes, keys_dev, sorted, n, 0, 64, nullptr);
+   if (status == hipSuccess) {
+      status = hipMalloc(&scratch, scratch_bytes);
+   }
+   if (status == hipSuccess) {
+      status = hipcub::DeviceRadixSort::SortKeys(scratch, scratch_bytes, keys_dev, sorted, n, 0, 64, nullptr);
+   }
+   if (status == hipSuccess) {
+      status = hipMemcpy(keys_dev, sorted, n * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+   }
+   (void)hipFree(scratch);
+   (void)hipFree(sorted);
+   SILO_HIP_TRY(status);
+   return SILO_GPU_OK;
+}

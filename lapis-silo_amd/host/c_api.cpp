@@ -157,7 +157,12 @@ int silo_engine_generate_synthetic(silo_engine* engine, int partition, const cha
    if (id < 0) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
    }
-   const int status = silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
+   int status = silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
+   if (status == 0) {
+      // the generator fills the whole sequence store in this one call: re-encode it now, so that the build-time planes of
+      // the stores of a partition (112 GB for the nucleotide genome at 10 M sequences) are never resident together
+      status = silo_gpu_store_finalize_seqstore(part->store, static_cast<uint32_t>(id));
+   }
    return status == 0 ? 0 : fail(status, silo_gpu_last_error());
 }
 

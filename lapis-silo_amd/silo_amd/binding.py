@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
-    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes", "silo_gpu_store_scan_rows", "silo_gpu_store_finalize_seqstore",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
     "silo_gpu_comm_unique_id", "silo_gpu_comm_create", "silo_gpu_comm_destroy", "silo_gpu_comm_rank", "silo_gpu_comm_world",
@@ -160,6 +160,9 @@ def load_library():
     lib.silo_gpu_tune.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.silo_gpu_last_scan_kernel.restype = ctypes.c_char_p
     lib.silo_gpu_last_error.restype = ctypes.c_char_p
+    lib.silo_gpu_store_scan_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.silo_gpu_store_scan_rows.restype = ctypes.c_uint64
+    lib.silo_gpu_store_finalize_seqstore.argtypes = [vp, ctypes.c_uint32]
     lib.silo_gpu_filter_eval_batch.argtypes = [vp, ctypes.POINTER(BitProg), ctypes.c_uint32, ctypes.POINTER(vp), c_u64p, vp]
     lib.silo_gpu_comm_unique_id.argtypes = [vp]
     lib.silo_gpu_comm_create.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp)]
@@ -520,8 +523,15 @@ class GpuStore:
         return tables
 
     def scan_planes(self, seqstore_id):
-        """Plane rows the Mutations scan reads per position: 2 with the compact scan index (K1i), else 3 / 5."""
+        """Code planes per position of the store's most common layout: 2 (or 3) after the re-encoding at finalize, else 3 / 5."""
         return self.lib.silo_gpu_store_scan_planes(self.handle, seqstore_id)
+
+    def scan_rows(self, seqstore_id, pos_begin, pos_end):
+        """Plane rows the Mutations scan reads for positions [pos_begin, pos_end)."""
+        return int(self.lib.silo_gpu_store_scan_rows(self.handle, seqstore_id, pos_begin, pos_end))
+
+    def finalize_seqstore(self, seqstore_id):
+        _check(self.lib.silo_gpu_store_finalize_seqstore(self.handle, seqstore_id))
 
     def scan_escapes(self, seqstore_id):
         return self.lib.silo_gpu_store_scan_escapes(self.handle, seqstore_id)

@@ -179,48 +179,67 @@ def scan_table(lib, store, filt, begin, end):
     return table.reshape(end - begin, 5)
 
 
-def test_config3_scan_at_10m_compact_index_full_planes_and_c_port_agree(full_store):
+def test_config3_scan_at_10m_adaptive_planes_identity_planes_and_c_port_agree(full_store):
     engine, model, tree, lineage = full_store
     lib = binding.load_library()
     store = engine.partition_store(0)
     member = tree.subtree(tree.names.index(bench.QUERY_LINEAGE))
-    filt = ctypes.c_void_p()
-    binding._check(lib.silo_gpu_bitset_alloc(store.handle, ctypes.byref(filt)))
-    binding._check(lib.silo_gpu_bitset_from_lineages(store.handle, filt, member.ctypes.data_as(ctypes.c_void_p), len(member), None))
     positions = model.positions
+
+    def lineage_filter(handle):
+        filt = ctypes.c_void_p()
+        binding._check(lib.silo_gpu_bitset_alloc(handle, ctypes.byref(filt)))
+        binding._check(lib.silo_gpu_bitset_from_lineages(handle, filt, member.ctypes.data_as(ctypes.c_void_p), len(member), None))
+        return filt
+
+    filt = lineage_filter(store.handle)
     try:
-        assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 2, "the 10 M nucleotide store is expected to carry the compact scan index"
-        compact = scan_table(lib, store, filt, 0, positions)
-        previous = lib.silo_gpu_tune(4, -1)  # SILO_GPU_TUNE_COMPACT_INDEX: scan the full code planes
-        try:
-            full = scan_table(lib, store, filt, 0, positions)
-        finally:
-            lib.silo_gpu_tune(4, previous)
-        assert np.array_equal(compact, full)  # two layouts, two kernels, the whole genome
+        assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 2, "the 10 M nucleotide store is expected to be re-encoded into 2 code planes"
+        rows = int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, positions))
+        assert 2 * positions <= rows < 2.01 * positions  # a few positions keep their 3 identity planes
+        adaptive = scan_table(lib, store, filt, 0, positions)
         mask = member[lineage].astype(bool)
-        assert int(compact.sum(axis=1).max()) <= int(mask.sum())
+        assert int(adaptive.sum(axis=1).max()) <= int(mask.sum())
         # the reference's algorithm over roaring-format containers (C port) on three windows of positions
         port_filter = cpu_port.Filter(dense.pack_bits(mask), FULL_N)
         for begin, count in ((0, 32), (positions // 2 // 64 * 64, 64), (positions - 32, 32)):
             port = cpu_port.PortStore(FULL_N, begin, count, "nuc", model=model)
             want, _ = port.mutations_scan(port_filter, n_threads=0, grain=max(1, count // 8))
             port.close()
-            assert np.array_equal(compact[begin:begin + count], want[:, :5]), (begin, count)
+            assert np.array_equal(adaptive[begin:begin + count], want[:, :5]), (begin, count)
         # and the engine's rows come from these counts: minProportion 0.05 of the filtered total per position
         rows = engine.execute_query(bench.make_query())
         by_mutation = {row["mutation"]: row for row in rows}
         reference = model.reference
         expected = 0
         for position in range(positions):
-            total = int(compact[position].sum())
+            total = int(adaptive[position].sum())
             if total == 0:
                 continue
             threshold = int(np.ceil(total * 0.05) - 1)
             for symbol in range(5):
-                if symbol != reference[position] and compact[position][symbol] > threshold:
+                if symbol != reference[position] and adaptive[position][symbol] > threshold:
                     expected += 1
                     row = by_mutation[f"{NUC_CHARS[reference[position]]}{position + 1}{NUC_CHARS[symbol]}"]
-                    assert row["count"] == int(compact[position][symbol]) and row["proportion"] == compact[position][symbol] / total
+                    assert row["count"] == int(adaptive[position][symbol]) and row["proportion"] == adaptive[position][symbol] / total
         assert expected == len(rows) > 100
     finally:
         lib.silo_gpu_free(filt)
+    # A second store of the same data that keeps its build-time identity planes (re-encoding switched off): another layout,
+    # another kernel instantiation, the whole genome — the same table.  (The module's engine is closed first: both do not
+    # fit the device together with their build-time planes.)
+    engine.close()
+    previous = lib.silo_gpu_tune(4, -1)  # SILO_GPU_TUNE_COMPACT_INDEX < 0: finalize keeps the identity planes
+    try:
+        plain_engine = bench.build_engine(FULL_N, 0, 1, None, 0)[0]
+    finally:
+        lib.silo_gpu_tune(4, previous)
+    try:
+        plain_store = plain_engine.partition_store(0)
+        assert lib.silo_gpu_store_scan_planes(plain_store.handle, 0) == 3
+        plain_filter = lineage_filter(plain_store.handle)
+        identity = scan_table(lib, plain_store, plain_filter, 0, positions)
+        lib.silo_gpu_free(plain_filter)
+        assert np.array_equal(adaptive, identity)
+    finally:
+        plain_engine.close()

@@ -274,48 +274,76 @@ def skewed_symbols(rng, n, positions, alphabet):
 
 
 @pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc")])
-def test_compact_scan_index_gives_the_same_tables(built, n, alphabet):
-    """K1i: on alignment-like data finalize() builds the 2-plane scan index with its escape keys; the scan through it
-    (single, batched, sub-ranges, sparse filters, several ranges) equals the naive counts and the scan of the full planes."""
+def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
+    """finalize() re-encodes alignment-like data into 2 code planes per position + escape keys (and releases the build-time
+    planes); with the re-encoding switched off the store keeps its 3 / 5 identity planes.  Both stores answer every scan
+    (single, batched, sub-ranges, sparse filters, several ranges), every filter leaf and FastaAligned like the naive oracle."""
     rng = np.random.default_rng(n + 17)
     positions = 29
     sym = skewed_symbols(rng, n, positions, alphabet)
     sym2 = skewed_symbols(rng, n, 11, alphabet)
+    # one position where many symbols are frequent: it keeps more planes than its neighbours (a run of its own)
+    table_size = 16 if alphabet == "nuc" else 25
+    sym[:, 13] = rng.integers(0, table_size, size=n)
     chars = NUC_CHARS if alphabet == "nuc" else AA_CHARS
-    with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:
-        store.append_sequences(0, 0, chars[sym])
-        store.append_sequences(1, 0, chars[sym2])
-        store.finalize()
-        scan_symbols = list(store.scan_symbols[0])
-        assert store.scan_planes(0) == 2 and store.scan_planes(1) == 2
-        escapes = store.scan_escapes(0)
-        valid = np.isin(sym, scan_symbols)
-        assert 0 < escapes <= n * positions // 512
-        sparse = np.zeros(n, bool)
-        sparse[rng.choice(n, size=9, replace=False)] = True
-        masks = [rng.random(n) < 0.4, sparse, np.ones(n, bool), rng.random(n) < 0.02, np.zeros(n, bool)]
-        ptrs = []
-        for mask in masks:
-            ptr = store.bitset_alloc()
-            store.bitset_upload(ptr, dense.pack_bits(mask))
-            ptrs.append(ptr)
-        want = [dense.mutation_counts(sym, mask, scan_symbols) for mask in masks]
-        want2 = [dense.mutation_counts(sym2, mask, scan_symbols) for mask in masks]
-        assert int(want[2].sum()) == int(valid.sum())
-        for knob in (0, -1):  # through the index, then through the full code planes
+    sparse = np.zeros(n, bool)
+    sparse[rng.choice(n, size=9, replace=False)] = True
+    masks = [rng.random(n) < 0.4, sparse, np.ones(n, bool), rng.random(n) < 0.02, np.zeros(n, bool)]
+    sizes = {}
+    for knob in (0, -1):  # re-encoded, then the identity planes kept
+        with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:
             store.tune(4, knob)
-            assert store.scan_planes(0) == (2 if knob == 0 else (3 if alphabet == "nuc" else 5))
+            try:
+                store.append_sequences(0, 0, chars[sym])
+                store.append_sequences(1, 0, chars[sym2])
+                store.finalize()
+            finally:
+                store.tune(4, 0)
+            sizes[knob] = store.device_bytes
+            scan_symbols = list(store.scan_symbols[0])
+            full_planes = 3 if alphabet == "nuc" else 5
+            if knob == 0:
+                assert store.scan_planes(0) == 2 and store.scan_planes(1) == 2
+                rows = store.scan_rows(0, 0, positions)
+                assert 2 * positions < rows <= 2 * (positions - 1) + full_planes  # position 13 keeps more planes
+                assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2
+                valid = np.isin(sym, scan_symbols)
+                assert 0 < store.scan_escapes(0) <= n * positions // 320
+                with pytest.raises(Exception):  # the build-time planes are gone
+                    store.append_sequences(0, 0, chars[sym[:1]])
+            else:
+                assert store.scan_planes(0) == full_planes and store.scan_rows(0, 0, positions) == full_planes * positions
+                assert store.scan_escapes(0) == 0
+            ptrs = []
+            for mask in masks:
+                ptr = store.bitset_alloc()
+                store.bitset_upload(ptr, dense.pack_bits(mask))
+                ptrs.append(ptr)
+            want = [dense.mutation_counts(sym, mask, scan_symbols) for mask in masks]
+            want2 = [dense.mutation_counts(sym2, mask, scan_symbols) for mask in masks]
+            assert int(want[2].sum()) == int(np.isin(sym, scan_symbols).sum())
             for ptr, table in zip(ptrs, want):
                 assert np.array_equal(store.mutations_scan(0, ptr), table), knob
             assert np.array_equal(store.mutations_scan(0, None), want[2])
             for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
                 assert np.array_equal(got, table), knob
             assert np.array_equal(store.mutations_scan(0, ptrs[0], 3, 20), dense.mutation_counts(sym, masks[0], scan_symbols, 3, 20))
-            tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6)], ptrs[:3])
+            tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6), (0, 13, 14), (0, 12, 15)], ptrs[:3])
             for q in range(3):
                 assert np.array_equal(tables[0][q], want[q]) and np.array_equal(tables[1][q], want2[q])
-                assert np.array_equal(tables[2][q], want[q][5:6])
-        store.tune(4, 0)
+                assert np.array_equal(tables[2][q], want[q][5:6]) and np.array_equal(tables[3][q], want[q][13:14])
+                assert np.array_equal(tables[4][q], want[q][12:15])
+            # every symbol's one-hot plane (filter leaves): coded symbols, escape keys, the missing symbol, sparse symbols
+            for position in (0, 13, positions - 1):
+                for symbol in range(table_size):
+                    got = store.plane_download(0, position, symbol)
+                    want_plane = dense.pack_bits(sym[:, position] == symbol)
+                    assert np.array_equal(got[: len(want_plane)], want_plane), (knob, position, symbol)
+                    assert not got[len(want_plane):].any()
+            # FastaAligned reads the same planes (and the keys)
+            picked = np.concatenate([rng.choice(n, size=40, replace=False), np.nonzero(~np.isin(sym[:, 13], scan_symbols))[0][:5]]).astype(np.uint32)
+            assert np.array_equal(store.reconstruct_sequences(0, picked), chars[sym[picked]])
+    assert sizes[0] < 0.85 * sizes[-1]  # 2 planes + the missing-symbol plane instead of 3 / 5 + 1
 
 
 @pytest.mark.parametrize("n", [900, 140000])
