@@ -308,7 +308,7 @@ __device__ __forceinline__ ulonglong2 loadGlobal16(const uint64_t* ptr) {
    return make_ulonglong2(v.x, v.y);
 }
 
-constexpr uint32_t SCAN_MAX_RANGES = 16;
+constexpr uint32_t SCAN_MAX_RANGES = 32;
 // the per-filter sector counters sit 256 bytes apart: atomics on one L2 channel serialise (~12 ns each), and a dense
 // filter makes every block add to its counter
 constexpr uint32_t SPARSE_COUNTER_STRIDE = 64;
@@ -745,81 +745,16 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
 //    3 planes: codes 1..7 = the seven most frequent (amino acids only: for nucleotides that is the full set),
 //    the full identity planes,
 // where the rows whose valid symbol got no code become explicit keys ("escapes": position << 37 | scan symbol << 32 |
-// sequence, sorted).  Cost model, in bytes the Mutations scan has to move: planes x row bytes + KEY_COST_BYTES per escape
-// (a key costs what ~40 plane bytes cost: 7.6 M keys in 46 us against 6.7 TB/s, profiles/r01_compact_index.md), the
-// 22-symbol decode of the full amino-acid planes weighted by what it costs in VALU time.  The build-time planes are
+// sequence, sorted).  Cost model (chooseLayouts, on the host from the unfiltered totals), in bytes the Mutations scan has
+// to move: planes x row bytes + KEY_COST_BYTES per escape (a key costs what ~40 plane bytes cost: 7.6 M keys in 46 us
+// against 6.7 TB/s, profiles/r01_compact_index.md), the 22-symbol decode of the full amino-acid planes weighted by what it
+// costs in VALU time, and a charge per change of layout between neighbouring positions: a scan launch takes runs of ONE
+// layout, and a run of a few positions costs its blocks the filter tile and the pipeline ramp all over again.  The build-time planes are
 // freed afterwards: at 10 M sequences the nucleotide store shrinks from 112 GB to 75 GB of code planes (+ 37 GB for the
 // missing-symbol plane) and every consumer — the scan, the sparse-filter gather, filter leaves, FastaAligned — reads the
 // adaptive planes.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t KEY_COST_BYTES = 40;
-
-__global__ __launch_bounds__(256) void k_choose_layout(
-   const uint32_t* __restrict__ totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint32_t row_bytes, uint8_t* __restrict__ code_map,
-   uint32_t* __restrict__ escape_count
-) {
-   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-   if (p >= positions) {
-      return;
-   }
-   const uint32_t* count = totals + static_cast<size_t>(p) * n_scan;
-   // the seven most frequent valid symbols, most frequent first; ties keep the lower symbol index in front
-   uint32_t best_symbol[7];
-   uint64_t best_sum[8];  // best_sum[k] = rows carried by the k most frequent
-   uint32_t taken = 0;    // bit s: symbol s is among the chosen
-   uint64_t total = 0;
-   for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-      total += count[symbol];
-   }
-   best_sum[0] = 0;
-   for (int k = 0; k < 7; ++k) {
-      uint32_t pick = 0xFFu;
-      uint32_t pick_count = 0;
-      for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-         if (((taken >> symbol) & 1u) == 0 && count[symbol] > pick_count) {
-            pick = symbol;
-            pick_count = count[symbol];
-         }
-      }
-      best_symbol[k] = pick;
-      best_sum[k + 1] = best_sum[k] + pick_count;
-      if (pick != 0xFFu) {
-         taken |= 1u << pick;
-      }
-   }
-   const uint64_t escapes2 = total - best_sum[3];
-   const uint64_t escapes3 = total - best_sum[7];
-   const uint64_t cost2 = 2ull * row_bytes + KEY_COST_BYTES * escapes2;
-   const uint64_t cost3 = 3ull * row_bytes + KEY_COST_BYTES * escapes3;
-   // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped
-   // layouts (profiles/README.md): weigh its bytes accordingly
-   const uint64_t cost_full = n_bits > 3 ? static_cast<uint64_t>(n_bits) * row_bytes * 115 / 100 : static_cast<uint64_t>(n_bits) * row_bytes;
-   uint32_t coded = 0;  // number of symbols that get a code; 0 = identity
-   uint32_t bits = n_bits;
-   if (cost2 <= cost_full && (n_bits <= 3 || cost2 <= cost3)) {
-      coded = 3;
-      bits = 2;
-   } else if (n_bits > 3 && cost3 < cost_full) {
-      coded = 7;
-      bits = 3;
-   }
-   uint8_t* map = code_map + static_cast<size_t>(p) * CODE_MAP_STRIDE;
-   map[0] = static_cast<uint8_t>(coded == 0 ? (bits | LAYOUT_IDENTITY) : bits);
-   for (uint32_t code = 1; code < CODE_MAP_STRIDE; ++code) {
-      map[code] = coded == 0 ? static_cast<uint8_t>(code - 1 < n_scan && code < (1u << n_bits) ? code - 1 : 0xFFu)
-                             : static_cast<uint8_t>(code <= coded ? best_symbol[code - 1] : 0xFFu);
-   }
-   // rows that become escape keys, per (position, symbol): exactly the totals of the symbols that got no code
-   uint32_t coded_mask = 0;
-   for (uint32_t k = 0; k < coded; ++k) {
-      if (best_symbol[k] != 0xFFu) {
-         coded_mask |= 1u << best_symbol[k];
-      }
-   }
-   for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-      escape_count[static_cast<size_t>(p) * n_scan + symbol] = coded == 0 || ((coded_mask >> symbol) & 1u) != 0 ? 0u : count[symbol];
-   }
-}
 
 /// Re-encodes the build-time planes of every position into its adaptive layout; rows without a code go, with an atomic
 /// cursor per (position, symbol), into that counter's exactly sized slice of the key list (sorted afterwards).
@@ -889,27 +824,42 @@ __global__ __launch_bounds__(256) void k_encode_adaptive(
    }
 }
 
-/// The rows the two code planes do not carry: one key per (position, symbol, sequence); grid.y = filter.
+/// The rows the code planes do not carry: one key per (position, symbol, sequence); grid.y = filter.  A thread takes
+/// ESCAPE_KEYS_PER_THREAD keys a block-width apart (their loads and the filter lookups behind them are in flight together).
+constexpr uint32_t ESCAPE_KEYS_PER_THREAD = 4;
 __global__ __launch_bounds__(256) void k_scan_escapes(
    const uint64_t* __restrict__ escapes, uint32_t n_escapes, const ScanBatchArgs batch, uint32_t pos_begin
 ) {
-   const uint32_t q = blockIdx.y;  // every filter: dense scan and sparse-filter gather of an indexed range both read the two planes
-   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   const uint32_t q = blockIdx.y;  // every filter: dense scan and sparse-filter gather of a range both read the same planes
    const uint32_t lane = threadIdx.x & 63u;
-   const uint64_t key = i < n_escapes ? escapes[i] : 0;
-   const uint32_t sequence = static_cast<uint32_t>(key);
-   bool pending = i < n_escapes && ((batch.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0;
-   // keys of one position sit together and share a few symbols: one atomic per distinct counter and wave, not per key
-   const uint32_t counter = (static_cast<uint32_t>(key >> 37) - pos_begin) * batch.out_symbols + (static_cast<uint32_t>(key >> 32) & 31u);
-   for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
-      const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
-      const uint32_t leader_counter = __shfl(counter, leader);
-      const uint64_t same = __ballot(pending && counter == leader_counter);
-      if (lane == leader) {
-         atomicAdd(&batch.counts[0][q][leader_counter], static_cast<uint32_t>(__popcll(same)));
-      }
-      if (counter == leader_counter) {
-         pending = false;
+   const uint32_t first = blockIdx.x * (256u * ESCAPE_KEYS_PER_THREAD) + threadIdx.x;
+   uint64_t key[ESCAPE_KEYS_PER_THREAD];
+   bool selected[ESCAPE_KEYS_PER_THREAD];
+#pragma unroll
+   for (uint32_t k = 0; k < ESCAPE_KEYS_PER_THREAD; ++k) {
+      const uint32_t i = first + k * 256u;
+      key[k] = i < n_escapes ? escapes[i] : 0;
+   }
+#pragma unroll
+   for (uint32_t k = 0; k < ESCAPE_KEYS_PER_THREAD; ++k) {
+      const uint32_t sequence = static_cast<uint32_t>(key[k]);
+      selected[k] = first + k * 256u < n_escapes && ((batch.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0;
+   }
+#pragma unroll
+   for (uint32_t k = 0; k < ESCAPE_KEYS_PER_THREAD; ++k) {
+      bool pending = selected[k];
+      // keys of one position sit together and share a few symbols: one atomic per distinct counter and wave, not per key
+      const uint32_t counter = (static_cast<uint32_t>(key[k] >> 37) - pos_begin) * batch.out_symbols + (static_cast<uint32_t>(key[k] >> 32) & 31u);
+      for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
+         const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
+         const uint32_t leader_counter = __shfl(counter, leader);
+         const uint64_t same = __ballot(pending && counter == leader_counter);
+         if (lane == leader) {
+            atomicAdd(&batch.counts[0][q][leader_counter], static_cast<uint32_t>(__popcll(same)));
+         }
+         if (counter == leader_counter) {
+            pending = false;
+         }
       }
    }
 }
@@ -2100,7 +2050,7 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    // words per thread: 8 for one filter over a layout of at most 5 counted symbols (2 or 3 planes x 4 chunks per position and
    // buffer), 4 otherwise (7 or 22 symbols; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
    const int variant = g_tune_scan_variant.load();
-   constexpr bool CAN_BE_WIDE = BITS <= 3 && NSYM <= 5;
+   constexpr bool CAN_BE_WIDE = BITS <= 3;
    bool wide = CAN_BE_WIDE && q_count == 1 && row_words >= SCAN_THREADS * 8;
    if (variant == 10) {
       wide = false;
@@ -2117,7 +2067,15 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    if (positions_per_block <= 0) {
       // 2 or 3 planes per position: 128 positions per block while that still leaves >= 4096 blocks, else 64; the 5 identity
       // planes of amino acids: 12 (60 plane rows) — profiles/r01_scan_variants.md
-      positions_per_block = BITS <= 3 ? (static_cast<uint64_t>(n_tiles) * ((total_positions + 127) / 128) >= 4096 ? 128 : 64) : 12;
+      // (a block re-reads its filter tile — one plane row's worth — whatever it scans, so fewer positions per block cost
+      // 1 / (positions x planes) more bytes; too few blocks leave the chip idle at the launch's tail)
+      positions_per_block = 12;
+      if constexpr (BITS <= 3) {
+         positions_per_block = 128;
+         while (positions_per_block > 32 && static_cast<uint64_t>(n_tiles) * ((total_positions + positions_per_block - 1) / positions_per_block) < 12288) {
+            positions_per_block /= 2;
+         }
+      }
    }
    positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
    batch.first_unit[0] = 0;
@@ -2292,8 +2250,67 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          escapes.filters[q] = filters[q];
          escapes.counts[0][q] = range.counts[q];
       }
-      k_scan_escapes<<<dim3((count + 255) / 256, q_count), 256, 0, hip_stream>>>(layout.d_escapes + begin, count, escapes, range.pos_begin);
+      const uint32_t keys_per_block = 256 * ESCAPE_KEYS_PER_THREAD;
+      k_scan_escapes<<<dim3((count + keys_per_block - 1) / keys_per_block, q_count), 256, 0, hip_stream>>>(
+         layout.d_escapes + begin, count, escapes, range.pos_begin
+      );
       HIP_TRY(hipGetLastError());
+   }
+   return SILO_GPU_OK;
+}
+
+/// A second stream (and the two events that tie it to the caller's) per host thread: the escape pass is a stream of keys,
+/// random filter lookups and atomics — latency-bound — and adds to the same count tables as the plane scans, which are
+/// bandwidth-bound, so the two run side by side instead of one after the other.  Never destroyed (thread exit may come
+/// after the HIP runtime has shut down).
+struct SideStream {
+   hipStream_t stream = nullptr;
+   hipEvent_t fork = nullptr;
+   hipEvent_t join = nullptr;
+   bool tried = false;
+};
+
+SideStream* sideStream() {
+   thread_local SideStream side;
+   if (!side.tried) {
+      side.tried = true;
+      if (hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) {
+         (void)hipGetLastError();
+         side.stream = nullptr;
+      }
+   }
+   return side.stream != nullptr ? &side : nullptr;
+}
+
+/// scanEscapes on the side stream: forked behind everything already queued on `hip_stream` (the filters are complete, the
+/// count tables zeroed), joined by joinEscapes before anything reads the tables.
+int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream, bool& forked) {
+   forked = false;
+   bool any = false;
+   for (const ScanRange& range : ranges) {
+      const SeqStoreHost::Layout& layout = range.seqstore->layout;
+      any = any || (layout.built && layout.d_escapes != nullptr && layout.escape_first[range.pos_end] != layout.escape_first[range.pos_begin]);
+   }
+   if (!any) {
+      return SILO_GPU_OK;
+   }
+   SideStream* side = sideStream();
+   if (side == nullptr) {
+      return scanEscapes(ranges, filters, q_count, hip_stream);
+   }
+   HIP_TRY(hipEventRecord(side->fork, hip_stream));
+   HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+   const int rc = scanEscapes(ranges, filters, q_count, side->stream);
+   HIP_TRY(hipEventRecord(side->join, side->stream));
+   forked = true;
+   return rc;
+}
+
+int joinEscapes(hipStream_t hip_stream, bool forked) {
+   if (forked) {
+      HIP_TRY(hipStreamWaitEvent(hip_stream, sideStream()->join, 0));
    }
    return SILO_GPU_OK;
 }
@@ -2333,14 +2350,21 @@ int scanRanges(
    std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
    cutIntoPieces(ranges, q_count, pieces);
    const int divisor = g_tune_sparse_divisor.load();
+   bool forked = false;
+   if (const int rc = forkEscapes(ranges, filters, q_count, hip_stream, forked); rc != SILO_GPU_OK) {
+      (void)joinEscapes(hip_stream, forked);
+      return rc;
+   }
    if (divisor < 0) {
       const int rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
-      return rc != SILO_GPU_OK ? rc : scanEscapes(ranges, filters, q_count, hip_stream);
+      const int joined = joinEscapes(hip_stream, forked);
+      return rc != SILO_GPU_OK ? rc : joined;
    }
    const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
    const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
    if (acquired != SILO_GPU_OK) {
+      (void)joinEscapes(hip_stream, forked);
       return acquired;
    }
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
@@ -2356,9 +2380,6 @@ int scanRanges(
          compact, any_store.row_words, stride, scratch->sparse_sectors, scratch->sector_index
       );
       rc = scanPiecesDense(pieces, any_store, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
-   }
-   if (rc == SILO_GPU_OK) {
-      rc = scanEscapes(ranges, filters, q_count, hip_stream);
    }
    // the gather over the sectors of the sparse filters, over the same pieces of the same planes
    for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
@@ -2381,10 +2402,108 @@ int scanRanges(
       }
    }
    releaseSparseScratch(scratch, hip_stream);
-   return rc;
+   const int joined = joinEscapes(hip_stream, forked);
+   return rc != SILO_GPU_OK ? rc : joined;
 }
 
-/// finalize(): derive the adaptive code planes of one sequence store (see k_choose_layout) and release its build-time
+/// The layout of every position of a sequence store (see "The adaptive code planes" above) from the unfiltered totals:
+/// code_map[p][0] = code planes (| LAYOUT_IDENTITY), code_map[p][c] = the scan symbol of code c; escape_count[p][s] = rows
+/// of symbol s at p that get no code.  A small dynamic program over the positions: the cost of a position under each of
+/// the three layouts plus RUN_COST for every change of layout between neighbours.
+void chooseLayouts(
+   const std::vector<uint32_t>& totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint64_t row_bytes, std::vector<uint8_t>& code_map,
+   std::vector<uint32_t>& escape_count
+) {
+   enum { TWO_PLANES = 0, THREE_PLANES = 1, IDENTITY = 2, N_LAYOUTS = 3 };
+   constexpr uint64_t NEVER = ~0ull >> 2;
+   const uint64_t run_cost = 2 * row_bytes;
+   std::vector<uint8_t> best(static_cast<size_t>(positions) * 7, 0xFF);   // the seven most frequent valid symbols, most frequent first
+   std::vector<uint64_t> cost(static_cast<size_t>(positions) * N_LAYOUTS);
+   for (uint32_t p = 0; p < positions; ++p) {
+      const uint32_t* count = totals.data() + static_cast<size_t>(p) * n_scan;
+      uint64_t total = 0;
+      for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+         total += count[symbol];
+      }
+      uint32_t taken = 0;
+      uint64_t carried[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rows carried by the k most frequent
+      for (int k = 0; k < 7; ++k) {
+         uint32_t pick = 0xFFu;
+         uint32_t pick_count = 0;
+         for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {  // ties keep the lower symbol index in front
+            if (((taken >> symbol) & 1u) == 0 && count[symbol] > pick_count) {
+               pick = symbol;
+               pick_count = count[symbol];
+            }
+         }
+         best[static_cast<size_t>(p) * 7 + k] = static_cast<uint8_t>(pick);
+         carried[k + 1] = carried[k] + pick_count;
+         if (pick != 0xFFu) {
+            taken |= 1u << pick;
+         }
+      }
+      cost[static_cast<size_t>(p) * N_LAYOUTS + TWO_PLANES] = 2 * row_bytes + KEY_COST_BYTES * (total - carried[3]);
+      // three mapped planes only pay where the identity layout has more (amino acids)
+      cost[static_cast<size_t>(p) * N_LAYOUTS + THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + KEY_COST_BYTES * (total - carried[7]) : NEVER;
+      // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped layouts
+      cost[static_cast<size_t>(p) * N_LAYOUTS + IDENTITY] = n_bits > 3 ? n_bits * row_bytes * 115 / 100 : n_bits * row_bytes;
+   }
+   std::vector<uint64_t> reach(static_cast<size_t>(positions) * N_LAYOUTS);  // cheapest way to encode positions [0, p] with p in that layout
+   std::vector<uint8_t> from(static_cast<size_t>(positions) * N_LAYOUTS);
+   for (uint32_t p = 0; p < positions; ++p) {
+      for (int layout = 0; layout < N_LAYOUTS; ++layout) {
+         uint64_t before = 0;
+         uint8_t previous = static_cast<uint8_t>(layout);
+         if (p > 0) {
+            before = NEVER;
+            for (int other = 0; other < N_LAYOUTS; ++other) {
+               const uint64_t candidate = reach[static_cast<size_t>(p - 1) * N_LAYOUTS + other] + (other == layout ? 0 : run_cost);
+               if (candidate < before) {
+                  before = candidate;
+                  previous = static_cast<uint8_t>(other);
+               }
+            }
+         }
+         reach[static_cast<size_t>(p) * N_LAYOUTS + layout] = std::min(NEVER, before + cost[static_cast<size_t>(p) * N_LAYOUTS + layout]);
+         from[static_cast<size_t>(p) * N_LAYOUTS + layout] = previous;
+      }
+   }
+   code_map.assign(static_cast<size_t>(positions) * CODE_MAP_STRIDE, 0xFF);
+   escape_count.assign(static_cast<size_t>(positions) * n_scan, 0);
+   int layout = 0;
+   for (int other = 1; other < N_LAYOUTS && positions > 0; ++other) {
+      if (reach[static_cast<size_t>(positions - 1) * N_LAYOUTS + other] < reach[static_cast<size_t>(positions - 1) * N_LAYOUTS + layout]) {
+         layout = other;
+      }
+   }
+   for (uint32_t p = positions; p-- > 0;) {
+      uint8_t* map = code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
+      if (layout == IDENTITY) {
+         map[0] = static_cast<uint8_t>(n_bits | LAYOUT_IDENTITY);
+         for (uint32_t code = 1; code < CODE_MAP_STRIDE; ++code) {
+            map[code] = static_cast<uint8_t>(code - 1 < n_scan && code < (1u << n_bits) ? code - 1 : 0xFFu);
+         }
+      } else {
+         const uint32_t coded = layout == TWO_PLANES ? 3 : 7;
+         map[0] = static_cast<uint8_t>(layout == TWO_PLANES ? 2 : 3);
+         uint32_t coded_mask = 0;
+         for (uint32_t code = 1; code <= coded; ++code) {
+            map[code] = best[static_cast<size_t>(p) * 7 + code - 1];
+            if (map[code] != 0xFFu) {
+               coded_mask |= 1u << map[code];
+            }
+         }
+         for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+            if (((coded_mask >> symbol) & 1u) == 0) {
+               escape_count[static_cast<size_t>(p) * n_scan + symbol] = totals[static_cast<size_t>(p) * n_scan + symbol];
+            }
+         }
+      }
+      layout = from[static_cast<size_t>(p) * N_LAYOUTS + layout];
+   }
+}
+
+/// finalize(): derive the adaptive code planes of one sequence store (see chooseLayouts) and release its build-time
 /// planes — or keep those as they are when re-encoding would not pay (short rows), is switched off
 /// (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit next to them.
 int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
@@ -2448,15 +2567,14 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
          HIP_TRY(status_);                                                          \
       }                                                                             \
    } while (0)
-   SILO_LAYOUT_TRY(hipMalloc(&d_code_map, static_cast<size_t>(positions) * CODE_MAP_STRIDE));
+   std::vector<uint32_t> totals(n_counters);
+   SILO_LAYOUT_TRY(hipMemcpy(totals.data(), seqstore.d_totals, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   std::vector<uint8_t> code_map;
+   std::vector<uint32_t> counts;  // escape keys per (position, symbol)
+   chooseLayouts(totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), code_map, counts);
+   SILO_LAYOUT_TRY(hipMalloc(&d_code_map, code_map.size()));
    SILO_LAYOUT_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
-   k_choose_layout<<<(positions + 255) / 256, 256>>>(
-      seqstore.d_totals, dev.n_scan, dev.n_bits, positions, dev.row_words * static_cast<uint32_t>(sizeof(uint64_t)), d_code_map, d_count
-   );
-   std::vector<uint8_t> code_map(static_cast<size_t>(positions) * CODE_MAP_STRIDE);
-   std::vector<uint32_t> counts(n_counters);
-   SILO_LAYOUT_TRY(hipMemcpy(code_map.data(), d_code_map, code_map.size(), hipMemcpyDeviceToHost));
-   SILO_LAYOUT_TRY(hipMemcpy(counts.data(), d_count, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   SILO_LAYOUT_TRY(hipMemcpy(d_code_map, code_map.data(), code_map.size(), hipMemcpyHostToDevice));
    std::vector<uint32_t> row_of(positions + 1, 0);
    std::vector<uint32_t> escape_first(positions + 1, 0);
    std::vector<uint32_t> escape_first_symbol(n_counters + 1, 0);
