@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(EVAL_BATCH_THREADS) void k_filter_eval_batch(
    };
    const auto set = [&](uint32_t index, Word2 value) { slots[index * 64u + lane] = make_ulonglong2(value.x, value.y); };
 
+   // (16 leaf loads in flight and non-temporal leaf loads were tried: +2 % and +1 %, within the noise — profiles/r02_filter_batch.md)
    Word2 result = silo_gpu::bitprog_run<Word2, 8>(code, header.n_instructions, valid, get, set, leaf);
    result = result & valid;
    if (active && header.out != nullptr) {
@@ -3124,27 +3125,29 @@ int silo_gpu_count_slot_wait(silo_gpu_count_slot* slot, uint64_t* out_count, voi
    if (slot == nullptr || out_count == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_count_slot_wait: null argument");
    }
-   // the kernel's last block stores the total with system scope; a launch that never finishes shows up on the stream
-   for (uint64_t spin = 0;; ++spin) {
+   // The kernel's last block stores the total with system scope.  The wait is a pure spin on that word — no HIP call from
+   // the polling threads (round 1 polled hipStreamQuery from every request thread; under rocprofv3's kernel tracing that run
+   // segfaulted, and whether the fault was the profiler's or the polling's was never established, so the polling is gone).
+   // A launch that does not deliver within the spin budget (tens of milliseconds: a failed or wedged launch, or a very busy
+   // device) is waited for with ONE blocking hipStreamSynchronize, which also reports a broken stream.
+   constexpr uint64_t SPIN_BUDGET = uint64_t{1} << 20;
+   for (uint64_t spin = 0; spin < SPIN_BUDGET; ++spin) {
       const unsigned long long value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
       if (value != COUNT_PENDING) {
          *out_count = value;
          return SILO_GPU_OK;
       }
-      if ((spin & 0xFFFFu) == 0xFFFFu) {
-         const hipError_t status = hipStreamQuery(static_cast<hipStream_t>(stream));
-         if (status != hipErrorNotReady) {
-            // the stream is idle (or broken): either the store has just landed or the kernel did not run to its end
-            const unsigned long long final_value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
-            if (status == hipSuccess && final_value != COUNT_PENDING) {
-               *out_count = final_value;
-               return SILO_GPU_OK;
-            }
-            HIP_TRY(status);
-            return fail(SILO_GPU_ERR_HIP, "count slot: the kernel finished without delivering its total");
-         }
-      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
    }
+   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+   const unsigned long long value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
+   if (value == COUNT_PENDING) {
+      return fail(SILO_GPU_ERR_HIP, "count slot: the kernel finished without delivering its total");
+   }
+   *out_count = value;
+   return SILO_GPU_OK;
 }
 
 namespace {

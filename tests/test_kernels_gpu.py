@@ -698,3 +698,36 @@ def test_filter_eval_batch_matches_numpy_and_single_launches(built, n):
         # a bad operand is refused on the host, nothing is launched
         with pytest.raises(b.SiloGpuError):
             store.filter_eval_batch(programs + [(b.encode(b.OP_AND, 0, 5, 6), leaves, 2)])
+
+
+def test_append_from_unaligned_pageable_memory_in_back_to_back_batches(built):
+    """Regression test for the path behind round 1's GPU memory-access fault: silo_gpu_store_append_sequences
+    fed from PAGEABLE host memory at an address that is not even 2-byte aligned, rows of a length that is not a multiple
+    of 4 (so a row's last characters share their 4-byte word with the next row), several batches back to back with
+    boundaries inside a 64-sequence word, null genomes in between — every plane equal to the naive transposition."""
+    rng = np.random.default_rng(99)
+    n, positions = 9_001, 1_003
+    sym = random_symbols(rng, n, positions, "nuc")
+    is_null = (rng.random(n) < 0.03).astype(np.uint8)
+    effective = sym.copy()
+    effective[is_null.astype(bool)] = 15
+    ref = rng.integers(1, 5, size=positions).astype(np.uint8)
+    with make_store(n, [dict(name="main", alphabet="nuc", reference=ref)]) as store:
+        first = 0
+        for size in (1, 63, 1, 2_000, 129, 4_096, 7, 2_704):  # sums to n; none of the boundaries is word aligned
+            backing = np.empty(size * positions + 3, dtype=np.uint8)       # pageable numpy memory
+            chars = backing[3:3 + size * positions].reshape(size, positions)  # ... entered 3 bytes into it
+            chars[:] = NUC_CHARS[sym[first:first + size]]
+            assert chars.ctypes.data % 2 == 1 or chars.ctypes.data % 4 != 0
+            store.append_sequences(0, first, chars, is_null[first:first + size])
+            first += size
+        assert first == n
+        store.finalize()
+        for p in (0, 1, 500, positions - 2, positions - 1):
+            for s in range(16):
+                want = dense.pack_bits(effective[:, p] == s)
+                got = store.plane_download(0, p, s)
+                assert np.array_equal(got[: len(want)], want), (p, s)
+                assert not got[len(want):].any()
+        counts = store.mutations_scan(0, None)
+        assert np.array_equal(counts, dense.mutation_counts(effective, np.ones(n, bool), list(store.scan_symbols[0])))

@@ -26,13 +26,13 @@ simple = b.encode(b.OP_OR_N, 0, imm=0 | (32 << 16))
 
 
 def run(label, pointers, program_code, slots):
-    programs = [(program_code, pointers[32 * q:32 * q + 32], slots) for q in range(q_count)]
-    b.filter_eval_batch(store.handle, programs)
+    programs = b.PreparedPrograms([(program_code, pointers[32 * q:32 * q + 32], slots) for q in range(q_count)])
+    programs.launch(store.handle)
     start, stop = b.GpuEvent(), b.GpuEvent()
     reps = 10
     start.record()
     for _ in range(reps):
-        b.filter_eval_batch(store.handle, programs)
+        programs.launch(store.handle)
     stop.record()
     ms = start.elapsed_ms(stop) / reps
     gb = q_count * 32 * (n + 63) // 64 * 8 / 1e9
@@ -53,7 +53,3 @@ for k in range(q_count * 32):
     single.append(p.value)
 run("one allocation per plane, configs[2] program", single, code, 6)
 run("one allocation per plane, OR_N over 32 leaves", single, simple, 1)
-for value in (16,):
-    lib.silo_gpu_tune(2, value)
-    run(f"one slab, configs[2] program, leaf batch {value}", slab_pointers, code, 6)
-    lib.silo_gpu_tune(2, 0)
