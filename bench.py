@@ -378,11 +378,19 @@ def filter_batch_kernel_time(engine, model, tree, batch, n_sequences, reps=20):
     w8 = 8 * ((n_sequences + 63) // 64)
     bytes_per_launch = len(programs) * 32 * w8
     gbps = bytes_per_launch / (ms * 1e-3) / 1e9
+    traffic, traffic_source = None, None
+    try:  # PMC figure of this launch shape on file (counters cannot be read in-process): labelled with its source, or null
+        entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get("k_filter_eval_batch@64x306")
+        if entry is not None and entry.get("programs") == len(programs) and entry.get("sequences") == n_sequences:
+            traffic = entry["hbm_bytes"]
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE of tools/filter_batch_probe.py, same launch shape; not measured by this run)"
+    except (OSError, ValueError, KeyError):
+        pass
     return {
         "bound": "hbm", "kernel": "k_filter_eval_batch", "programs_per_launch": len(programs),
         "ms_per_launch": ms, "timed": "HIP events around silo_gpu_filter_eval_batch: program-table upload, counter memset, the kernel, count copy and its wait",
         "bytes_per_launch": bytes_per_launch, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-        "traffic": None, "counts_nonzero": sum(1 for c in binding_counts if c > 0),
+        "traffic": traffic, "traffic_source": traffic_source, "counts_nonzero": sum(1 for c in binding_counts if c > 0),
     }
 
 
@@ -538,7 +546,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
     ap.add_argument("--no-client-threads", action="store_true",
-                    help="skip the config-2 filter-query leg (8 client threads): rocprofv3's kernel tracing segfaults inside hipStreamQuery when several host threads poll their streams")
+                    help="skip the config-2 filter-query legs (8 / 16 client threads; > 100 000 launches make a kernel trace large)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing only: every rank uses GPU 0 and the collectives go through gloo — the multi-rank code path of this file "
                          "on a one-GPU box (RCCL refuses two ranks on one device); the numbers mean nothing")
