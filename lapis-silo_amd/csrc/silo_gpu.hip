@@ -2181,6 +2181,64 @@ void releaseSparseScratch(SparseScratch* block, hipStream_t stream) {
 
 
 
+/// Side streams (and the events that tie them to the caller's) per host thread.  The escape pass is a stream of keys, random
+/// filter lookups and atomics — latency-bound — and adds to the same count tables as the plane scans, which are
+/// bandwidth-bound, so it runs beside them.  Never destroyed (thread exit may come after the HIP runtime has shut down).
+constexpr int N_SIDE_STREAMS = 1;  // [0] the escape pass
+struct SideStreams {
+   hipStream_t stream[N_SIDE_STREAMS] = {nullptr};
+   hipEvent_t fork[2] = {nullptr, nullptr};
+   hipEvent_t join[N_SIDE_STREAMS] = {nullptr};
+   bool used[N_SIDE_STREAMS] = {false};
+   bool tried = false;
+   bool ok = false;
+};
+
+SideStreams* sideStreams() {
+   thread_local SideStreams side;
+   if (!side.tried) {
+      side.tried = true;
+      side.ok = true;
+      for (int k = 0; k < N_SIDE_STREAMS; ++k) {
+         side.ok = side.ok && hipStreamCreateWithFlags(&side.stream[k], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&side.join[k], hipEventDisableTiming) == hipSuccess;
+      }
+      for (int k = 0; k < 2; ++k) {
+         side.ok = side.ok && hipEventCreateWithFlags(&side.fork[k], hipEventDisableTiming) == hipSuccess;
+      }
+      if (!side.ok) {
+         (void)hipGetLastError();
+      }
+   }
+   return side.ok ? &side : nullptr;
+}
+
+/// Makes side stream `k` wait for everything queued on `hip_stream` so far (through fork event `fork_index`).
+int forkSide(SideStreams* side, int k, int fork_index, hipStream_t hip_stream, bool record) {
+   if (record) {
+      HIP_TRY(hipEventRecord(side->fork[fork_index], hip_stream));
+   }
+   HIP_TRY(hipStreamWaitEvent(side->stream[k], side->fork[fork_index], 0));
+   side->used[k] = true;
+   return SILO_GPU_OK;
+}
+
+/// Makes `hip_stream` wait for every side stream that was used since the last join.
+int joinSides(hipStream_t hip_stream) {
+   SideStreams* side = sideStreams();
+   if (side == nullptr) {
+      return SILO_GPU_OK;
+   }
+   for (int k = 0; k < N_SIDE_STREAMS; ++k) {
+      if (side->used[k]) {
+         side->used[k] = false;
+         HIP_TRY(hipEventRecord(side->join[k], side->stream[k]));
+         HIP_TRY(hipStreamWaitEvent(hip_stream, side->join[k], 0));
+      }
+   }
+   return SILO_GPU_OK;
+}
+
 /// Fills the piece-dependent part of a launch descriptor from pieces[first, first + n).
 void enterPieces(ScanBatchArgs& batch, const std::vector<ScanPiece>& pieces, size_t first, uint32_t n, uint32_t first_filter, uint32_t n_filters) {
    batch.n_ranges = n;
@@ -2201,6 +2259,8 @@ int scanPiecesDense(
    const std::vector<ScanPiece> (&pieces)[N_SCAN_LAYOUTS], const SeqStoreDev& any_store, const uint64_t* const* filters, uint32_t q_count,
    const uint32_t* sparse_sectors, uint32_t sparse_capacity, hipStream_t hip_stream
 ) {
+   // (running the plane scans of a query's smaller layouts on side streams beside the largest one was tried: no gain, the
+   // launches are bandwidth-bound together — profiles/r02_amino_acid.md)
    for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
       const std::vector<ScanPiece>& list = pieces[layout];
       const uint32_t filters_per_pass = layout == SCAN_2_PLANES || layout == SCAN_FULL_NUCLEOTIDE ? SILO_GPU_MAX_SCAN_BATCH : 4;
@@ -2260,35 +2320,9 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    return SILO_GPU_OK;
 }
 
-/// A second stream (and the two events that tie it to the caller's) per host thread: the escape pass is a stream of keys,
-/// random filter lookups and atomics — latency-bound — and adds to the same count tables as the plane scans, which are
-/// bandwidth-bound, so the two run side by side instead of one after the other.  Never destroyed (thread exit may come
-/// after the HIP runtime has shut down).
-struct SideStream {
-   hipStream_t stream = nullptr;
-   hipEvent_t fork = nullptr;
-   hipEvent_t join = nullptr;
-   bool tried = false;
-};
-
-SideStream* sideStream() {
-   thread_local SideStream side;
-   if (!side.tried) {
-      side.tried = true;
-      if (hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess) {
-         (void)hipGetLastError();
-         side.stream = nullptr;
-      }
-   }
-   return side.stream != nullptr ? &side : nullptr;
-}
-
-/// scanEscapes on the side stream: forked behind everything already queued on `hip_stream` (the filters are complete, the
-/// count tables zeroed), joined by joinEscapes before anything reads the tables.
-int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream, bool& forked) {
-   forked = false;
+/// scanEscapes on side stream 0: forked behind everything already queued on `hip_stream` (the filters are complete, the
+/// count tables zeroed), joined by joinSides before anything reads the tables.
+int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream) {
    bool any = false;
    for (const ScanRange& range : ranges) {
       const SeqStoreHost::Layout& layout = range.seqstore->layout;
@@ -2297,23 +2331,14 @@ int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    if (!any) {
       return SILO_GPU_OK;
    }
-   SideStream* side = sideStream();
+   SideStreams* side = sideStreams();
    if (side == nullptr) {
       return scanEscapes(ranges, filters, q_count, hip_stream);
    }
-   HIP_TRY(hipEventRecord(side->fork, hip_stream));
-   HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-   const int rc = scanEscapes(ranges, filters, q_count, side->stream);
-   HIP_TRY(hipEventRecord(side->join, side->stream));
-   forked = true;
-   return rc;
-}
-
-int joinEscapes(hipStream_t hip_stream, bool forked) {
-   if (forked) {
-      HIP_TRY(hipStreamWaitEvent(hip_stream, sideStream()->join, 0));
+   if (const int rc = forkSide(side, 0, 0, hip_stream, true); rc != SILO_GPU_OK) {
+      return rc;
    }
-   return SILO_GPU_OK;
+   return scanEscapes(ranges, filters, q_count, side->stream[0]);
 }
 
 /// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores of one alphabet, with the
@@ -2351,21 +2376,20 @@ int scanRanges(
    std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
    cutIntoPieces(ranges, q_count, pieces);
    const int divisor = g_tune_sparse_divisor.load();
-   bool forked = false;
-   if (const int rc = forkEscapes(ranges, filters, q_count, hip_stream, forked); rc != SILO_GPU_OK) {
-      (void)joinEscapes(hip_stream, forked);
+   if (const int rc = forkEscapes(ranges, filters, q_count, hip_stream); rc != SILO_GPU_OK) {
+      (void)joinSides(hip_stream);
       return rc;
    }
    if (divisor < 0) {
       const int rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
-      const int joined = joinEscapes(hip_stream, forked);
+      const int joined = joinSides(hip_stream);
       return rc != SILO_GPU_OK ? rc : joined;
    }
    const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
    const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
    if (acquired != SILO_GPU_OK) {
-      (void)joinEscapes(hip_stream, forked);
+      (void)joinSides(hip_stream);
       return acquired;
    }
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
@@ -2402,8 +2426,8 @@ int scanRanges(
          }
       }
    }
+   const int joined = joinSides(hip_stream);  // before the scratch is released: side-stream scans read its counters
    releaseSparseScratch(scratch, hip_stream);
-   const int joined = joinEscapes(hip_stream, forked);
    return rc != SILO_GPU_OK ? rc : joined;
 }
 
@@ -3264,7 +3288,6 @@ struct EvalBatchScratch {
    uint8_t* host_table = nullptr;
    uint8_t* device_table = nullptr;
    size_t table_capacity = 0;
-   uint32_t* device_counts = nullptr;
    uint32_t* host_counts = nullptr;
    size_t counts_capacity = 0;  // programs
 };
@@ -3298,6 +3321,11 @@ int silo_gpu_filter_eval_batch(
    for (uint32_t q = 0; q < n_programs; ++q) {
       table_bytes += align16(static_cast<size_t>(programs[q].n_instructions) * 2 * sizeof(uint32_t)) + align16(static_cast<size_t>(programs[q].n_leaves) * sizeof(uint64_t*));
    }
+   // the count shards travel at the end of the table: the upload that brings the programs also zeroes them (no memset
+   // launch), and their device copy is read back from the same allocation
+   const size_t counts_bytes = static_cast<size_t>(n_programs) * EVAL_BATCH_SHARDS * sizeof(uint32_t);
+   const size_t counts_offset = table_bytes;
+   table_bytes += align16(counts_bytes);
    thread_local EvalBatchScratch scratch;
    if (table_bytes > scratch.table_capacity) {
       if (scratch.host_table != nullptr) {
@@ -3315,16 +3343,14 @@ int silo_gpu_filter_eval_batch(
    if (n_programs > scratch.counts_capacity) {
       if (scratch.host_counts != nullptr) {
          (void)hipHostFree(scratch.host_counts);
-         (void)hipFree(scratch.device_counts);
          scratch.host_counts = nullptr;
-         scratch.device_counts = nullptr;
          scratch.counts_capacity = 0;
       }
       const size_t capacity = std::max<size_t>(static_cast<size_t>(n_programs) * 2, 128);
       HIP_TRY(hipHostMalloc(&scratch.host_counts, capacity * EVAL_BATCH_SHARDS * sizeof(uint32_t), hipHostMallocDefault));
-      HIP_TRY(hipMalloc(&scratch.device_counts, capacity * EVAL_BATCH_SHARDS * sizeof(uint32_t)));
       scratch.counts_capacity = capacity;
    }
+   memset(scratch.host_table + counts_offset, 0, counts_bytes);
    auto* headers = reinterpret_cast<BatchProgramHeader*>(scratch.host_table);
    size_t cursor = align16(static_cast<size_t>(n_programs) * sizeof(BatchProgramHeader));
    for (uint32_t slot = 0; slot < n_programs; ++slot) {  // table slot `slot` holds program order[slot]
@@ -3344,9 +3370,8 @@ int silo_gpu_filter_eval_batch(
       header.reserved = 0;
    }
    auto hip_stream = static_cast<hipStream_t>(stream);
-   const size_t counts_bytes = static_cast<size_t>(n_programs) * EVAL_BATCH_SHARDS * sizeof(uint32_t);
    HIP_TRY(hipMemcpyAsync(scratch.device_table, scratch.host_table, table_bytes, hipMemcpyHostToDevice, hip_stream));
-   HIP_TRY(hipMemsetAsync(scratch.device_counts, 0, counts_bytes, hip_stream));
+   uint32_t* device_counts = reinterpret_cast<uint32_t*>(scratch.device_table + counts_offset);
    static std::once_flag lds_once;
    std::call_once(lds_once, [] {
       // 4 waves x up to 32 slots x 1 KiB: beyond the 64 KiB a kernel may ask for by default
@@ -3366,12 +3391,12 @@ int silo_gpu_filter_eval_batch(
       }
       const size_t lds_bytes = static_cast<size_t>(EVAL_BATCH_THREADS / 64) * max_slots * 64 * sizeof(ulonglong2);
       k_filter_eval_batch<<<dim3(last - first, tiles), EVAL_BATCH_THREADS, lds_bytes, hip_stream>>>(
-         scratch.device_table, first, store->sequence_count, store->row_words, max_slots, scratch.device_counts
+         scratch.device_table, first, store->sequence_count, store->row_words, max_slots, device_counts
       );
       HIP_TRY(hipGetLastError());
       first = last;
    }
-   HIP_TRY(hipMemcpyAsync(scratch.host_counts, scratch.device_counts, counts_bytes, hipMemcpyDeviceToHost, hip_stream));
+   HIP_TRY(hipMemcpyAsync(scratch.host_counts, device_counts, counts_bytes, hipMemcpyDeviceToHost, hip_stream));
    HIP_TRY(hipStreamSynchronize(hip_stream));
    if (out_counts != nullptr) {
       for (uint32_t slot = 0; slot < n_programs; ++slot) {

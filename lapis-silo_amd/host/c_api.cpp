@@ -415,8 +415,9 @@ int silo_engine_evaluate_filter(
          throw silo::QueryParseException("The query was not a valid JSON: " + std::string(ex.what()));
       }
       // Expression::compile + Operator::evaluate for this partition, query_engine.cpp:40-49
-      const silo::query_engine::OperatorResult result =
-         expression->compile(engine->database, database_partition, silo::query_engine::filter_expressions::Expression::AmbiguityMode::NONE)->evaluate();
+      const silo::query_engine::OperatorResult result = silo::query_engine::operators::Operator::evaluate(
+         expression->compile(engine->database, database_partition, silo::query_engine::filter_expressions::Expression::AmbiguityMode::NONE)
+      );
       if (out_bitset != nullptr) {
          std::memset(out_bitset, 0, n_words * sizeof(uint64_t));
          silo::checkGpu(

@@ -305,6 +305,11 @@ OperatorResult Operator::evaluate() const {
    return OperatorResult(rows, copy());
 }
 
+OperatorResult Operator::evaluate(std::unique_ptr<Operator> root) {
+   const RowSpace rows = root->rows;
+   return OperatorResult(rows, std::move(root));
+}
+
 namespace {
 
 OperatorVector copyAll(const OperatorVector& source) {

@@ -42,7 +42,7 @@ std::vector<OperatorResult> compileFilter(const Database& database, const filter
    std::vector<OperatorResult> per_partition;
    per_partition.reserve(database.partitions.size());
    for (const DatabasePartition& partition : database.partitions) {
-      per_partition.push_back(filter.compile(database, partition, filter_expressions::Expression::AmbiguityMode::NONE)->evaluate());
+      per_partition.push_back(operators::Operator::evaluate(filter.compile(database, partition, filter_expressions::Expression::AmbiguityMode::NONE)));
    }
    return per_partition;
 }

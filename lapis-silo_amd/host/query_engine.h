@@ -163,6 +163,8 @@ class Operator {
 
    [[nodiscard]] virtual Type type() const = 0;
    virtual OperatorResult evaluate() const;
+   /// The same for a tree nobody else needs any more: the result takes the tree over instead of copying it.
+   static OperatorResult evaluate(std::unique_ptr<Operator> root);
    virtual std::string toString() const = 0;
    virtual std::unique_ptr<Operator> copy() const = 0;
    virtual std::unique_ptr<Operator> negate() const = 0;
