@@ -286,10 +286,9 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
     batch_seconds = (time.perf_counter() - t0) / reps
     batch_counts = [json.loads(body.decode())["queryResult"][0]["count"] for _, body in one_by_one]
 
-    # the same with several request threads (the box's CPU share, at most 16), each submitting such batches on its own
-    # stream: host-side parsing and compilation (the larger part of a batch's wall time) run in parallel, the launches
-    # overlap on the device
-    n_clients = max(2, min(16, cpu_share()))
+    # the same with 8 request threads, each submitting such batches on its own stream: the host work of one client's batch
+    # (parse and compile, spread over the engine's batch workers) overlaps the launches of the others
+    n_clients = max(2, min(8, cpu_share()))
     batches_done = []
 
     def batch_client():

@@ -89,6 +89,28 @@ int silo_gpu_store_append_sequences(
    const char* chars, const uint8_t* is_null
 );
 
+/* ---- import from the reference's own storage form (the roaring payloads of a snapshot) ---------------
+ * A reference Position (position.h:27-37) is one roaring bitmap per symbol — written by saveDatabaseState in CRoaring's
+ * portable serialization (roaring_serialize.h:17-45) — with the most numerous symbol stored FLIPPED (its complement) or
+ * DELETED (empty; position.cpp:42-127), and the missing symbol kept ROW-wise (missing_symbol_bitmaps[row] = the positions
+ * where the row has N / X, sequence_store.cpp:153-190).  silo_gpu_store_import_missing_rows first (the deleted symbol of a
+ * position is "no other symbol and not missing"), then silo_gpu_store_import_position per position; finalize as usual.
+ * The containers are expanded on the device.  The Boost archive framing around the payloads is the caller's to strip: it is
+ * not read here (nothing in this image to pin it against), and the portable format itself is restated from its published
+ * specification — parity unpinned.  SILO_GPU_SYMBOL_NONE = no flipped / deleted symbol. */
+typedef struct silo_gpu_roaring_payload {
+   uint32_t symbol;    /* reference enum value; ignored by silo_gpu_store_import_missing_rows */
+   const void* bytes;  /* portable-format roaring bitmap, host memory */
+   size_t n_bytes;
+} silo_gpu_roaring_payload;
+int silo_gpu_store_import_missing_rows(
+   silo_gpu_store* store, uint32_t seqstore_id, uint32_t first_sequence, uint32_t n_sequences, const silo_gpu_roaring_payload* rows
+);
+int silo_gpu_store_import_position(
+   silo_gpu_store* store, uint32_t seqstore_id, uint32_t position, const silo_gpu_roaring_payload* bitmaps, uint32_t n_bitmaps,
+   uint32_t flipped_symbol, uint32_t deleted_symbol
+);
+
 /* Sorts the sparse triples gathered by append/generate; call once after the last append and
  * before any query.  (The reference's optimizeBitmaps, sequence_store.cpp:192-211, has no dense
  * analogue: flipped/deleted bitmaps are storage tricks) */

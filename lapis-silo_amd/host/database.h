@@ -19,6 +19,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <optional>
 #include <string>
 #include <unordered_map>
@@ -259,12 +260,19 @@ class DatabasePartition {
    /// Materialised bitsets of sparsely stored symbols (IUPAC ambiguity codes), keyed by
    /// seqstore << 40 | local position << 8 | symbol; filled on first use by ProgramBuilder::sparseLeaf.
    static constexpr size_t SPARSE_CACHE_BYTES = size_t{32} << 30;
-   mutable std::mutex sparse_cache_mutex;
+   /// readers (every filter leaf of every query looks its plane up here) share the lock; only the first use of a plane writes
+   mutable std::shared_mutex sparse_cache_mutex;
    mutable std::map<uint64_t, DeviceBuffer> sparse_cache;
    /// Row bitsets of the values of INDEXED string columns, built on first use (the reference builds one roaring bitmap
    /// per value at insert time, indexed_string_column.cpp:24-36); same mutex, own budget.
    static constexpr size_t INDEXED_VALUE_CACHE_BYTES = size_t{1} << 30;
    mutable std::map<std::pair<const storage::column::MetadataColumnPartition*, uint32_t>, DeviceBuffer> indexed_value_cache;
+
+   /// Cardinalities of stored row bitsets (lineage sets, missing-symbol planes, derived planes) by device address: stored
+   /// bitmaps never change once the database is finalized, and roaring keeps a bitmap's cardinality at hand
+   /// (mutations.cpp:45 reads it for free) — a filter that IS a stored bitmap costs no popcount launch and no copy here either.
+   mutable std::shared_mutex cardinality_cache_mutex;
+   mutable std::unordered_map<const uint64_t*, uint32_t> cardinality_cache;
 
    [[nodiscard]] uint32_t rowWords() const { return silo_gpu_store_row_words(store); }
 

@@ -370,7 +370,7 @@ std::unique_ptr<Operator> cachedUpperBoundPlane(
    const uint64_t key = (uint64_t{1} << 63) | (static_cast<uint64_t>(seqstore_id) << 40) | (static_cast<uint64_t>(position) << 8) | symbol;
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
    {
-      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const std::shared_lock<std::shared_mutex> lock(partition.sparse_cache_mutex);
       const auto found = partition.sparse_cache.find(key);
       if (found != partition.sparse_cache.end()) {  // the usual case: no expansion is even built
          return std::make_unique<operators::IndexScan>(found->second.as<uint64_t>(), rows);
@@ -381,7 +381,7 @@ std::unique_ptr<Operator> cachedUpperBoundPlane(
       return expanded;  // there is nothing to combine
    }
    {
-      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const std::shared_lock<std::shared_mutex> lock(partition.sparse_cache_mutex);
       if ((partition.sparse_cache.size() + 1) * row_bytes > DatabasePartition::SPARSE_CACHE_BYTES) {
          return expanded;
       }
@@ -396,7 +396,7 @@ std::unique_ptr<Operator> cachedUpperBoundPlane(
    checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");
    const uint64_t* pointer = buffer.as<uint64_t>();
    {
-      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const std::unique_lock<std::shared_mutex> lock(partition.sparse_cache_mutex);
       const auto [entry, inserted] = partition.sparse_cache.try_emplace(key, std::move(buffer));
       pointer = entry->second.as<uint64_t>();  // another thread may have been first: use its plane, ours returns to the pool
    }
@@ -620,7 +620,7 @@ std::unique_ptr<Operator> StringEquals::compile(
       const size_t row_bytes = static_cast<size_t>(database_partition.rowWords()) * sizeof(uint64_t);
       bool room = false;
       {
-         const std::lock_guard<std::mutex> lock(database_partition.sparse_cache_mutex);
+         const std::shared_lock<std::shared_mutex> lock(database_partition.sparse_cache_mutex);
          const auto found = database_partition.indexed_value_cache.find(key);
          if (found != database_partition.indexed_value_cache.end()) {
             return std::make_unique<operators::IndexScan>(found->second.as<uint64_t>(), rows);
@@ -637,7 +637,7 @@ std::unique_ptr<Operator> StringEquals::compile(
             "silo_gpu_bitset_from_compare"
          );
          checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");  // other streams may read it at once
-         const std::lock_guard<std::mutex> lock(database_partition.sparse_cache_mutex);
+         const std::unique_lock<std::shared_mutex> lock(database_partition.sparse_cache_mutex);
          const auto [entry, inserted] = database_partition.indexed_value_cache.try_emplace(key, std::move(buffer));
          return std::make_unique<operators::IndexScan>(entry->second.as<uint64_t>(), rows);
       }

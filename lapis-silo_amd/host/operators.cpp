@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <bit>
 #include <mutex>
+#include <shared_mutex>
 
 #include "query_engine.h"
 
@@ -62,10 +63,24 @@ void OperatorResult::materialize() const {
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
    const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
    if (scan != nullptr && !scan->sparse) {
-      DeviceBuffer counter = zeroedCounter(partition);
       state->borrowed = scan->bitmap;  // index_scan.cpp:28-30: borrow, no copy
+      if (scan->received == nullptr) {  // a stored bitmap (not a plane received from another rank): its cardinality is kept
+         const std::shared_lock<std::shared_mutex> lock(partition.cardinality_cache_mutex);
+         const auto known = partition.cardinality_cache.find(scan->bitmap);
+         if (known != partition.cardinality_cache.end()) {
+            state->count = known->second;
+            return;
+         }
+      }
+      DeviceBuffer counter = zeroedCounter(partition);
       checkGpu(silo_gpu_popcount(partition.store, scan->bitmap, counter.as<uint64_t>(), queryStream()), "silo_gpu_popcount");
       state->count = readCount(counter);
+      if (scan->received == nullptr) {
+         const std::unique_lock<std::shared_mutex> lock(partition.cardinality_cache_mutex);
+         if (partition.cardinality_cache.size() < (size_t{1} << 20)) {
+            partition.cardinality_cache.emplace(scan->bitmap, *state->count);
+         }
+      }
    } else {
       DeviceBuffer out = partition.pool.acquire(row_bytes);
       ProgramBuilder builder(state->rows);
@@ -90,9 +105,26 @@ uint32_t OperatorResult::cardinality() const {
          state->count = state->rows.row_count;
          return *state->count;
       }
+      const auto* scan = state->root->type() == operators::INDEX_SCAN ? dynamic_cast<const operators::IndexScan*>(state->root.get()) : nullptr;
+      const bool stored = scan != nullptr && !scan->sparse && scan->received == nullptr;
+      const DatabasePartition& partition = *state->rows.partition;
+      if (stored) {  // the kept cardinality of a stored bitmap (see DatabasePartition::cardinality_cache)
+         const std::shared_lock<std::shared_mutex> lock(partition.cardinality_cache_mutex);
+         const auto known = partition.cardinality_cache.find(scan->bitmap);
+         if (known != partition.cardinality_cache.end()) {
+            state->count = known->second;
+            return *state->count;
+         }
+      }
       ProgramBuilder builder(state->rows);
       const uint32_t slot = state->root->lower(builder);
       state->count = builder.runCounting(slot, nullptr, queryStream());
+      if (stored) {
+         const std::unique_lock<std::shared_mutex> lock(partition.cardinality_cache_mutex);
+         if (partition.cardinality_cache.size() < (size_t{1} << 20)) {
+            partition.cardinality_cache.emplace(scan->bitmap, *state->count);
+         }
+      }
       return *state->count;
    }
 }
@@ -200,7 +232,7 @@ const uint64_t* ProgramBuilder::sparsePointer(uint32_t seqstore_id, uint32_t pos
    const size_t row_bytes = static_cast<size_t>(partition.rowWords()) * sizeof(uint64_t);
    const uint64_t key = (static_cast<uint64_t>(seqstore_id) << 40) | (static_cast<uint64_t>(position) << 8) | symbol;
    {
-      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const std::shared_lock<std::shared_mutex> lock(partition.sparse_cache_mutex);
       const auto found = partition.sparse_cache.find(key);
       if (found != partition.sparse_cache.end()) {
          return found->second.as<uint64_t>();
@@ -215,7 +247,7 @@ const uint64_t* ProgramBuilder::sparsePointer(uint32_t seqstore_id, uint32_t pos
    // other threads (on their own streams) may pick the plane up from the cache at once: finish it first
    checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");
    {
-      const std::lock_guard<std::mutex> lock(partition.sparse_cache_mutex);
+      const std::unique_lock<std::shared_mutex> lock(partition.sparse_cache_mutex);
       if ((partition.sparse_cache.size() + 1) * row_bytes <= DatabasePartition::SPARSE_CACHE_BYTES &&
           partition.sparse_cache.find(key) == partition.sparse_cache.end()) {
          partition.sparse_cache.emplace(key, std::move(buffer));

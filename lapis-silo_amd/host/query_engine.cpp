@@ -2,7 +2,13 @@
 // Reference: src/silo/query_engine/{query,query_engine,query_result}.cpp.
 #include "query_engine.h"
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace silo::query_engine {
 
@@ -47,6 +53,97 @@ std::vector<OperatorResult> compileFilter(const Database& database, const filter
    return per_partition;
 }
 
+
+/// A few worker threads for the host side of a batch: parsing and compiling its queries are independent of each other
+/// (≈ 20 µs each for a 32-leaf filter, against 7 µs of device time per query in a multi-program launch), so a batch of 64
+/// would otherwise spend three times as long on the host as on the device.  The workers only parse and compile — anything
+/// that records into the calling thread's ScanBatcher stays on the calling thread.  Never joined (process exit may come
+/// after the runtime libraries have shut down); idle workers sleep on a condition variable.
+class BatchWorkers {
+  public:
+   static BatchWorkers& instance() {
+      static BatchWorkers* workers = new BatchWorkers();  // intentionally leaked
+      return *workers;
+   }
+
+   /// Runs task(i) for i in [0, n) on the workers and the calling thread; returns when all are done.
+   template <typename Task>
+   void run(size_t n, Task&& task) {
+      if (n < 4 || threads.empty()) {
+         for (size_t i = 0; i < n; ++i) {
+            task(i);
+         }
+         return;
+      }
+      Job job;
+      job.n = n;
+      job.task = [&task](size_t i) { task(i); };
+      {
+         const std::lock_guard<std::mutex> lock(mutex);
+         jobs.push_back(&job);
+      }
+      wake.notify_all();
+      work(job);  // the caller takes its share
+      std::unique_lock<std::mutex> lock(mutex);
+      jobs.erase(std::remove(jobs.begin(), jobs.end(), &job), jobs.end());
+      done.wait(lock, [&job] { return job.finished.load() == job.n && job.active.load() == 0; });
+   }
+
+  private:
+   struct Job {
+      size_t n = 0;
+      std::function<void(size_t)> task;
+      std::atomic<size_t> next{0};
+      std::atomic<size_t> finished{0};
+      std::atomic<int> active{0};  // workers currently inside work(job)
+   };
+
+   BatchWorkers() {
+      const unsigned hardware = std::thread::hardware_concurrency();
+      const unsigned count = std::min(7u, hardware > 2 ? hardware / 2 - 1 : 0u);
+      for (unsigned k = 0; k < count; ++k) {
+         threads.emplace_back([this] { loop(); });
+         threads.back().detach();
+      }
+   }
+
+   void work(Job& job) {
+      for (size_t i = job.next.fetch_add(1); i < job.n; i = job.next.fetch_add(1)) {
+         job.task(i);  // tasks catch their own exceptions
+         job.finished.fetch_add(1);
+      }
+   }
+
+   void loop() {
+      std::unique_lock<std::mutex> lock(mutex);
+      while (true) {
+         Job* job = nullptr;
+         for (Job* candidate : jobs) {
+            if (candidate->next.load() < candidate->n) {
+               job = candidate;
+               break;
+            }
+         }
+         if (job == nullptr) {
+            wake.wait(lock);
+            continue;
+         }
+         job->active.fetch_add(1);
+         lock.unlock();
+         work(*job);
+         lock.lock();
+         job->active.fetch_sub(1);
+         done.notify_all();
+      }
+   }
+
+   std::mutex mutex;
+   std::condition_variable wake;
+   std::condition_variable done;
+   std::vector<Job*> jobs;
+   std::vector<std::thread> threads;
+};
+
 }  // namespace
 
 QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  // query_engine.cpp:30-68
@@ -69,53 +166,75 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
    std::vector<std::unique_ptr<Query>> parsed(queries.size());
    std::vector<std::unique_ptr<actions::Action::Pending>> pending(queries.size());
    actions::ScanBatcher batcher;  // active on this thread until the end of the function
-   for (size_t i = 0; i < queries.size(); ++i) {  // phase 1: parse, compile, evaluate filters, queue scans
-      const actions::ScanBatcher::Checkpoint mark = batcher.checkpoint();
-      try {
-         parsed[i] = std::make_unique<Query>(queries[i]);
-         pending[i] = parsed[i]->action->begin(database, compileFilter(database, *parsed[i]->filter));
-      } catch (...) {
-         batcher.rollback(mark);  // scans recorded by the failed query point into buffers that are gone
-         outcomes[i].error = std::current_exception();
-      }
-   }
-   Trace::mark("batch_compiled");
-   // The filter -> count queries of the batch (Aggregated without groupByFields): every filter program of a partition
-   // in ONE launch (K3b) instead of one latency-bound launch per query.
+   // phase 1a: parse and compile — and, for the filter -> count queries (Aggregated without groupByFields), lower the filter
+   // to its bit-program — queries side by side on the batch workers
    struct CountJob {
-      size_t query;
       size_t partition;
+      OperatorResult filter;                    // shares its state with the copy the action holds
       std::unique_ptr<ProgramBuilder> builder;  // owns the code and leaf arrays the program points into
       silo_gpu_bitprog program;
    };
-   std::vector<CountJob> jobs;
-   for (size_t i = 0; i < queries.size(); ++i) {
-      if (outcomes[i].error != nullptr || !parsed[i]->action->countsOnly()) {
-         continue;
-      }
-      const size_t first_job = jobs.size();
+   std::vector<std::vector<OperatorResult>> filters(queries.size());
+   std::vector<std::vector<CountJob>> count_jobs(queries.size());
+   const auto parseAndCompile = [&](size_t i) {
       try {
-         for (size_t partition_index = 0; partition_index < pending[i]->bitmap_filter.size(); ++partition_index) {
-            const OperatorResult& filter = pending[i]->bitmap_filter[partition_index];
-            CountJob job{i, partition_index, std::make_unique<ProgramBuilder>(filter.rows()), {}};
-            if (filter.prepareCount(*job.builder, job.program)) {
-               jobs.push_back(std::move(job));
+         parsed[i] = std::make_unique<Query>(queries[i]);
+         filters[i] = compileFilter(database, *parsed[i]->filter);
+         if (parsed[i]->action->countsOnly()) {
+            for (size_t partition_index = 0; partition_index < filters[i].size(); ++partition_index) {
+               CountJob job{partition_index, filters[i][partition_index], std::make_unique<ProgramBuilder>(filters[i][partition_index].rows()), {}};
+               if (job.filter.prepareCount(*job.builder, job.program)) {
+                  if (job.builder->queuedDeviceWork()) {  // the program is launched from the batch's stream, not this thread's
+                     checkGpu(silo_gpu_stream_synchronize(queryStream()), "silo_gpu_stream_synchronize");
+                  }
+                  count_jobs[i].push_back(std::move(job));
+               }
             }
          }
       } catch (...) {
-         jobs.resize(first_job);
+         count_jobs[i].clear();
          outcomes[i].error = std::current_exception();
+      }
+   };
+   if (database.broadcast != nullptr) {
+      // position-range shards fetch filter leaves from other ranks WHILE compiling: those collectives must be issued in the
+      // same order on every rank, so the queries are compiled one after the other
+      for (size_t i = 0; i < queries.size(); ++i) {
+         parseAndCompile(i);
+      }
+   } else {
+      BatchWorkers::instance().run(queries.size(), parseAndCompile);
+   }
+   Trace::mark("batch_compiled");
+   for (size_t i = 0; i < queries.size(); ++i) {  // phase 1b: validate the actions, queue their scans (this thread's batcher)
+      if (outcomes[i].error != nullptr) {
+         continue;
+      }
+      const actions::ScanBatcher::Checkpoint mark = batcher.checkpoint();
+      try {
+         pending[i] = parsed[i]->action->begin(database, std::move(filters[i]));
+      } catch (...) {
+         batcher.rollback(mark);  // scans recorded by the failed query point into buffers that are gone
+         count_jobs[i].clear();
+         outcomes[i].error = std::current_exception();
+      }
+   }
+   // every filter program of a partition in ONE launch (K3b) instead of one latency-bound launch per query
+   std::vector<CountJob*> jobs;
+   for (std::vector<CountJob>& of_query : count_jobs) {
+      for (CountJob& job : of_query) {
+         jobs.push_back(&job);
       }
    }
    Trace::mark("batch_lowered");
    if (jobs.size() > 1) {
       for (size_t partition_index = 0; partition_index < database.partitions.size(); ++partition_index) {
          std::vector<silo_gpu_bitprog> programs;
-         std::vector<const CountJob*> members;
-         for (const CountJob& job : jobs) {
-            if (job.partition == partition_index) {
-               programs.push_back(job.program);
-               members.push_back(&job);
+         std::vector<CountJob*> members;
+         for (CountJob* job : jobs) {
+            if (job->partition == partition_index) {
+               programs.push_back(job->program);
+               members.push_back(job);
             }
          }
          if (programs.empty()) {
@@ -129,11 +248,11 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
             "silo_gpu_filter_eval_batch"
          );
          for (size_t k = 0; k < members.size(); ++k) {
-            pending[members[k]->query]->bitmap_filter[partition_index].setCount(static_cast<uint32_t>(counts[k]));
+            members[k]->filter.setCount(static_cast<uint32_t>(counts[k]));
          }
       }
    }
-   jobs.clear();  // a single job takes the ordinary path in finish(): one launch with the count slot
+   count_jobs.clear();  // a single job takes the ordinary path in finish(): one launch with the count slot
    Trace::mark("batch_queued");
    batcher.flush();  // the scans of all queries, several filters per pass over the planes
    Trace::mark("batch_launched");

@@ -131,6 +131,9 @@ class ProgramBuilder {
    /// thread's count slot (no counter memset, no device-to-host copy, no stream synchronisation).
    uint32_t runCounting(uint32_t result_slot, uint64_t* out_bitset, void* stream);
 
+   /// Lowering queued device work of its own on the lowering thread's stream (metadata predicates, insertion searches
+   /// write temporary bitsets): a program that is launched from ANOTHER stream has to wait for that work first.
+   [[nodiscard]] bool queuedDeviceWork() const { return !temporaries.empty(); }
    /// The finished program (result expected in `result_slot`); points into this builder, which must outlive its use.
    silo_gpu_bitprog finishProgram(uint32_t result_slot);
 

@@ -64,6 +64,10 @@ class SynthDesc(ctypes.Structure):
     ]
 
 
+class RoaringPayload(ctypes.Structure):
+    _fields_ = [("symbol", ctypes.c_uint32), ("bytes", ctypes.c_char_p), ("n_bytes", ctypes.c_size_t)]
+
+
 class BitProg(ctypes.Structure):
     _fields_ = [
         ("n_instructions", ctypes.c_uint32),
@@ -82,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",
     "silo_gpu_bitset_from_value_ids", "silo_gpu_free",
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
-    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes", "silo_gpu_store_scan_rows", "silo_gpu_store_finalize_seqstore",
+    "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes", "silo_gpu_store_scan_rows", "silo_gpu_store_finalize_seqstore", "silo_gpu_store_import_position", "silo_gpu_store_import_missing_rows",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
     "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_last_error",
     "silo_gpu_comm_unique_id", "silo_gpu_comm_create", "silo_gpu_comm_destroy", "silo_gpu_comm_rank", "silo_gpu_comm_world",
@@ -163,6 +167,9 @@ def load_library():
     lib.silo_gpu_store_scan_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.silo_gpu_store_scan_rows.restype = ctypes.c_uint64
     lib.silo_gpu_store_finalize_seqstore.argtypes = [vp, ctypes.c_uint32]
+    lib.silo_gpu_store_import_position.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(RoaringPayload), ctypes.c_uint32, ctypes.c_uint32,
+                                                   ctypes.c_uint32]
+    lib.silo_gpu_store_import_missing_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(RoaringPayload)]
     lib.silo_gpu_filter_eval_batch.argtypes = [vp, ctypes.POINTER(BitProg), ctypes.c_uint32, ctypes.POINTER(vp), c_u64p, vp]
     lib.silo_gpu_comm_unique_id.argtypes = [vp]
     lib.silo_gpu_comm_create.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp)]
@@ -276,6 +283,23 @@ class PreparedPrograms:
     def launch(self, store_handle, stream=None):
         _check(load_library().silo_gpu_filter_eval_batch(store_handle, self.array, self.n, self.outs, self.counts.ctypes.data_as(c_u64p), stream))
         return [int(c) for c in self.counts[:self.n]]
+
+
+SYMBOL_NONE = 0xFF
+
+
+def import_position(store_handle, seqstore_id, position, payloads, flipped=None, deleted=None):
+    """silo_gpu_store_import_position: payloads = {symbol id: portable-format roaring bytes} of one reference Position."""
+    items = sorted(payloads.items())
+    array = (RoaringPayload * max(1, len(items)))(*[RoaringPayload(symbol, data, len(data)) for symbol, data in items])
+    _check(load_library().silo_gpu_store_import_position(
+        store_handle, seqstore_id, position, array, len(items), SYMBOL_NONE if flipped is None else flipped, SYMBOL_NONE if deleted is None else deleted))
+
+
+def import_missing_rows(store_handle, seqstore_id, first_sequence, payloads):
+    """silo_gpu_store_import_missing_rows: payloads[r] = portable-format roaring bytes of the POSITIONS where row first_sequence + r is missing."""
+    array = (RoaringPayload * max(1, len(payloads)))(*[RoaringPayload(0, data, len(data)) for data in payloads])
+    _check(load_library().silo_gpu_store_import_missing_rows(store_handle, seqstore_id, first_sequence, len(payloads), array))
 
 
 def filter_eval_batch(store_handle, programs, out_bitsets=None, stream=None):

@@ -53,3 +53,34 @@ for k in range(q_count * 32):
     single.append(p.value)
 run("one allocation per plane, configs[2] program", single, code, 6)
 run("one allocation per plane, OR_N over 32 leaves", single, simple, 1)
+
+# aggregate rate of the bare C call from several host threads (each its own stream and its own disjoint programs)
+import threading
+import time
+
+streams = []
+for _ in range(8):
+    stream = ctypes.c_void_p()
+    b._check(lib.silo_gpu_stream_create(ctypes.byref(stream)))
+    streams.append(stream)
+for n_threads in (1, 2, 4, 8):
+    prepared = [b.PreparedPrograms([(code, slab_pointers[32 * q:32 * q + 32], 6) for q in range(q_count)]) for _ in range(n_threads)]
+    done = []
+
+    def worker(k):
+        count = 0
+        end = time.perf_counter() + 1.0
+        while time.perf_counter() < end:
+            prepared[k].launch(store.handle, streams[k])
+            count += 1
+        done.append(count)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    seconds = time.perf_counter() - t0
+    gb = sum(done) * q_count * 32 * ((n + 63) // 64 * 8) / 1e9
+    print(f"{n_threads} host threads: {sum(done) / seconds:7.0f} launches/s, {sum(done) * q_count / seconds:9.0f} programs/s, {gb / seconds:6.0f} GB/s", flush=True)

@@ -24,3 +24,24 @@ t0 = time.perf_counter()
 for wire in batch:
     engine.execute_text(wire)
 print(f"one by one: {(time.perf_counter() - t0) * 1e6 / q:.1f} us per query;", json.dumps(engine.last_trace()))
+
+import threading
+
+for clients in (1, 2, 4, 8, 16):
+    done = []
+
+    def client():
+        k = 0
+        end = time.perf_counter() + 1.0
+        while time.perf_counter() < end:
+            engine.execute_batch_text(batch)
+            k += 1
+        done.append(k)
+
+    threads = [threading.Thread(target=client) for _ in range(clients)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    print(f"{clients:2d} client threads x batches of {q}: {sum(done) * q / (time.perf_counter() - t0):9.0f} queries/s", flush=True)
