@@ -166,6 +166,10 @@ int silo_gpu_stream_synchronize(void* stream);
 /* A non-blocking HIP stream (does not synchronise with the null stream); every `void* stream` parameter of
  * this ABI accepts one, or NULL for the null stream. */
 int silo_gpu_stream_create(void** out_stream);
+/* Selects the HIP device of the CALLING host thread (HIP keeps the current device per thread, starting at 0): a thread that
+ * creates streams, events or buffers for a store on device r selects r first.  Entry points that take a store select its
+ * device themselves. */
+int silo_gpu_set_device(int device);
 void silo_gpu_stream_destroy(void* stream);
 
 /* Device pointer of the one-hot plane of (seqstore, position, symbol) when the store holds one: the extra symbols

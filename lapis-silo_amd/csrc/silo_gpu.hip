@@ -2905,6 +2905,11 @@ void silo_gpu_event_destroy(void* event) {
    (void)hipEventDestroy(static_cast<hipEvent_t>(event));
 }
 
+int silo_gpu_set_device(int device) {
+   HIP_TRY(hipSetDevice(device));
+   return SILO_GPU_OK;
+}
+
 int silo_gpu_stream_create(void** out_stream) {
    if (out_stream == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_stream_create: null out pointer");

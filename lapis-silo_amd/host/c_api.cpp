@@ -83,6 +83,7 @@ int silo_engine_create(
    return guarded([&] {
       auto engine = std::make_unique<silo_engine>();
       engine->database.device = device;
+      silo::setEngineDevice(device);
       engine->database.setReferenceGenomes(silo::json::parse(reference_genomes_json));
       if (alias_json != nullptr) {
          engine->database.alias_key = silo::PangoLineageAliasLookup::fromJson(silo::json::parse(alias_json));
@@ -107,6 +108,7 @@ int silo_engine_create_from_directory(const char* directory, int device, silo_en
    return guarded([&] {
       auto engine = std::make_unique<silo_engine>();
       engine->database.device = device;
+      silo::setEngineDevice(device);
       const auto summary = silo::preprocessing::loadDataset(engine->database, directory);
       if (out_summary_json != nullptr) {
          silo::json::Value doc = silo::json::Value::object();
@@ -402,6 +404,7 @@ int silo_engine_evaluate_filter(
       *out_http_status = status;
    };
    try {
+      silo::checkGpu(silo_gpu_set_device(engine->database.device), "silo_gpu_set_device");
       silo::json::Value json;
       try {
          json = silo::json::parse(filter_json);

@@ -25,10 +25,21 @@ struct ThreadStream {  // never destroyed: thread exit may come after the HIP ru
 
 }  // namespace
 
+namespace {
+std::atomic<int> g_engine_device{0};
+}
+
+void setEngineDevice(int device) {
+   g_engine_device.store(device);
+}
+
 void* queryStream() {
    thread_local ThreadStream holder;
    if (!holder.tried) {
       holder.tried = true;
+      // HIP's current device is per host thread and starts at 0: a request thread or batch worker of the process that serves
+      // GPU r (one process per GPU, all devices visible) must create its stream — and everything else it creates — on r
+      (void)silo_gpu_set_device(g_engine_device.load());
       if (silo_gpu_stream_create(&holder.stream) != SILO_GPU_OK) {
          holder.stream = nullptr;  // fall back to the null stream
       }

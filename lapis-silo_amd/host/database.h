@@ -51,6 +51,8 @@ void checkGpu(int status, const char* what);
 /// stream — natively through silo_gpu_allreduce_counts / silo_gpu_broadcast_bytes, or by a caller-supplied
 /// callback that is handed the stream — so sharding does not cost the per-request concurrency.
 void* queryStream();
+/// The device of this process's engine (one process per GPU): what a new host thread selects before it creates its stream.
+void setEngineDevice(int device);
 
 /// Phase marks of the calling thread's last query, microseconds since the query began — the finer
 /// grained companion of the reference's two LOG_PERFORMANCE timings (query_engine.cpp:63-65).

@@ -148,6 +148,7 @@ class BatchWorkers {
 
 QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  // query_engine.cpp:30-68
    Trace::reset();
+   checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");  // HIP's current device is per thread (request threads start at 0)
    const Query query(query_string);
    Trace::mark("parsed");
    std::vector<OperatorResult> filters;
@@ -162,6 +163,7 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
 
 std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries) const {
    Trace::reset();
+   checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");
    std::vector<BatchOutcome> outcomes(queries.size());
    std::vector<std::unique_ptr<Query>> parsed(queries.size());
    std::vector<std::unique_ptr<actions::Action::Pending>> pending(queries.size());
@@ -178,6 +180,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
    std::vector<std::vector<CountJob>> count_jobs(queries.size());
    const auto parseAndCompile = [&](size_t i) {
       try {
+         checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");  // this may be a batch worker's first touch of the device
          parsed[i] = std::make_unique<Query>(queries[i]);
          filters[i] = compileFilter(database, *parsed[i]->filter);
          if (parsed[i]->action->countsOnly()) {
