@@ -670,7 +670,9 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
-            if name.startswith(f"k_scan_sliced<{scan_planes},") and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
+            # the dominant launch: pairs of one-hot rows (k_scan_sliced<2, 2, ...>) where most positions take one row
+            prefix = "k_scan_sliced<2, 2," if scan_planes == 1 else f"k_scan_sliced<{scan_planes},"
+            if name.startswith(prefix) and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
                 traffic = entry["hbm_bytes"]
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
     except (OSError, ValueError, KeyError):
@@ -720,7 +722,11 @@ def main():
             "scan_planes_per_position": scan_planes,
             "plane_rows": scan_rows,
             "escape_keys": scan_escapes,
-            "layout": ("adaptive code planes: 2 planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) with the other "
+            "plane_rows_per_position": scan_rows / max(1, n_local),
+            "layout": ("adaptive planes, chosen per position at finalize: ONE one-hot row of the position's most frequent valid symbol (two or three "
+                       "rows where a second / third symbol is frequent), or 2 code planes (codes 1..3 = the 3 most frequent), the other rows as "
+                       "escape keys; positions where neither pays keep 3 identity planes" if scan_planes == 1 else
+                       "adaptive code planes: 2 planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) with the other "
                        "rows as escape keys; positions where that does not pay keep 3 identity planes"
                        if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes"),
         },

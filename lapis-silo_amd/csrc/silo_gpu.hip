@@ -36,6 +36,7 @@ std::atomic<int> g_tune_rows_per_block{0};
 std::atomic<int> g_tune_scan_variant{0};
 std::atomic<int> g_tune_eval_leaf_batch{0};
 std::atomic<int> g_tune_compact_index{0};  // < 0: never scan the compact index (K1i), even where one was built
+std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream of the lowest priority, 1 = of default priority, 2 = the caller's stream
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
 int fail(int code, const std::string& msg) {
@@ -101,6 +102,10 @@ enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
 // Layout of a position in the adaptive code planes (code_map[p][0]): the number of code planes, and whether the codes are
 // the identity (code = index of the valid mutation symbol + 1, no escapes: the position keeps its full planes).
 constexpr uint8_t LAYOUT_IDENTITY = 0x80;
+// ... or ONE-HOT rows: the low bits give k = 1..3 rows, row j holds exactly the rows of the position's j-th most frequent
+// valid symbol (code_map[p][1 + j]); every other valid symbol of a row is an escape key.  Rows of one-hot positions need no
+// joint decoding — each is one AND + popcount under the filter — so positions with different k form ONE run for the scan.
+constexpr uint8_t LAYOUT_ONE_HOT = 0x40;
 constexpr uint32_t CODE_MAP_STRIDE = 8;  // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
 
 struct SeqStoreDev {
@@ -149,25 +154,28 @@ __host__ __device__ inline const uint64_t* scanPlanes(const SeqStoreDev& s, uint
 /// Where a position sits in the adaptive planes and how its codes read.
 struct PositionLayout {
    const uint64_t* rows;  // first plane row
-   uint32_t bits;         // code planes
+   uint32_t bits;         // plane rows: code planes, or one-hot rows
    bool identity;
-   const uint8_t* map;    // code -> scan symbol index (unused when identity)
+   bool one_hot;
+   const uint8_t* map;    // code (or 1 + one-hot row) -> scan symbol index (unused when identity)
 };
 __device__ __forceinline__ PositionLayout layoutOf(const SeqStoreDev& s, uint32_t position) {
    if (s.code_map == nullptr) {
-      return {s.planes + static_cast<size_t>(position) * s.n_bits * s.row_words, s.n_bits, true, nullptr};
+      return {s.planes + static_cast<size_t>(position) * s.n_bits * s.row_words, s.n_bits, true, false, nullptr};
    }
    const uint8_t* map = s.code_map + static_cast<size_t>(position) * CODE_MAP_STRIDE;
-   return {s.planes + static_cast<size_t>(s.row_of[position]) * s.row_words, map[0] & 0x7Fu, (map[0] & LAYOUT_IDENTITY) != 0, map};
+   return {s.planes + static_cast<size_t>(s.row_of[position]) * s.row_words, map[0] & 0x3Fu, (map[0] & LAYOUT_IDENTITY) != 0,
+           (map[0] & LAYOUT_ONE_HOT) != 0, map};
 }
 
-/// The code (0 = none) that stands for scan symbol index `scan_index` at a position, or 0xFFFFFFFF when the symbol has
-/// no code there (its rows are escape keys).
+/// The code (0 = none) that stands for scan symbol index `scan_index` at a position — for a one-hot position 1 + the row
+/// that holds the symbol — or 0xFFFFFFFF when the symbol has neither there (its rows are escape keys).
 __device__ __forceinline__ uint32_t codeOfSymbol(const PositionLayout& layout, uint32_t scan_index) {
    if (layout.identity) {
       return scan_index + 1u;
    }
-   for (uint32_t code = 1; code < (1u << layout.bits); ++code) {
+   const uint32_t n_codes = layout.one_hot ? layout.bits + 1u : (1u << layout.bits);
+   for (uint32_t code = 1; code < n_codes; ++code) {
       if (layout.map[code] == scan_index) {
          return code;
       }
@@ -175,14 +183,27 @@ __device__ __forceinline__ uint32_t codeOfSymbol(const PositionLayout& layout, u
    return 0xFFFFFFFFu;
 }
 
-/// Word `word` of the rows whose code at the position is `code`, decoded from the position's planes.
+/// Word `word` of the rows whose code at the position is `code`, decoded from the position's planes (one-hot: read).
 __device__ __forceinline__ uint64_t decodeCodeWord(const PositionLayout& layout, uint32_t row_words, uint32_t code, uint32_t word) {
+   if (layout.one_hot) {
+      return layout.rows[static_cast<size_t>(code - 1u) * row_words + word];
+   }
    uint64_t match = ~0ull;
    for (uint32_t bit = 0; bit < layout.bits; ++bit) {
       const uint64_t plane_word = layout.rows[static_cast<size_t>(bit) * row_words + word];
       match &= ((code >> bit) & 1u) != 0 ? plane_word : ~plane_word;
    }
    return match;  // padding bits have code 0, every coded symbol a code >= 1
+}
+
+/// The row's code at the position (0 = none coded): read out of the code planes, or the one-hot row that has its bit.
+__device__ __forceinline__ uint32_t codeOfRow(const PositionLayout& layout, uint32_t row_words, uint32_t word, uint32_t bit) {
+   uint32_t code = 0;
+   for (uint32_t plane = 0; plane < layout.bits; ++plane) {
+      const uint32_t set = static_cast<uint32_t>((layout.rows[static_cast<size_t>(plane) * row_words + word] >> bit) & 1u);
+      code = layout.one_hot ? (set != 0 ? plane + 1u : code) : (code | (set << plane));
+   }
+   return code;
 }
 
 struct SeqStoreHost {
@@ -204,13 +225,15 @@ struct SeqStoreHost {
    struct Run {  // consecutive positions of one layout: a scan launch takes runs of ONE layout
       uint32_t begin;
       uint32_t end;
-      uint8_t bits;
+      uint8_t bits;   // code planes per position; 0 for a run of one-hot positions (1..3 rows each)
       bool identity;
+      bool one_hot;
    };
    struct Layout {
       bool built = false;
       uint64_t* planes = nullptr;       // owned; nullptr when the store keeps its build-time planes (dev.planes == dev.scan)
       uint32_t* d_row_of = nullptr;
+      uint32_t* d_row_target = nullptr;  // [rows] one-hot rows: position * n_scan + scan symbol of the row (else 0xFFFFFFFF)
       uint8_t* d_code_map = nullptr;
       uint64_t* d_escapes = nullptr;
       uint32_t* d_escape_first = nullptr;
@@ -333,9 +356,15 @@ struct ScanBatchArgs {
    uint32_t* counts[SCAN_MAX_RANGES][SILO_GPU_MAX_SCAN_BATCH];  // counts[range][filter], at the first position of the range
    // mapped layouts (2 or 3 code planes): per position of the range CODE_MAP_STRIDE bytes, [c] = the scan symbol that
    // code c stands for at this position (0xFF = none); out_symbols = symbols per position of the count tables (5 / 22)
+   // one-hot rows (KIND_ROWS): the range is a run of plane ROWS, n_positions counts rows, code_map[range] points at the
+   // uint32 table row -> position * out_symbols + symbol (positions of the store), target_base = that of counts[range]
    const uint8_t* code_map[SCAN_MAX_RANGES];
+   uint32_t target_base[SCAN_MAX_RANGES];
    uint32_t out_symbols;
 };
+
+// what a run of plane rows holds
+enum : int { KIND_IDENTITY = 0, KIND_MAPPED = 1, KIND_ROWS = 2 };
 
 // positions whose partial counts sit in LDS between two flushes: ~16 KiB of LDS whatever NSYM * Q is
 template <int NSYM, int Q>
@@ -346,13 +375,16 @@ constexpr int scanPositionsBatch() {
 }
 
 // blocks per CU the register budget has to allow: plane buffers 2 * BITS * WPT * 2 VGPRs, filters Q * WPT * 2
-template <int BITS, int WPT, int Q>
+template <int BITS, int NSYM, int WPT, int Q>
 constexpr int scanMinBlocks() {
+   if (BITS == 3 && NSYM == 7 && WPT == 8) {
+      return 2;  // 7 counted symbols over 8 words per thread: 3 blocks per CU would spill
+   }
    return Q == 1 ? (BITS * WPT <= 12 ? 4 : (BITS * WPT <= 18 ? 4 : (BITS <= 3 && BITS * WPT <= 24 ? 3 : 2))) : (Q <= 2 && BITS <= 3 ? 4 : (Q <= 4 && BITS <= 3 ? 3 : 2));
 }
 
-template <int BITS, int NSYM, int WPT, int Q, bool MAPPED>
-__global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void k_scan_sliced(
+template <int BITS, int NSYM, int WPT, int Q, int KIND>
+__global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, NSYM, WPT, Q>())) void k_scan_sliced(
    const ScanBatchArgs batch, uint32_t row_words, uint32_t positions_per_block, uint32_t n_tiles
 ) {
    constexpr int CHUNKS = WPT / 2;  // 16-byte chunks per thread and plane
@@ -369,7 +401,10 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
    }
    const uint32_t block_in_range = blockIdx.x - batch.first_unit[range];
    const uint64_t* __restrict__ planes = batch.planes[range];
-   const uint32_t n_positions = batch.n_positions[range];
+   // one-hot rows: a "position" of the pipeline is a PAIR of rows (BITS = NSYM = 2), each counted on its own
+   static_assert(KIND != KIND_ROWS || (BITS == 2 && NSYM == 2), "rows are scanned in pairs");
+   const uint32_t n_rows = batch.n_positions[range];
+   const uint32_t n_positions = KIND == KIND_ROWS ? (n_rows + 1u) / 2u : n_rows;
    const uint32_t tile = block_in_range % n_tiles;
    const uint32_t position_group = block_in_range / n_tiles;
    const uint32_t pos_begin = position_group * positions_per_block;
@@ -411,9 +446,11 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
       const uint64_t* base = planes + static_cast<size_t>(position) * BITS * row_words;
 #pragma unroll
       for (int bit = 0; bit < BITS; ++bit) {
+         // the second row of the last pair of an odd run is the first one again (in bounds, not stored)
+         const size_t row = KIND == KIND_ROWS ? static_cast<size_t>(min(static_cast<uint32_t>(bit), n_rows - 1u - position * 2u)) : static_cast<size_t>(bit);
 #pragma unroll
          for (int j = 0; j < CHUNKS; ++j) {
-            dst[bit][j] = loadPlane16<true>(base + static_cast<size_t>(bit) * row_words + word[j]);
+            dst[bit][j] = loadPlane16<true>(base + row * row_words + word[j]);
          }
       }
    };
@@ -439,6 +476,16 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             // is then two ANDs (22 symbols from 5 planes: ~55 logic ops per word instead of 110).  With one filter the
             // filter is folded into the low pair, so the per-symbol AND with it disappears as well.
             const uint64_t filter0 = half == 0 ? f[0][j].x : f[0][j].y;
+            if constexpr (KIND == KIND_ROWS) {
+#pragma unroll
+               for (int row = 0; row < NSYM; ++row) {
+#pragma unroll
+                  for (int q = 0; q < Q; ++q) {
+                     acc[row][q] += static_cast<uint32_t>(__popcll(bits[row] & (half == 0 ? f[q][j].x : f[q][j].y)));
+                  }
+               }
+               continue;
+            }
             uint64_t low[4];
             low[0] = ~bits[1] & ~bits[0];
             low[1] = ~bits[1] & bits[0];
@@ -507,7 +554,13 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, WPT, Q>())) void
             total += s_partial[buffer][w][position][rest];
          }
          if (total != 0) {
-            if constexpr (MAPPED) {  // code -> the symbol it stands for at this position
+            if constexpr (KIND == KIND_ROWS) {  // row -> its (position, symbol) counter
+               const uint32_t row = (batch_first_position + position) * 2u + rest % NSYM;
+               if (row < n_rows) {
+                  const uint32_t target = reinterpret_cast<const uint32_t*>(batch.code_map[range])[row] - batch.target_base[range];
+                  atomicAdd(&batch.counts[range][rest / NSYM][target], total);
+               }
+            } else if constexpr (KIND == KIND_MAPPED) {  // code -> the symbol it stands for at this position
                const uint32_t symbol = batch.code_map[range][static_cast<size_t>(batch_first_position + position) * CODE_MAP_STRIDE + 1 + rest % NSYM];
                if (symbol < batch.out_symbols) {  // an unused code (0xFF) has no rows: never taken, never out of bounds
                   atomicAdd(&batch.counts[range][rest / NSYM][static_cast<size_t>(batch_first_position + position) * batch.out_symbols + symbol], total);
@@ -643,7 +696,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
 
 // One WAVE per group of POSG consecutive positions (no LDS, no block-level reduction: a sparse filter may have fewer
 // non-zero words than a block has lanes); lanes stride over the words of the listed sectors, POSG * BITS gathers in flight each.
-template <int BITS, int NSYM, int POSG, bool MAPPED>
+template <int BITS, int NSYM, int POSG, int KIND>
 __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_scan_gather(
    const ScanBatchArgs batch, const uint32_t* __restrict__ sector_index, uint32_t capacity, uint32_t row_words
 ) {
@@ -663,7 +716,8 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
       ++range;
    }
    const uint64_t* __restrict__ planes = batch.planes[range];
-   const uint32_t n_positions = batch.n_positions[range];
+   static_assert(KIND != KIND_ROWS || (BITS == 1 && NSYM == 1), "one-hot rows are gathered one by one");
+   const uint32_t n_positions = batch.n_positions[range];  // KIND_ROWS: plane rows
    const uint32_t pos_begin = (unit - batch.first_unit[range]) * POSG;
    const uint32_t last_pos = n_positions - 1;
    const uint32_t* index = sector_index + static_cast<size_t>(q) * capacity;
@@ -693,20 +747,24 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
       }
 #pragma unroll
       for (int g = 0; g < POSG; ++g) {
+         if constexpr (KIND == KIND_ROWS) {
+            acc[g][0] += static_cast<uint32_t>(__popcll(bits[g][0] & filter_word));
+            continue;
+         }
+         constexpr int B1 = BITS > 1 ? 1 : 0;  // (one plane: never decoded)
          uint64_t low[4];
-         low[0] = ~bits[g][1] & ~bits[g][0] & filter_word;
-         low[1] = ~bits[g][1] & bits[g][0] & filter_word;
-         low[2] = bits[g][1] & ~bits[g][0] & filter_word;
-         low[3] = bits[g][1] & bits[g][0] & filter_word;
+         low[0] = ~bits[g][B1] & ~bits[g][0] & filter_word;
+         low[1] = ~bits[g][B1] & bits[g][0] & filter_word;
+         low[2] = bits[g][B1] & ~bits[g][0] & filter_word;
+         low[3] = bits[g][B1] & bits[g][0] & filter_word;
          uint64_t high[BITS <= 3 ? 2 : 8];
-         if constexpr (BITS == 2) {
+         if constexpr (BITS <= 2) {
             high[0] = ~0ull;  // the codes are the low pair
             high[1] = 0;
          } else if constexpr (BITS == 3) {
             high[0] = ~bits[g][2];
             high[1] = bits[g][2];
-         } else {
-            static_assert(BITS == 5, "decode tree written for 2, 3 or 5 code bits");
+         } else if constexpr (BITS == 5) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                high[k] = ((k & 1) != 0 ? bits[g][2] : ~bits[g][2]) & ((k & 2) != 0 ? bits[g][3] : ~bits[g][3]) &
@@ -716,7 +774,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
 #pragma unroll
          for (int symbol = 0; symbol < NSYM; ++symbol) {
             const uint32_t code = static_cast<uint32_t>(symbol) + 1u;
-            acc[g][symbol] += static_cast<uint32_t>(__popcll(BITS == 2 ? low[code & 3u] : (low[code & 3u] & high[code >> 2])));
+            acc[g][symbol] += static_cast<uint32_t>(__popcll(BITS <= 2 ? low[code & 3u] : (low[code & 3u] & high[code >> 2])));
          }
       }
    }
@@ -726,7 +784,10 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
       for (int symbol = 0; symbol < NSYM; ++symbol) {
          const uint32_t total = waveSumToLane63(acc[g][symbol]);
          if (lane == 63u && total != 0 && pos_begin + g < n_positions) {
-            if constexpr (MAPPED) {  // code -> the symbol it stands for at this position
+            if constexpr (KIND == KIND_ROWS) {  // row -> its (position, symbol) counter
+               const uint32_t target = reinterpret_cast<const uint32_t*>(batch.code_map[range])[pos_begin + g] - batch.target_base[range];
+               atomicAdd(&batch.counts[range][q][target], total);
+            } else if constexpr (KIND == KIND_MAPPED) {  // code -> the symbol it stands for at this position
                const uint32_t mapped = batch.code_map[range][static_cast<size_t>(pos_begin + g) * CODE_MAP_STRIDE + 1 + symbol];
                if (mapped < batch.out_symbols) {
                   atomicAdd(&batch.counts[range][q][static_cast<size_t>(pos_begin + g) * batch.out_symbols + mapped], total);
@@ -787,10 +848,11 @@ __global__ __launch_bounds__(256) void k_encode_adaptive(
       }
       return;
    }
-   const uint32_t out_bits = map[0] & 0x7Fu;  // 2 or 3
+   const uint32_t out_bits = map[0] & 0x3Fu;  // 2 or 3 code planes, or 1..3 one-hot rows
+   const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
    uint64_t out_plane[3] = {0, 0, 0};
    uint64_t coded = 0;
-   for (uint32_t code = 1; code < (1u << out_bits); ++code) {
+   for (uint32_t code = 1; code < (one_hot ? out_bits + 1u : (1u << out_bits)); ++code) {
       const uint32_t symbol = map[code];
       if (symbol == 0xFFu) {
          continue;
@@ -804,7 +866,7 @@ __global__ __launch_bounds__(256) void k_encode_adaptive(
       coded |= match;
 #pragma unroll
       for (uint32_t bit = 0; bit < 3; ++bit) {
-         if (((code >> bit) & 1u) != 0) {
+         if (one_hot ? code == bit + 1u : ((code >> bit) & 1u) != 0) {
             out_plane[bit] |= match;
          }
       }
@@ -1375,10 +1437,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
    uint32_t found = 0xFFu;
    // the row's code in the position's planes, and the valid mutation symbol that code stands for there (0 = none coded)
    const PositionLayout layout = layoutOf(store, position);
-   uint32_t code = 0;
-   for (uint32_t plane_bit = 0; plane_bit < layout.bits; ++plane_bit) {
-      code |= static_cast<uint32_t>((layout.rows[static_cast<size_t>(plane_bit) * store.row_words + word] >> bit) & 1u) << plane_bit;
-   }
+   const uint32_t code = codeOfRow(layout, store.row_words, word, bit);
    const uint32_t coded_index = code == 0 ? 0xFFu : (layout.identity ? code - 1u : layout.map[code]);
    for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
       if (store.kind[symbol] == PLANE_SCAN) {
@@ -1540,6 +1599,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_COMPACT_INDEX) {
       return g_tune_compact_index.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_SIDE_STREAM) {
+      return g_tune_side_stream.exchange(value);
+   }
    return -1;
 }
 
@@ -1659,6 +1721,7 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_totals);
       (void)hipFree(seqstore.layout.planes);
       (void)hipFree(seqstore.layout.d_row_of);
+      (void)hipFree(seqstore.layout.d_row_target);
       (void)hipFree(seqstore.layout.d_code_map);
       (void)hipFree(seqstore.layout.d_escapes);
       (void)hipFree(seqstore.layout.d_escape_first);
@@ -2004,15 +2067,19 @@ struct ScanRange {
 /// The part of a range that lies in ONE run of its store's layout: what a launch takes.
 struct ScanPiece {
    const uint64_t* planes;    // first plane row of the piece
-   const uint8_t* code_map;   // of the piece's first position (mapped layouts), else nullptr
-   uint32_t n_positions;
+   const uint8_t* code_map;   // of the piece's first position (mapped layouts); the row targets of its first row (one-hot rows); else nullptr
+   uint32_t n_positions;      // one-hot rows: plane rows
+   uint32_t target_base;      // one-hot rows: first position of the piece * n_scan
    uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];  // tables at the piece's first position
 };
 
 /// The four plane layouts the scan kernels are instantiated for.
-enum ScanLayout { SCAN_2_PLANES = 0, SCAN_3_PLANES_MAPPED, SCAN_FULL_NUCLEOTIDE, SCAN_FULL_AMINO_ACID, N_SCAN_LAYOUTS };
+enum ScanLayout { SCAN_2_PLANES = 0, SCAN_3_PLANES_MAPPED, SCAN_FULL_NUCLEOTIDE, SCAN_FULL_AMINO_ACID, SCAN_ONE_HOT_ROWS, N_SCAN_LAYOUTS };
 
-ScanLayout layoutOfRun(const SeqStoreDev& dev, uint32_t bits, bool identity) {
+ScanLayout layoutOfRun(const SeqStoreDev& dev, uint32_t bits, bool identity, bool one_hot) {
+   if (one_hot) {
+      return SCAN_ONE_HOT_ROWS;
+   }
    if (!identity) {
       return bits == 2 ? SCAN_2_PLANES : SCAN_3_PLANES_MAPPED;
    }
@@ -2024,7 +2091,7 @@ void cutIntoPieces(const std::vector<ScanRange>& ranges, uint32_t q_count, std::
    for (const ScanRange& range : ranges) {
       const SeqStoreHost& seqstore = *range.seqstore;
       const SeqStoreDev& dev = seqstore.dev;
-      const auto add = [&](uint32_t begin, uint32_t end, uint32_t bits, bool identity) {
+      const auto add = [&](uint32_t begin, uint32_t end, uint32_t bits, bool identity, bool one_hot) {
          begin = std::max(begin, range.pos_begin);
          end = std::min(end, range.pos_end);
          if (begin >= end) {
@@ -2034,24 +2101,30 @@ void cutIntoPieces(const std::vector<ScanRange>& ranges, uint32_t q_count, std::
          const bool encoded = seqstore.layout.built && seqstore.layout.d_row_of != nullptr;
          const size_t first_row = encoded ? seqstore.layout.row_of[begin] : static_cast<size_t>(begin) * dev.n_bits;
          piece.planes = dev.planes + first_row * dev.row_words;
-         piece.code_map = identity ? nullptr : seqstore.layout.d_code_map + static_cast<size_t>(begin) * CODE_MAP_STRIDE;
          piece.n_positions = end - begin;
+         if (one_hot) {
+            piece.code_map = reinterpret_cast<const uint8_t*>(seqstore.layout.d_row_target + first_row);
+            piece.n_positions = seqstore.layout.row_of[end] - seqstore.layout.row_of[begin];
+            piece.target_base = begin * dev.n_scan;
+         } else if (!identity) {
+            piece.code_map = seqstore.layout.d_code_map + static_cast<size_t>(begin) * CODE_MAP_STRIDE;
+         }
          for (uint32_t q = 0; q < q_count; ++q) {
             piece.counts[q] = range.counts[q] + static_cast<size_t>(begin - range.pos_begin) * dev.n_scan;
          }
-         pieces[layoutOfRun(dev, bits, identity)].push_back(piece);
+         pieces[layoutOfRun(dev, bits, identity, one_hot)].push_back(piece);
       };
       if (seqstore.layout.runs.empty()) {  // still the build-time planes (the totals scan inside finalize)
-         add(0, dev.positions, dev.n_bits, true);
+         add(0, dev.positions, dev.n_bits, true, false);
       }
       for (const SeqStoreHost::Run& run : seqstore.layout.runs) {
-         add(run.begin, run.end, run.bits, run.identity);
+         add(run.begin, run.end, run.bits, run.identity, run.one_hot);
       }
    }
 }
 
 /// Launches k_scan_sliced for the `q_count` filters and the pieces already entered in `batch` (planes, n_positions, counts).
-template <int BITS, int NSYM, bool MAPPED>
+template <int BITS, int NSYM, int KIND>
 int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
    // words per thread: 8 for one filter over a layout of at most 5 counted symbols (2 or 3 planes x 4 chunks per position and
    // buffer), 4 otherwise (7 or 22 symbols; batches: Q filter tiles in registers).  SILO_GPU_TUNE_SCAN_VARIANT 10 / 12 force 4 / 8.
@@ -2066,9 +2139,11 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    const uint32_t tile_words = SCAN_THREADS * (wide ? 8 : 4);
    int positions_per_block = g_tune_rows_per_block.load();
    const uint32_t n_tiles = (row_words + tile_words - 1) / tile_words;
+   // what the pipeline steps through: positions of BITS planes, or pairs of one-hot rows
+   const auto units = [&](uint32_t r) { return KIND == KIND_ROWS ? (batch.n_positions[r] + 1u) / 2u : batch.n_positions[r]; };
    uint64_t total_positions = 0;
    for (uint32_t r = 0; r < batch.n_ranges; ++r) {
-      total_positions += batch.n_positions[r];
+      total_positions += units(r);
    }
    if (positions_per_block <= 0) {
       // 2 or 3 planes per position: 128 positions per block while that still leaves >= 4096 blocks, else 64; the 5 identity
@@ -2086,11 +2161,11 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    positions_per_block += positions_per_block & 1;  // the pipeline works on pairs of positions
    batch.first_unit[0] = 0;
    for (uint32_t r = 0; r < batch.n_ranges; ++r) {
-      batch.first_unit[r + 1] = batch.first_unit[r] + n_tiles * ((batch.n_positions[r] + positions_per_block - 1) / positions_per_block);
+      batch.first_unit[r + 1] = batch.first_unit[r] + n_tiles * ((units(r) + positions_per_block - 1) / positions_per_block);
    }
    const dim3 grid(batch.first_unit[batch.n_ranges]);
 #define SILO_LAUNCH_SLICED(WPT, Q) \
-   k_scan_sliced<BITS, NSYM, WPT, Q, MAPPED><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
+   k_scan_sliced<BITS, NSYM, WPT, Q, KIND><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
    if (wide) {
       if constexpr (CAN_BE_WIDE) {
          SILO_LAUNCH_SLICED(8, 1);
@@ -2120,14 +2195,14 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
 }
 
 /// Launches k_scan_gather (one wave per POSG positions) for the pieces in `batch`; grid.y = filter.
-template <int BITS, int NSYM, int POSG, bool MAPPED>
+template <int BITS, int NSYM, int POSG, int KIND>
 int launchGatherScan(ScanBatchArgs& batch, const uint32_t* sector_index, uint32_t stride, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
    batch.first_unit[0] = 0;
    for (uint32_t r = 0; r < batch.n_ranges; ++r) {
       batch.first_unit[r + 1] = batch.first_unit[r] + (batch.n_positions[r] + POSG - 1) / POSG;
    }
    const uint32_t waves = batch.first_unit[batch.n_ranges];
-   k_scan_gather<BITS, NSYM, POSG, MAPPED><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(batch, sector_index, stride, row_words);
+   k_scan_gather<BITS, NSYM, POSG, KIND><<<dim3((waves + 3) / 4, q_count), 256, 0, hip_stream>>>(batch, sector_index, stride, row_words);
    HIP_TRY(hipGetLastError());
    return SILO_GPU_OK;
 }
@@ -2189,12 +2264,12 @@ void releaseSparseScratch(SparseScratch* block, hipStream_t stream) {
 /// Side streams (and the events that tie them to the caller's) per host thread.  The escape pass is a stream of keys, random
 /// filter lookups and atomics — latency-bound — and adds to the same count tables as the plane scans, which are
 /// bandwidth-bound, so it runs beside them.  Never destroyed (thread exit may come after the HIP runtime has shut down).
-constexpr int N_SIDE_STREAMS = 1;  // [0] the escape pass
+constexpr int N_SIDE_STREAMS = 2;  // the escape pass: [0] at the lowest stream priority, [1] at the default one (SILO_GPU_TUNE_SIDE_STREAM)
 struct SideStreams {
-   hipStream_t stream[N_SIDE_STREAMS] = {nullptr};
+   hipStream_t stream[N_SIDE_STREAMS] = {nullptr, nullptr};
    hipEvent_t fork[2] = {nullptr, nullptr};
-   hipEvent_t join[N_SIDE_STREAMS] = {nullptr};
-   bool used[N_SIDE_STREAMS] = {false};
+   hipEvent_t join[N_SIDE_STREAMS] = {nullptr, nullptr};
+   bool used[N_SIDE_STREAMS] = {false, false};
    bool tried = false;
    bool ok = false;
 };
@@ -2204,8 +2279,10 @@ SideStreams* sideStreams() {
    if (!side.tried) {
       side.tried = true;
       side.ok = true;
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       for (int k = 0; k < N_SIDE_STREAMS; ++k) {
-         side.ok = side.ok && hipStreamCreateWithFlags(&side.stream[k], hipStreamNonBlocking) == hipSuccess &&
+         side.ok = side.ok && hipStreamCreateWithPriority(&side.stream[k], hipStreamNonBlocking, k == 0 ? least : 0) == hipSuccess &&
                    hipEventCreateWithFlags(&side.join[k], hipEventDisableTiming) == hipSuccess;
       }
       for (int k = 0; k < 2; ++k) {
@@ -2251,6 +2328,7 @@ void enterPieces(ScanBatchArgs& batch, const std::vector<ScanPiece>& pieces, siz
       const ScanPiece& piece = pieces[first + r];
       batch.planes[r] = piece.planes;
       batch.code_map[r] = piece.code_map;
+      batch.target_base[r] = piece.target_base;
       batch.n_positions[r] = piece.n_positions;
       for (uint32_t q = 0; q < n_filters; ++q) {
          batch.counts[r][q] = piece.counts[first_filter + q];
@@ -2268,7 +2346,7 @@ int scanPiecesDense(
    // launches are bandwidth-bound together — profiles/r02_amino_acid.md)
    for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
       const std::vector<ScanPiece>& list = pieces[layout];
-      const uint32_t filters_per_pass = layout == SCAN_2_PLANES || layout == SCAN_FULL_NUCLEOTIDE ? SILO_GPU_MAX_SCAN_BATCH : 4;
+      const uint32_t filters_per_pass = layout == SCAN_2_PLANES || layout == SCAN_FULL_NUCLEOTIDE || layout == SCAN_ONE_HOT_ROWS ? SILO_GPU_MAX_SCAN_BATCH : 4;
       for (size_t first_piece = 0; first_piece < list.size(); first_piece += SCAN_MAX_RANGES) {
          const uint32_t n_pieces = static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, list.size() - first_piece));
          for (uint32_t first = 0; first < q_count; first += filters_per_pass) {
@@ -2283,10 +2361,11 @@ int scanPiecesDense(
             enterPieces(batch, list, first_piece, n_pieces, first, n);
             int rc = SILO_GPU_OK;
             switch (layout) {
-               case SCAN_2_PLANES: rc = launchSlicedScan<2, 3, true>(batch, any_store.row_words, n, hip_stream); break;
-               case SCAN_3_PLANES_MAPPED: rc = launchSlicedScan<3, 7, true>(batch, any_store.row_words, n, hip_stream); break;
-               case SCAN_FULL_NUCLEOTIDE: rc = launchSlicedScan<3, 5, false>(batch, any_store.row_words, n, hip_stream); break;
-               default: rc = launchSlicedScan<5, 22, false>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_2_PLANES: rc = launchSlicedScan<2, 3, KIND_MAPPED>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_3_PLANES_MAPPED: rc = launchSlicedScan<3, 7, KIND_MAPPED>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_FULL_NUCLEOTIDE: rc = launchSlicedScan<3, 5, KIND_IDENTITY>(batch, any_store.row_words, n, hip_stream); break;
+               case SCAN_ONE_HOT_ROWS: rc = launchSlicedScan<2, 2, KIND_ROWS>(batch, any_store.row_words, n, hip_stream); break;
+               default: rc = launchSlicedScan<5, 22, KIND_IDENTITY>(batch, any_store.row_words, n, hip_stream); break;
             }
             if (rc != SILO_GPU_OK) {
                return rc;
@@ -2336,14 +2415,16 @@ int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    if (!any) {
       return SILO_GPU_OK;
    }
-   SideStreams* side = sideStreams();
+   const int mode = g_tune_side_stream.load();  // 0: lowest-priority side stream, 1: default priority, 2: the caller's stream
+   SideStreams* side = mode == 2 ? nullptr : sideStreams();
    if (side == nullptr) {
       return scanEscapes(ranges, filters, q_count, hip_stream);
    }
-   if (const int rc = forkSide(side, 0, 0, hip_stream, true); rc != SILO_GPU_OK) {
+   const int k = mode == 1 ? 1 : 0;
+   if (const int rc = forkSide(side, k, 0, hip_stream, true); rc != SILO_GPU_OK) {
       return rc;
    }
-   return scanEscapes(ranges, filters, q_count, side->stream[0]);
+   return scanEscapes(ranges, filters, q_count, side->stream[k]);
 }
 
 /// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores of one alphabet, with the
@@ -2424,10 +2505,11 @@ int scanRanges(
          }
          enterPieces(batch, list, first_piece, static_cast<uint32_t>(std::min<size_t>(SCAN_MAX_RANGES, list.size() - first_piece)), 0, q_count);
          switch (layout) {
-            case SCAN_2_PLANES: rc = launchGatherScan<2, 3, 4, true>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
-            case SCAN_3_PLANES_MAPPED: rc = launchGatherScan<3, 7, 4, true>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
-            case SCAN_FULL_NUCLEOTIDE: rc = launchGatherScan<3, 5, 4, false>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
-            default: rc = launchGatherScan<5, 22, 2, false>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_2_PLANES: rc = launchGatherScan<2, 3, 4, KIND_MAPPED>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_3_PLANES_MAPPED: rc = launchGatherScan<3, 7, 4, KIND_MAPPED>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_FULL_NUCLEOTIDE: rc = launchGatherScan<3, 5, 4, KIND_IDENTITY>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            case SCAN_ONE_HOT_ROWS: rc = launchGatherScan<1, 1, 8, KIND_ROWS>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
+            default: rc = launchGatherScan<5, 22, 2, KIND_IDENTITY>(batch, scratch->sector_index, stride, any_store.row_words, q_count, hip_stream); break;
          }
       }
    }
@@ -2437,17 +2519,19 @@ int scanRanges(
 }
 
 /// The layout of every position of a sequence store (see "The adaptive code planes" above) from the unfiltered totals:
-/// code_map[p][0] = code planes (| LAYOUT_IDENTITY), code_map[p][c] = the scan symbol of code c; escape_count[p][s] = rows
-/// of symbol s at p that get no code.  A small dynamic program over the positions: the cost of a position under each of
-/// the three layouts plus RUN_COST for every change of layout between neighbours.
+/// code_map[p][0] = code planes (| LAYOUT_IDENTITY) or one-hot rows (| LAYOUT_ONE_HOT), code_map[p][c] = the scan symbol of
+/// code c (of one-hot row c - 1); escape_count[p][s] = rows of symbol s at p that get neither.  A small dynamic program over
+/// the positions: the cost of a position under each of the four layouts plus RUN_COST for every change of layout between
+/// neighbours (one-hot positions of 1, 2 or 3 rows are ONE layout: a run of rows).
 void chooseLayouts(
-   const std::vector<uint32_t>& totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint64_t row_bytes, std::vector<uint8_t>& code_map,
-   std::vector<uint32_t>& escape_count
+   const std::vector<uint32_t>& totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint64_t row_bytes, bool allow_one_hot,
+   std::vector<uint8_t>& code_map, std::vector<uint32_t>& escape_count
 ) {
-   enum { TWO_PLANES = 0, THREE_PLANES = 1, IDENTITY = 2, N_LAYOUTS = 3 };
+   enum { TWO_PLANES = 0, THREE_PLANES = 1, IDENTITY = 2, ONE_HOT = 3, N_LAYOUTS = 4 };
    constexpr uint64_t NEVER = ~0ull >> 2;
    const uint64_t run_cost = 2 * row_bytes;
    std::vector<uint8_t> best(static_cast<size_t>(positions) * 7, 0xFF);   // the seven most frequent valid symbols, most frequent first
+   std::vector<uint8_t> one_hot_rows(positions, 1);                       // rows of the position as a one-hot one
    std::vector<uint64_t> cost(static_cast<size_t>(positions) * N_LAYOUTS);
    for (uint32_t p = 0; p < positions; ++p) {
       const uint32_t* count = totals.data() + static_cast<size_t>(p) * n_scan;
@@ -2472,11 +2556,21 @@ void chooseLayouts(
             taken |= 1u << pick;
          }
       }
-      cost[static_cast<size_t>(p) * N_LAYOUTS + TWO_PLANES] = 2 * row_bytes + KEY_COST_BYTES * (total - carried[3]);
+      uint64_t* position_cost = cost.data() + static_cast<size_t>(p) * N_LAYOUTS;
+      position_cost[TWO_PLANES] = 2 * row_bytes + KEY_COST_BYTES * (total - carried[3]);
       // three mapped planes only pay where the identity layout has more (amino acids)
-      cost[static_cast<size_t>(p) * N_LAYOUTS + THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + KEY_COST_BYTES * (total - carried[7]) : NEVER;
+      position_cost[THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + KEY_COST_BYTES * (total - carried[7]) : NEVER;
       // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped layouts
-      cost[static_cast<size_t>(p) * N_LAYOUTS + IDENTITY] = n_bits > 3 ? n_bits * row_bytes * 115 / 100 : n_bits * row_bytes;
+      position_cost[IDENTITY] = n_bits > 3 ? n_bits * row_bytes * 115 / 100 : n_bits * row_bytes;
+      // k rows, one per symbol: one row where one symbol has (nearly) all rows — most positions of a real alignment
+      position_cost[ONE_HOT] = NEVER;
+      for (uint32_t k = 1; allow_one_hot && k <= 3; ++k) {
+         const uint64_t with_k = k * row_bytes + KEY_COST_BYTES * (total - carried[k]);
+         if (with_k < position_cost[ONE_HOT]) {
+            position_cost[ONE_HOT] = with_k;
+            one_hot_rows[p] = static_cast<uint8_t>(k);
+         }
+      }
    }
    std::vector<uint64_t> reach(static_cast<size_t>(positions) * N_LAYOUTS);  // cheapest way to encode positions [0, p] with p in that layout
    std::vector<uint8_t> from(static_cast<size_t>(positions) * N_LAYOUTS);
@@ -2514,8 +2608,8 @@ void chooseLayouts(
             map[code] = static_cast<uint8_t>(code - 1 < n_scan && code < (1u << n_bits) ? code - 1 : 0xFFu);
          }
       } else {
-         const uint32_t coded = layout == TWO_PLANES ? 3 : 7;
-         map[0] = static_cast<uint8_t>(layout == TWO_PLANES ? 2 : 3);
+         const uint32_t coded = layout == ONE_HOT ? one_hot_rows[p] : (layout == TWO_PLANES ? 3 : 7);
+         map[0] = static_cast<uint8_t>(layout == ONE_HOT ? (one_hot_rows[p] | LAYOUT_ONE_HOT) : (layout == TWO_PLANES ? 2 : 3));
          uint32_t coded_mask = 0;
          for (uint32_t code = 1; code <= coded; ++code) {
             map[code] = best[static_cast<size_t>(p) * 7 + code - 1];
@@ -2541,7 +2635,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SeqStoreHost::Layout& layout = seqstore.layout;
    const uint32_t positions = dev.positions;
    const auto keepBuildPlanes = [&]() {  // every position: the n_bits identity planes, where they are
-      layout.runs.assign(1, SeqStoreHost::Run{0, positions, static_cast<uint8_t>(dev.n_bits), true});
+      layout.runs.assign(1, SeqStoreHost::Run{0, positions, static_cast<uint8_t>(dev.n_bits), true, false});
       dev.planes = dev.scan;
       dev.row_of = nullptr;
       dev.code_map = nullptr;
@@ -2577,10 +2671,12 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    uint32_t* d_count = nullptr;  // escapes per (position, symbol), later the cursors of the encoder
    uint32_t* d_first = nullptr;
    uint32_t* d_row_of = nullptr;
+   uint32_t* d_row_target = nullptr;
    uint32_t* d_escape_first = nullptr;
    uint64_t* d_planes = nullptr;
    uint64_t* d_escapes = nullptr;
    const auto discard = [&]() {
+      (void)hipFree(d_row_target);
       (void)hipFree(d_code_map);
       (void)hipFree(d_count);
       (void)hipFree(d_first);
@@ -2601,11 +2697,16 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SILO_LAYOUT_TRY(hipMemcpy(totals.data(), seqstore.d_totals, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost));
    std::vector<uint8_t> code_map;
    std::vector<uint32_t> counts;  // escape keys per (position, symbol)
-   chooseLayouts(totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), code_map, counts);
+   // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows (the layouts before one-hot rows, for comparisons)
+   chooseLayouts(
+      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2, code_map,
+      counts
+   );
    SILO_LAYOUT_TRY(hipMalloc(&d_code_map, code_map.size()));
    SILO_LAYOUT_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
    SILO_LAYOUT_TRY(hipMemcpy(d_code_map, code_map.data(), code_map.size(), hipMemcpyHostToDevice));
    std::vector<uint32_t> row_of(positions + 1, 0);
+   std::vector<uint32_t> row_target;  // of the one-hot rows
    std::vector<uint32_t> escape_first(positions + 1, 0);
    std::vector<uint32_t> escape_first_symbol(n_counters + 1, 0);
    std::vector<SeqStoreHost::Run> runs;
@@ -2613,18 +2714,24 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    uint64_t total_rows = 0;
    bool any_encoded = false;
    for (uint32_t p = 0; p < positions; ++p) {
-      const uint8_t bits = code_map[static_cast<size_t>(p) * CODE_MAP_STRIDE] & 0x7Fu;
-      const bool identity = (code_map[static_cast<size_t>(p) * CODE_MAP_STRIDE] & LAYOUT_IDENTITY) != 0;
+      const uint8_t* map = code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
+      const uint8_t bits = map[0] & 0x3Fu;
+      const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
+      const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
       any_encoded = any_encoded || !identity;
       row_of[p] = static_cast<uint32_t>(total_rows);
       total_rows += bits;
+      for (uint32_t row = 0; row < bits; ++row) {  // a row without a symbol (no valid symbol at the position at all) is empty: any counter of the position
+         row_target.push_back(one_hot ? p * dev.n_scan + (map[1 + row] != 0xFFu ? map[1 + row] : 0u) : 0xFFFFFFFFu);
+      }
       escape_first[p] = static_cast<uint32_t>(total_escapes);
       for (uint32_t symbol = 0; symbol < dev.n_scan; ++symbol) {
          escape_first_symbol[static_cast<size_t>(p) * dev.n_scan + symbol] = static_cast<uint32_t>(total_escapes);
          total_escapes += counts[static_cast<size_t>(p) * dev.n_scan + symbol];
       }
-      if (runs.empty() || runs.back().bits != bits || runs.back().identity != identity) {
-         runs.push_back(SeqStoreHost::Run{p, p + 1, bits, identity});
+      const uint8_t run_bits = one_hot ? 0 : bits;
+      if (runs.empty() || runs.back().bits != run_bits || runs.back().identity != identity || runs.back().one_hot != one_hot) {
+         runs.push_back(SeqStoreHost::Run{p, p + 1, run_bits, identity, one_hot});
       } else {
          runs.back().end = p + 1;
       }
@@ -2649,6 +2756,8 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SILO_LAYOUT_TRY(hipMalloc(&d_escape_first, escape_first.size() * sizeof(uint32_t)));
    SILO_LAYOUT_TRY(hipMemcpy(d_first, escape_first_symbol.data(), escape_first_symbol.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
    SILO_LAYOUT_TRY(hipMemcpy(d_row_of, row_of.data(), row_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMalloc(&d_row_target, std::max<size_t>(row_target.size(), 1) * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMemcpy(d_row_target, row_target.data(), row_target.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
    SILO_LAYOUT_TRY(hipMemcpy(d_escape_first, escape_first.data(), escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
    SILO_LAYOUT_TRY(hipMemset(d_count, 0, n_counters * sizeof(uint32_t)));
    {
@@ -2675,6 +2784,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    store->device_bytes -= build_bytes;
    layout.planes = d_planes;
    layout.d_row_of = d_row_of;
+   layout.d_row_target = d_row_target;
    layout.d_code_map = d_code_map;
    layout.d_escapes = d_escapes;
    layout.d_escape_first = d_escape_first;
@@ -2683,7 +2793,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    layout.escape_first = std::move(escape_first);
    layout.escape_first_symbol = std::move(escape_first_symbol);
    layout.runs = std::move(runs);
-   layout.device_bytes = plane_bytes + escape_bytes + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8);
+   layout.device_bytes = plane_bytes + escape_bytes + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) + total_rows * sizeof(uint32_t);
    store->device_bytes += layout.device_bytes;
    dev.planes = d_planes;
    dev.row_of = d_row_of;
@@ -2777,9 +2887,12 @@ uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqsto
       return 0;
    }
    const SeqStoreHost& seqstore = store->seqstores[seqstore_id];
-   uint64_t positions_with[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // by number of code planes
+   uint64_t positions_with[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // by number of plane rows
    for (const SeqStoreHost::Run& run : seqstore.layout.runs) {
-      positions_with[run.bits & 7u] += run.end - run.begin;
+      for (uint32_t p = run.begin; run.one_hot && p < run.end; ++p) {
+         positions_with[(seqstore.layout.row_of[p + 1] - seqstore.layout.row_of[p]) & 7u] += 1;
+      }
+      positions_with[run.bits & 7u] += run.one_hot ? 0 : run.end - run.begin;
    }
    uint32_t most_common = seqstore.dev.n_bits;
    uint64_t most = 0;

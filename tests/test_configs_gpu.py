@@ -194,9 +194,9 @@ def test_config3_scan_at_10m_adaptive_planes_identity_planes_and_c_port_agree(fu
 
     filt = lineage_filter(store.handle)
     try:
-        assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 2, "the 10 M nucleotide store is expected to be re-encoded into 2 code planes"
+        assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 1, "the 10 M nucleotide store is expected to be re-encoded into one-hot rows"
         rows = int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, positions))
-        assert 2 * positions <= rows < 2.01 * positions  # a few positions keep their 3 identity planes
+        assert positions <= rows < 1.1 * positions  # one row at most positions, 2 rows or 2 code planes where lineages differ
         adaptive = scan_table(lib, store, filt, 0, positions)
         mask = member[lineage].astype(bool)
         assert int(adaptive.sum(axis=1).max()) <= int(mask.sum())

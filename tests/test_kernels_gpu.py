@@ -273,11 +273,29 @@ def skewed_symbols(rng, n, positions, alphabet):
     return out
 
 
+def settle_positions(rng, sym, columns, alphabet, second=0.0002):
+    """Columns where ONE valid symbol has nearly every row, a second valid symbol `second` of them, and the remaining valid
+    symbols 0.01 %, the missing symbol and the ambiguity codes 0.1 %: what most positions of a real alignment look like."""
+    from silo_amd import alphabet as alphabets
+
+    table = alphabets.NUCLEOTIDE if alphabet == "nuc" else alphabets.AMINO_ACID
+    valid = np.array(list(table.valid_mutation_symbols))
+    others = np.array([s for s in range(table.count) if s not in set(valid.tolist())])
+    for p in columns:
+        order = rng.permutation(valid)
+        probs = np.zeros(table.count)
+        probs[order[0]], probs[order[1]] = 0.9989 - second, second
+        probs[order[2:]] = 0.0001 / (len(valid) - 2)
+        probs[others] = 0.001 / len(others)
+        sym[:, p] = rng.choice(table.count, size=len(sym), p=probs / probs.sum())
+
+
 @pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc")])
 def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
-    """finalize() re-encodes alignment-like data into 2 code planes per position + escape keys (and releases the build-time
-    planes); with the re-encoding switched off the store keeps its 3 / 5 identity planes.  Both stores answer every scan
-    (single, batched, sub-ranges, sparse filters, several ranges), every filter leaf and FastaAligned like the naive oracle."""
+    """finalize() re-encodes alignment-like data per position into one-hot rows (1-3 symbols) or 2 code planes (3 symbols)
+    + escape keys, and releases the build-time planes; knob 2 leaves the one-hot rows out, with the re-encoding switched off
+    the store keeps its 3 / 5 identity planes.  All three stores answer every scan (single, batched, sub-ranges, sparse
+    filters, several ranges), every filter leaf and FastaAligned like the naive oracle."""
     rng = np.random.default_rng(n + 17)
     positions = 29
     sym = skewed_symbols(rng, n, positions, alphabet)
@@ -285,12 +303,17 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
     # one position where many symbols are frequent: it keeps more planes than its neighbours (a run of its own)
     table_size = 16 if alphabet == "nuc" else 25
     sym[:, 13] = rng.integers(0, table_size, size=n)
+    # settled positions: one row each as one-hot rows (an odd number of rows in the run), one of them with a second frequent symbol
+    settled = list(range(3, 10)) + list(range(19, 27))
+    settle_positions(rng, sym, settled, alphabet)
+    settle_positions(rng, sym, [22], alphabet, second=0.02)
+    settle_positions(rng, sym2, range(11), alphabet)  # a store that is ONE run of one-hot rows
     chars = NUC_CHARS if alphabet == "nuc" else AA_CHARS
     sparse = np.zeros(n, bool)
     sparse[rng.choice(n, size=9, replace=False)] = True
     masks = [rng.random(n) < 0.4, sparse, np.ones(n, bool), rng.random(n) < 0.02, np.zeros(n, bool)]
     sizes = {}
-    for knob in (0, -1):  # re-encoded, then the identity planes kept
+    for knob in (0, 2, -1):  # re-encoded with and without one-hot rows, then the identity planes kept
         with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:
             store.tune(4, knob)
             try:
@@ -302,15 +325,20 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             sizes[knob] = store.device_bytes
             scan_symbols = list(store.scan_symbols[0])
             full_planes = 3 if alphabet == "nuc" else 5
-            if knob == 0:
+            if knob == 2:
                 assert store.scan_planes(0) == 2 and store.scan_planes(1) == 2
                 rows = store.scan_rows(0, 0, positions)
                 assert 2 * positions < rows <= 2 * (positions - 1) + full_planes  # position 13 keeps more planes
                 assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2
-                valid = np.isin(sym, scan_symbols)
                 assert 0 < store.scan_escapes(0) <= n * positions // 320
                 with pytest.raises(Exception):  # the build-time planes are gone
                     store.append_sequences(0, 0, chars[sym[:1]])
+            elif knob == 0:
+                assert store.scan_rows(1, 0, 11) == 11 and store.scan_planes(1) == 1
+                assert store.scan_rows(0, 3, 10) == 7 and store.scan_rows(0, 19, 27) == 9 and store.scan_rows(0, 22, 23) == 2
+                assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2 and store.scan_rows(0, 0, 3) == 6
+                assert 0 < store.scan_escapes(0) <= n * positions // 320
+                assert store.scan_escapes(1) > store.scan_escapes(0) // 29  # every non-dominant valid symbol of store 1 is a key
             else:
                 assert store.scan_planes(0) == full_planes and store.scan_rows(0, 0, positions) == full_planes * positions
                 assert store.scan_escapes(0) == 0
@@ -328,13 +356,16 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
                 assert np.array_equal(got, table), knob
             assert np.array_equal(store.mutations_scan(0, ptrs[0], 3, 20), dense.mutation_counts(sym, masks[0], scan_symbols, 3, 20))
-            tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6), (0, 13, 14), (0, 12, 15)], ptrs[:3])
+            tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6), (0, 13, 14), (0, 12, 15), (0, 8, 23), (1, 4, 6)], ptrs[:3])
             for q in range(3):
                 assert np.array_equal(tables[0][q], want[q]) and np.array_equal(tables[1][q], want2[q])
                 assert np.array_equal(tables[2][q], want[q][5:6]) and np.array_equal(tables[3][q], want[q][13:14])
-                assert np.array_equal(tables[4][q], want[q][12:15])
+                assert np.array_equal(tables[4][q], want[q][12:15]) and np.array_equal(tables[5][q], want[q][8:23])
+                assert np.array_equal(tables[6][q], want2[q][4:6])
+            for got, table in zip(store.mutations_scan_batch(1, ptrs, 0, 11), want2):
+                assert np.array_equal(got, table), knob
             # every symbol's one-hot plane (filter leaves): coded symbols, escape keys, the missing symbol, sparse symbols
-            for position in (0, 13, positions - 1):
+            for position in (0, 5, 13, 22, positions - 1):
                 for symbol in range(table_size):
                     got = store.plane_download(0, position, symbol)
                     want_plane = dense.pack_bits(sym[:, position] == symbol)
@@ -343,7 +374,7 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             # FastaAligned reads the same planes (and the keys)
             picked = np.concatenate([rng.choice(n, size=40, replace=False), np.nonzero(~np.isin(sym[:, 13], scan_symbols))[0][:5]]).astype(np.uint32)
             assert np.array_equal(store.reconstruct_sequences(0, picked), chars[sym[picked]])
-    assert sizes[0] < 0.85 * sizes[-1]  # 2 planes + the missing-symbol plane instead of 3 / 5 + 1
+    assert sizes[0] < sizes[2] < 0.85 * sizes[-1]  # <= 2 planes + the missing-symbol plane instead of 3 / 5 + 1
 
 
 @pytest.mark.parametrize("n", [900, 140000])

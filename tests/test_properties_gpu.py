@@ -139,7 +139,7 @@ def test_empty_database_and_empty_partition(built):
 
 def test_compact_scan_index_option(built):
     """silo_engine_set_option("compact_scan_index", 0) before finalize: the stores keep their 3 / 5 identity planes instead of
-    the re-encoded 2-plane layout (4/3 of the HBM for a nucleotide store with its missing-symbol plane), same answers."""
+    the re-encoded adaptive layout (about twice the HBM for a nucleotide store with its missing-symbol plane), same answers."""
     import bench
     from silo_amd import binding
     from silo_amd.engine import Engine
@@ -155,7 +155,7 @@ def test_compact_scan_index_option(built):
             with bench.build_engine(200_000, 0, 1, None, 0)[0] as engine:
                 store = engine.partition_store(0)
                 sizes.append(store.device_bytes)
-                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (2 if enabled else 3)
+                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (1 if enabled else 3)
                 answers.append(engine.execute_text(query))
     finally:
         lib.silo_gpu_tune(4, 0)

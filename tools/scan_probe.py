@@ -17,6 +17,7 @@ ap.add_argument("--lineages", type=int, default=2000)
 ap.add_argument("--rows", type=str, default="32,64,128")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--variants", type=str, default="0,10,12")
+ap.add_argument("--side", type=str, default="0", help="SILO_GPU_TUNE_SIDE_STREAM values to try (escape pass: 0 low-priority side stream, 1 default priority, 2 caller's stream)")
 args = ap.parse_args()
 
 n, positions = args.sequences, args.positions
@@ -43,9 +44,11 @@ alg_bytes = positions * 5 * w8 + w8
 counts = store.malloc(4 * positions * 5)
 start, stop = binding.GpuEvent(), binding.GpuEvent()
 reference_counts = None
-for variant, rows in [(int(v), int(r)) for v in args.variants.split(",") for r in args.rows.split(",")]:
+print("plane rows", store.scan_rows(0, 0, positions), "escape keys", store.scan_escapes(0), flush=True)
+for variant, rows, side in [(int(v), int(r), int(s)) for v in args.variants.split(",") for r in args.rows.split(",") for s in args.side.split(",")]:
     store.tune(1, variant)
     store.tune(0, rows)
+    store.tune(5, side)
     best = 1e9
     for rep in range(args.reps + 1):
         store.memset(counts, 0, 4 * positions * 5)
@@ -59,7 +62,7 @@ for variant, rows in [(int(v), int(r)) for v in args.variants.split(",") for r i
     if reference_counts is None:
         reference_counts = c.copy()
     assert np.array_equal(c, reference_counts), "variant changed the counts"
-    print(f"variant={variant:2d} rows_per_block={rows:5d}  {best:8.3f} ms  {alg_bytes / best / 1e6:8.1f} GB/s  "
+    print(f"variant={variant:2d} rows_per_block={rows:5d} side={side}  {best:8.3f} ms  {alg_bytes / best / 1e6:8.1f} GB/s  "
           f"{n * positions / best / 1e9 * 1e3:.3e} pos*seq/s  kernel={store.last_scan_kernel()}", flush=True)
 c = store.read(counts, np.uint32, positions * 5).reshape(positions, 5)
 print("checksum", int(c.sum()), "total@pos1000", c[1000])
