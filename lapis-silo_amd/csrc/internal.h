@@ -12,6 +12,9 @@ int silo_gpu_internal_fail(int code, const std::string& message);
 /// Sorts n 64-bit keys in device memory ascending, in place (silo_gpu_sort.hip); synchronises the null stream.
 int silo_gpu_internal_sort_keys(uint64_t* keys_dev, size_t n);
 
+/// The same by the key bits [begin_bit, end_bit) only; stable (keys equal in those bits keep their order).
+int silo_gpu_internal_sort_keys_by_bits(uint64_t* keys_dev, size_t n, int begin_bit, int end_bit);
+
 #define SILO_HIP_TRY(expr)                                                                                  \
    do {                                                                                                     \
       hipError_t err_ = (expr);                                                                             \

@@ -36,7 +36,8 @@ std::atomic<int> g_tune_rows_per_block{0};
 std::atomic<int> g_tune_scan_variant{0};
 std::atomic<int> g_tune_eval_leaf_batch{0};
 std::atomic<int> g_tune_compact_index{0};  // < 0: never scan the compact index (K1i), even where one was built
-std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream of the lowest priority, 1 = of default priority, 2 = the caller's stream
+std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream of the lowest priority, 1 = of default priority, 2 = the caller's stream, 3 = as 0 with the position-major keys (k_scan_escapes)
+std::atomic<int> g_tune_key_cost{0};        // > 0: what an escape key costs in plane bytes in the layout choice (default KEY_COST_BYTES)
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
 int fail(int code, const std::string& msg) {
@@ -237,6 +238,13 @@ struct SeqStoreHost {
       uint8_t* d_code_map = nullptr;
       uint64_t* d_escapes = nullptr;
       uint32_t* d_escape_first = nullptr;
+      // the same keys once more, SLICE-major: slice = sequence >> slice_shift, (position, symbol, sequence) order within a
+      // slice — what the scan's escape pass streams, a slice of the filter in LDS (k_scan_escapes_sliced)
+      uint64_t* d_escapes_sliced = nullptr;
+      uint32_t slice_shift = 0;
+      uint32_t n_slices = 0;
+      uint32_t* d_slice_first = nullptr;          // [n_slices][P + 1] first key of a position within a slice
+      std::vector<uint32_t> slice_first;          // host copy
       std::vector<uint32_t> row_of;               // [P + 1]
       std::vector<uint8_t> code_map;              // [P][CODE_MAP_STRIDE]
       std::vector<uint32_t> escape_first;         // [P + 1]
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
 // missing-symbol plane) and every consumer — the scan, the sparse-filter gather, filter leaves, FastaAligned — reads the
 // adaptive planes.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t KEY_COST_BYTES = 40;
+constexpr uint32_t KEY_COST_BYTES = 16;
 
 /// Re-encodes the build-time planes of every position into its adaptive layout; rows without a code go, with an atomic
 /// cursor per (position, symbol), into that counter's exactly sized slice of the key list (sorted afterwards).
@@ -927,6 +935,114 @@ __global__ __launch_bounds__(256) void k_scan_escapes(
          }
       }
    }
+}
+
+/// The escape pass over the SLICE-major copy of the keys.  A key costs one filter-bit lookup, and 64 lanes looking up 64
+/// rows of a 1.25 MB filter pull 64 cache lines through the L2 for 64 bits (45 M keys: 5.8 GB of line traffic, 0.28 ms —
+/// as much as 40 plane bytes per key).  Here a block owns one slice of the rows, copies that slice of the filter into LDS
+/// (64 KiB for 2^19 rows) and streams the slice's keys of the scanned positions against it: a lookup is an LDS read.
+constexpr uint32_t ESCAPE_SLICE_SHIFT = 19;                    // 2^19 rows = 8192 filter words = 64 KiB of LDS
+constexpr uint32_t ESCAPE_SLICE_WORDS32 = (1u << ESCAPE_SLICE_SHIFT) / 32u;
+constexpr uint32_t ESCAPE_MAX_SLICES = 64;
+constexpr uint32_t ESCAPE_SLICE_THREADS = 1024;
+constexpr uint32_t ESCAPE_KEYS_IN_FLIGHT = 16;                 // per thread: the key loads of a chunk are all issued before the first is used
+constexpr uint32_t ESCAPE_CHUNK_KEYS = ESCAPE_SLICE_THREADS * ESCAPE_KEYS_IN_FLIGHT;
+constexpr uint32_t ESCAPE_MAX_RANGES = 16;
+/// One launch for up to ESCAPE_MAX_RANGES position ranges (the 12 genes of an AminoAcidMutations query): grid =
+/// (blocks per slice, slice x range, filter).  Block j of a (range, slice) takes the chunks j, j + gridDim.x, ... of that
+/// slice's keys of the scanned positions; where those begin and end is read from the store's slice index on the device.
+struct EscapeSliceArgs {
+   const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
+   uint32_t row_words;
+   uint32_t n_slices;
+   uint32_t out_symbols;
+   struct Range {
+      const uint64_t* keys;          // slice-major keys of the store
+      const uint32_t* slice_first;   // [n_slices][positions + 1]
+      uint32_t positions;
+      uint32_t pos_begin;
+      uint32_t pos_end;
+      uint32_t* counts[SILO_GPU_MAX_SCAN_BATCH];  // of the range's first position
+   } ranges[ESCAPE_MAX_RANGES];
+};
+
+__global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(const EscapeSliceArgs args) {
+   __shared__ uint32_t s_filter[ESCAPE_SLICE_WORDS32];
+   const uint32_t q = blockIdx.z;
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t slice = blockIdx.y % args.n_slices;
+   const EscapeSliceArgs::Range& range = args.ranges[blockIdx.y / args.n_slices];
+   const uint32_t* first = range.slice_first + static_cast<size_t>(slice) * (range.positions + 1u);
+   const uint32_t key_begin = first[range.pos_begin];
+   const uint32_t key_end = first[range.pos_end];
+   if (key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS >= key_end) {
+      return;  // (uniform) no chunk for this block
+   }
+   {  // this slice of the filter: 8 words (4 x 16 bytes) per thread, zeros past the end of the row
+      const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
+      const uint64_t* filter = args.filters[q];
+#pragma unroll
+      for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS; ++j) {
+         const uint32_t chunk = j * ESCAPE_SLICE_THREADS + threadIdx.x;  // 16-byte chunk of the slice
+         const uint32_t word = first_word + chunk * 2u;
+         const ulonglong2 v = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
+         *reinterpret_cast<ulonglong2*>(s_filter + chunk * 4u) = v;
+      }
+   }
+   __syncthreads();
+   const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
+   uint32_t* __restrict__ counts = range.counts[q];
+   for (uint32_t base = key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS; base < key_end; base += gridDim.x * ESCAPE_CHUNK_KEYS) {  // uniform per block
+      uint64_t key[ESCAPE_KEYS_IN_FLIGHT];
+#pragma unroll
+      for (uint32_t k = 0; k < ESCAPE_KEYS_IN_FLIGHT; ++k) {
+         const uint32_t i = base + k * ESCAPE_SLICE_THREADS + threadIdx.x;
+         key[k] = i < key_end ? __builtin_nontemporal_load(range.keys + i) : ~0ull;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < ESCAPE_KEYS_IN_FLIGHT; ++k) {
+         const bool valid = key[k] != ~0ull;  // (no key is all ones: the symbol field holds at most 21)
+         const uint32_t local = valid ? static_cast<uint32_t>(key[k]) - slice_first_row : 0u;
+         bool pending = valid && ((s_filter[local >> 5] >> (local & 31u)) & 1u) != 0;
+         // keys of one (position, symbol) sit together: one atomic per distinct counter and wave, not per key
+         const uint32_t counter = (static_cast<uint32_t>(key[k] >> 37) - range.pos_begin) * args.out_symbols + (static_cast<uint32_t>(key[k] >> 32) & 31u);
+         for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
+            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
+            const uint32_t leader_counter = __shfl(counter, leader);
+            const uint64_t same = __ballot(pending && counter == leader_counter);
+            if (lane == leader) {
+               atomicAdd(&counts[leader_counter], static_cast<uint32_t>(__popcll(same)));
+            }
+            if (counter == leader_counter) {
+               pending = false;
+            }
+         }
+      }
+   }
+}
+
+/// first[slice][p] = index of the first slice-major key of (slice, position >= p): a binary search per entry.
+__global__ __launch_bounds__(256) void k_slice_index(
+   const uint64_t* __restrict__ keys, uint32_t n_keys, uint32_t slice_shift, uint32_t n_slices, uint32_t positions, uint32_t* __restrict__ first
+) {
+   const uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x;
+   if (entry >= n_slices * (positions + 1u)) {
+      return;
+   }
+   const uint32_t slice = entry / (positions + 1u);
+   const uint32_t position = entry % (positions + 1u);
+   uint32_t lo = 0, hi = n_keys;
+   while (lo < hi) {  // keys before (slice, position): a smaller slice, or the same slice and a smaller position
+      const uint32_t mid = lo + (hi - lo) / 2;
+      const uint32_t key_slice = static_cast<uint32_t>(keys[mid]) >> slice_shift;
+      const uint32_t key_position = static_cast<uint32_t>(keys[mid] >> 37);
+      if (key_slice < slice || (key_slice == slice && key_position < position)) {
+         lo = mid + 1;
+      } else {
+         hi = mid;
+      }
+   }
+   first[entry] = lo;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1602,6 +1718,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_SIDE_STREAM) {
       return g_tune_side_stream.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_KEY_COST) {
+      return g_tune_key_cost.exchange(value);
+   }
    return -1;
 }
 
@@ -1724,6 +1843,8 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.layout.d_row_target);
       (void)hipFree(seqstore.layout.d_code_map);
       (void)hipFree(seqstore.layout.d_escapes);
+      (void)hipFree(seqstore.layout.d_escapes_sliced);
+      (void)hipFree(seqstore.layout.d_slice_first);
       (void)hipFree(seqstore.layout.d_escape_first);
    }
    (void)hipFree(store->d_ones);
@@ -2379,6 +2500,22 @@ int scanPiecesDense(
 /// The rows the code planes do not carry: one pass over the escape keys of every range, for all filters (dense and
 /// sparse alike: the gather reads the same planes).
 int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream) {
+   // the ranges whose stores have slice-major keys go ESCAPE_MAX_RANGES at a time into one launch of k_scan_escapes_sliced
+   EscapeSliceArgs sliced{};
+   uint32_t n_sliced = 0;
+   uint32_t most_chunks = 0;  // of one (range, slice)
+   const auto launchSliced = [&]() -> int {
+      if (n_sliced == 0) {
+         return SILO_GPU_OK;
+      }
+      // at most two chunks per block: short blocks keep the launch balanced whatever the slices hold
+      const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, q_count);
+      k_scan_escapes_sliced<<<grid, ESCAPE_SLICE_THREADS, 0, hip_stream>>>(sliced);
+      HIP_TRY(hipGetLastError());
+      n_sliced = 0;
+      most_chunks = 0;
+      return SILO_GPU_OK;
+   };
    for (const ScanRange& range : ranges) {
       const SeqStoreHost::Layout& layout = range.seqstore->layout;
       if (!layout.built || layout.d_escapes == nullptr) {
@@ -2387,6 +2524,32 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       const uint32_t begin = layout.escape_first[range.pos_begin];
       const uint32_t count = layout.escape_first[range.pos_end] - begin;
       if (count == 0) {
+         continue;
+      }
+      if (layout.d_escapes_sliced != nullptr && g_tune_side_stream.load() != 3) {  // the slice-major keys, a slice of the filter in LDS
+         if (n_sliced == ESCAPE_MAX_RANGES || (n_sliced != 0 && sliced.n_slices != layout.n_slices)) {
+            if (const int rc = launchSliced(); rc != SILO_GPU_OK) {
+               return rc;
+            }
+         }
+         sliced.row_words = range.seqstore->dev.row_words;
+         sliced.n_slices = layout.n_slices;
+         sliced.out_symbols = range.seqstore->dev.n_scan;
+         EscapeSliceArgs::Range& entry = sliced.ranges[n_sliced++];
+         entry.keys = layout.d_escapes_sliced;
+         entry.slice_first = layout.d_slice_first;
+         entry.positions = range.seqstore->dev.positions;
+         entry.pos_begin = range.pos_begin;
+         entry.pos_end = range.pos_end;
+         for (uint32_t q = 0; q < q_count; ++q) {
+            sliced.filters[q] = filters[q];
+            entry.counts[q] = range.counts[q];
+         }
+         const size_t stride = static_cast<size_t>(entry.positions) + 1;
+         for (uint32_t slice = 0; slice < layout.n_slices; ++slice) {
+            const uint32_t keys = layout.slice_first[slice * stride + range.pos_end] - layout.slice_first[slice * stride + range.pos_begin];
+            most_chunks = std::max(most_chunks, (keys + ESCAPE_CHUNK_KEYS - 1) / ESCAPE_CHUNK_KEYS);
+         }
          continue;
       }
       ScanBatchArgs escapes{};
@@ -2401,7 +2564,7 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       );
       HIP_TRY(hipGetLastError());
    }
-   return SILO_GPU_OK;
+   return launchSliced();
 }
 
 /// scanEscapes on side stream 0: forked behind everything already queued on `hip_stream` (the filters are complete, the
@@ -2529,6 +2692,7 @@ void chooseLayouts(
 ) {
    enum { TWO_PLANES = 0, THREE_PLANES = 1, IDENTITY = 2, ONE_HOT = 3, N_LAYOUTS = 4 };
    constexpr uint64_t NEVER = ~0ull >> 2;
+   const uint64_t key_cost = g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES;
    const uint64_t run_cost = 2 * row_bytes;
    std::vector<uint8_t> best(static_cast<size_t>(positions) * 7, 0xFF);   // the seven most frequent valid symbols, most frequent first
    std::vector<uint8_t> one_hot_rows(positions, 1);                       // rows of the position as a one-hot one
@@ -2557,15 +2721,15 @@ void chooseLayouts(
          }
       }
       uint64_t* position_cost = cost.data() + static_cast<size_t>(p) * N_LAYOUTS;
-      position_cost[TWO_PLANES] = 2 * row_bytes + KEY_COST_BYTES * (total - carried[3]);
+      position_cost[TWO_PLANES] = 2 * row_bytes + key_cost * (total - carried[3]);
       // three mapped planes only pay where the identity layout has more (amino acids)
-      position_cost[THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + KEY_COST_BYTES * (total - carried[7]) : NEVER;
+      position_cost[THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + key_cost * (total - carried[7]) : NEVER;
       // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped layouts
       position_cost[IDENTITY] = n_bits > 3 ? n_bits * row_bytes * 115 / 100 : n_bits * row_bytes;
       // k rows, one per symbol: one row where one symbol has (nearly) all rows — most positions of a real alignment
       position_cost[ONE_HOT] = NEVER;
       for (uint32_t k = 1; allow_one_hot && k <= 3; ++k) {
-         const uint64_t with_k = k * row_bytes + KEY_COST_BYTES * (total - carried[k]);
+         const uint64_t with_k = k * row_bytes + key_cost * (total - carried[k]);
          if (with_k < position_cost[ONE_HOT]) {
             position_cost[ONE_HOT] = with_k;
             one_hot_rows[p] = static_cast<uint8_t>(k);
@@ -2745,7 +2909,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SILO_LAYOUT_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
    // both representations are resident until the re-encoding is done; the sort of the keys needs as much again as the keys
    if (!any_encoded || total_rows >= (uint64_t{1} << 32) || total_escapes >= (uint64_t{1} << 32) ||
-       free_bytes < plane_bytes + 3 * escape_bytes + (size_t{1} << 30)) {
+       free_bytes < plane_bytes + 4 * escape_bytes + (size_t{1} << 30)) {
       discard();
       return keepBuildPlanes();
    }
@@ -2774,6 +2938,40 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
       discard();
       return rc;
    }
+   // the slice-major copy of the keys for the scan's escape pass, and where each position's keys begin in every slice
+   uint64_t* d_escapes_sliced = nullptr;
+   uint32_t* d_slice_first = nullptr;
+   std::vector<uint32_t> slice_first;
+   const uint32_t n_slices = (store->sequence_count + (1u << ESCAPE_SLICE_SHIFT) - 1) >> ESCAPE_SLICE_SHIFT;
+   if (total_escapes > 0 && n_slices <= ESCAPE_MAX_SLICES) {
+      const size_t n_entries = static_cast<size_t>(n_slices) * (positions + 1);
+      const auto discardSliced = [&]() {
+         (void)hipFree(d_escapes_sliced);
+         (void)hipFree(d_slice_first);
+      };
+      hipError_t status = hipMalloc(&d_escapes_sliced, escape_bytes);
+      status = status != hipSuccess ? status : hipMalloc(&d_slice_first, n_entries * sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMemcpy(d_escapes_sliced, d_escapes, total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+      if (status != hipSuccess) {
+         discardSliced();
+         SILO_LAYOUT_TRY(status);
+      }
+      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + 6); rc != SILO_GPU_OK) {
+         discardSliced();
+         discard();
+         return rc;
+      }
+      k_slice_index<<<static_cast<uint32_t>((n_entries + 255) / 256), 256>>>(
+         d_escapes_sliced, static_cast<uint32_t>(total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
+      );
+      slice_first.resize(n_entries);
+      status = hipGetLastError();
+      status = status != hipSuccess ? status : hipMemcpy(slice_first.data(), d_slice_first, n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (status != hipSuccess) {
+         discardSliced();
+         SILO_LAYOUT_TRY(status);
+      }
+   }
 #undef SILO_LAYOUT_TRY
    (void)hipFree(d_first);
    (void)hipFree(d_count);
@@ -2787,13 +2985,19 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    layout.d_row_target = d_row_target;
    layout.d_code_map = d_code_map;
    layout.d_escapes = d_escapes;
+   layout.d_escapes_sliced = d_escapes_sliced;
+   layout.d_slice_first = d_slice_first;
+   layout.slice_shift = ESCAPE_SLICE_SHIFT;
+   layout.n_slices = d_escapes_sliced != nullptr ? n_slices : 0;
+   layout.slice_first = std::move(slice_first);
    layout.d_escape_first = d_escape_first;
    layout.row_of = std::move(row_of);
    layout.code_map = std::move(code_map);
    layout.escape_first = std::move(escape_first);
    layout.escape_first_symbol = std::move(escape_first_symbol);
    layout.runs = std::move(runs);
-   layout.device_bytes = plane_bytes + escape_bytes + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) + total_rows * sizeof(uint32_t);
+   layout.device_bytes = plane_bytes + escape_bytes * (d_escapes_sliced != nullptr ? 2 : 1) + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
+                         total_rows * sizeof(uint32_t);
    store->device_bytes += layout.device_bytes;
    dev.planes = d_planes;
    dev.row_of = d_row_of;

@@ -2,25 +2,30 @@
 // that the kernel file does not pay for the template instantiation on every rebuild.  Used once per sequence store at
 // finalize: the escape keys position << 37 | symbol << 32 | sequence of the adaptive code planes are put in ascending
 // order, which groups them by (position, symbol) for the scan's escape pass and makes a (position, symbol, sequence)
-// lookup a binary search (FastaAligned).
+// lookup a binary search (FastaAligned); a second, STABLE pass over a few sequence bits then gives the slice-major copy of
+// the keys that the scan's escape pass streams (keys of one slice of the rows together, (position, symbol, sequence) within).
 #include <hipcub/hipcub.hpp>
 
 #include "internal.h"
 
 int silo_gpu_internal_sort_keys(uint64_t* keys_dev, size_t n) {
-   if (n < 2) {
+   return silo_gpu_internal_sort_keys_by_bits(keys_dev, n, 0, 64);
+}
+
+int silo_gpu_internal_sort_keys_by_bits(uint64_t* keys_dev, size_t n, int begin_bit, int end_bit) {
+   if (n < 2 || begin_bit >= end_bit) {
       return SILO_GPU_OK;
    }
    uint64_t* sorted = nullptr;
    void* scratch = nullptr;
    size_t scratch_bytes = 0;
    SILO_HIP_TRY(hipMalloc(&sorted, n * sizeof(uint64_t)));
-   hipError_t status = hipcub::DeviceRadixSort::SortKeys(nullptr, scratch_bytes, keys_dev, sorted, n, 0, 64, nullptr);
+   hipError_t status = hipcub::DeviceRadixSort::SortKeys(nullptr, scratch_bytes, keys_dev, sorted, n, begin_bit, end_bit, nullptr);
    if (status == hipSuccess) {
       status = hipMalloc(&scratch, scratch_bytes);
    }
    if (status == hipSuccess) {
-      status = hipcub::DeviceRadixSort::SortKeys(scratch, scratch_bytes, keys_dev, sorted, n, 0, 64, nullptr);
+      status = hipcub::DeviceRadixSort::SortKeys(scratch, scratch_bytes, keys_dev, sorted, n, begin_bit, end_bit, nullptr);
    }
    if (status == hipSuccess) {
       status = hipMemcpy(keys_dev, sorted, n * sizeof(uint64_t), hipMemcpyDeviceToDevice);

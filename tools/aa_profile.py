@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The AminoAcidMutations query over all 12 genes (BASELINE.json configs[3], amino-acid leg) on the one-GPU database, for
-`rocprofv3 --kernel-trace`: layout of every gene, then the query `reps` times.  usage: aa_profile.py [sequences] [reps]"""
+`rocprofv3 --kernel-trace`: layout of every gene, then the query `reps` times.  usage: aa_profile.py [sequences] [reps] [nucleotide stub positions] [escape-pass modes]"""
 import json
 import os
 import sys
@@ -14,6 +14,7 @@ from silo_amd import binding  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 nuc_stub = int(sys.argv[3]) if len(sys.argv) > 3 else None
+side_modes = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]  # SILO_GPU_TUNE_SIDE_STREAM values to time
 lib = binding.load_library()
 t0 = time.time()
 engine, model, tree, lineage, window = bench.build_engine(n, 0, 1, None, 0, with_genes=True, nuc_positions=nuc_stub)
@@ -25,9 +26,12 @@ for gene in bench.load_reference_genomes(True)["genes"]:
     rows = int(lib.silo_gpu_store_scan_rows(store.handle, sid, 0, length))
     print(f"{gene['name']:6s} P={length:5d} rows/position {rows / length:.2f} escapes {int(lib.silo_gpu_store_scan_escapes(store.handle, sid))}")
 query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05}, "filterExpression": json.loads(bench.make_query())["filterExpression"]}).encode()
-engine.execute_text(query)
-t0 = time.perf_counter()
-for _ in range(reps):
+for side in side_modes:
+    lib.silo_gpu_tune(5, side)
     engine.execute_text(query)
-print(f"AminoAcidMutations: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per query", flush=True)
-print(json.dumps(engine.last_trace()))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        engine.execute_text(query)
+    print(f"AminoAcidMutations (escape pass mode {side}): {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per query", flush=True)
+    print(json.dumps(engine.last_trace()))
+lib.silo_gpu_tune(5, 0)
