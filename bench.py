@@ -90,7 +90,8 @@ def make_query():
 
 
 def time_kernel(engine, tree, window, reps):
-    """Average duration of one k_scan_sliced launch over this rank's window, HIP events on the null stream."""
+    """Average duration of one Mutations scan over this rank's window (HIP events on the null stream, where the scan is
+    launched), and of every k_scan_sliced launch inside it (time_kernel.per_launch)."""
     import ctypes
 
     from silo_amd import binding
@@ -114,7 +115,24 @@ def time_kernel(engine, tree, window, reps):
     stop.record()
     ms = start.elapsed_ms(stop) / reps
     kernel = lib.silo_gpu_last_scan_kernel().decode()
+    # the dominant launch by itself: HIP events around every k_scan_sliced launch of `reps` more scans (on the stream the
+    # kernels are launched on), averaged per kernel instantiation
+    launches = {}
+    previous = lib.silo_gpu_tune(7, 1)  # SILO_GPU_TUNE_SCAN_TIMING
+    try:
+        for _ in range(reps):
+            binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, 0, n_positions, counts, None))
+            for entry in binding.scan_timings():
+                slot = launches.setdefault(entry["kernel"], dict(kernel=entry["kernel"], plane_rows=entry["plane_rows"], blocks=entry["blocks"], ms=[]))
+                slot["ms"].append(entry["ms"])
+    finally:
+        lib.silo_gpu_tune(7, previous)
+    per_launch = sorted(({**v, "launches": len(v["ms"]), "ms": sum(v["ms"]) / len(v["ms"])} for v in launches.values()), key=lambda v: -v["ms"])
+    time_kernel.per_launch = per_launch
     return ms, kernel, store, filt, counts
+
+
+time_kernel.per_launch = []
 
 
 def cpu_share():
@@ -426,6 +444,39 @@ def batch_workload(engine, positions, n_sequences, sync, reps=5):
     }
 
 
+def config4_workload(engine, tree, reference_text, positions, aa_positions, n_sequences, sync, reps=3):
+    """BASELINE.json configs[4] as ONE of its 8 sequence-id shards sees it (50 M sequences over 8 GPUs = 6.25 M rows per
+    GPU, genome + genes resident): one silo_engine_execute_batch of 100 distinct lineage filters (every fourth AND a
+    nucleotide predicate), each with a Mutations and an AminoAcidMutations action — 200 queries whose scans share passes
+    over the planes, 8 filters at a time (K1c).  The all-reduce of the count tables across shards is not part of it."""
+    queries = []
+    for k, name in enumerate(tree.names[1:101]):
+        expression = {"type": "PangoLineage", "column": "pango_lineage", "value": name, "includeSublineages": True}
+        if k % 4 == 3:
+            position = 1000 + 257 * k
+            expression = {"type": "And", "children": [expression, {"type": "NucleotideEquals", "position": position, "symbol": reference_text[position - 1]}]}
+        for action in ("Mutations", "AminoAcidMutations"):
+            queries.append(json.dumps({"action": {"type": action, "minProportion": 0.05}, "filterExpression": expression}).encode())
+    batched = engine.execute_batch_text(queries)
+    if batched[:6] != [engine.execute_text(q) for q in queries[:6]] or any(status != 200 for status, _ in batched):
+        raise AssertionError("batched results differ from one-by-one results")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        engine.execute_batch_text(queries)
+    sync()
+    seconds = (time.perf_counter() - t0) / reps
+    return {
+        "workload": f"BASELINE.json configs[4], one of 8 sequence-id shards: {n_sequences} sequences (genome + 12 genes), ONE batch of 100 lineage filters "
+                    "(every fourth AND a nucleotide predicate) x (Mutations + AminoAcidMutations) = 200 queries; no collective",
+        "queries": len(queries),
+        "ms_per_batch": seconds * 1e3,
+        "value": (len(queries) // 2) * n_sequences * (positions + aa_positions) / seconds,
+        "unit": "positions*sequences/s",
+        "queries_per_s": len(queries) / seconds,
+    }
+
+
 def selective_workload(engine, lib, tree, lineage, positions, n_sequences, sync, reps=20):
     """Mutations under SELECTIVE filters (one exact lineage: a few thousand rows scattered over the store): the dense
     scan would cost the same 16 ms whatever the filter selects; K1s gathers only the 64-byte sectors of the planes
@@ -659,8 +710,12 @@ def main():
     scan_rows = int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, n_local))  # plane rows of the adaptive layout, all positions
     scan_escapes = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
     alg_bytes = n_local * 5 * w8 + w8
-    physical_bytes = scan_rows * w8 + w8 + 8 * scan_escapes
-    physical_gbps = physical_bytes / (kernel_ms * 1e-3) / 1e9
+    physical_bytes = scan_rows * w8 + w8 + 8 * scan_escapes          # of the whole scan: every plane-scan launch + the escape pass
+    scan_gbps = physical_bytes / (kernel_ms * 1e-3) / 1e9
+    # the dominant launch by itself (HIP events around that launch): its plane rows, each read once, and the filter row
+    dominant = time_kernel.per_launch[0] if time_kernel.per_launch else dict(kernel=kernel_name, plane_rows=scan_rows, ms=kernel_ms, blocks=0, launches=0)
+    dominant_bytes = dominant["plane_rows"] * w8 + w8
+    physical_gbps = dominant_bytes / (dominant["ms"] * 1e-3) / 1e9
     # HBM traffic per launch is a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     # the microarchitecture guide prescribes); counters cannot be read from inside this process, so the value is the one
     # on file for exactly this launch shape — labelled with its source — or null.
@@ -670,9 +725,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
             name, _, grid = key.rpartition("@")
-            # the dominant launch: pairs of one-hot rows (k_scan_sliced<2, 2, ...>) where most positions take one row
-            prefix = "k_scan_sliced<2, 2," if scan_planes == 1 else f"k_scan_sliced<{scan_planes},"
-            if name.startswith(prefix) and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
+            if name == dominant["kernel"] and grid == str(dominant["blocks"] * 256) and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
                 traffic = entry["hbm_bytes"]
                 traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
     except (OSError, ValueError, KeyError):
@@ -702,10 +755,12 @@ def main():
             "reference_phases_us": {"filter": filter_us, "action": action_us},
         },
         "roofline": {
-            # achieved / frac: the bytes this launch asks of the HBM interface (its physical bytes) / kernel time / peak.
-            # The layout-independent algorithmic figure of SURVEY.md §8(d) (5 one-hot symbol columns per position + the
-            # filter, 0.625 B per position x sequence) is kept beside it with the byte-reduction factor of the layout:
-            # algorithmic bytes / time exceeds the peak precisely because the scan moves 2.5x fewer bytes than that model.
+            # The dominant kernel of the step — the k_scan_sliced launch over the runs of one-hot rows — by itself:
+            # achieved = the bytes that launch has to read (its plane rows once + the filter row) / its own duration (HIP
+            # events around the launch, on its stream), frac = achieved / peak.  The whole scan of the query (every
+            # plane-scan launch + the escape-key pass) and the layout-independent algorithmic figure of SURVEY.md §8(d)
+            # (5 one-hot symbol columns per position + the filter, 0.625 B per position x sequence) are kept beside it;
+            # algorithmic bytes / time exceeds the peak precisely because the scan moves `byte_reduction` x fewer bytes.
             "bound": "hbm",
             "achieved": physical_gbps,
             "peak": HBM_PEAK_GBS,
@@ -713,16 +768,23 @@ def main():
             "frac": physical_gbps / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": kernel_name,
-            "kernel_ms": kernel_ms,
-            "physical_bytes_per_launch": physical_bytes,
-            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel": dominant["kernel"],
+            "kernel_ms": dominant["ms"],
+            "kernel_launches_timed": dominant["launches"],
+            "kernel_plane_rows": dominant["plane_rows"],
+            "physical_bytes_per_launch": dominant_bytes,
+            "launches_per_scan": [{"kernel": v["kernel"], "ms": v["ms"], "plane_rows": v["plane_rows"], "blocks": v["blocks"]} for v in time_kernel.per_launch],
+            "scan_ms": kernel_ms,
+            "scan_physical_bytes": physical_bytes,
+            "scan_GBps": scan_gbps,
+            "scan_frac": scan_gbps / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_scan": alg_bytes,
             "algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
             "byte_reduction": alg_bytes / physical_bytes,
             "scan_planes_per_position": scan_planes,
             "plane_rows": scan_rows,
-            "escape_keys": scan_escapes,
             "plane_rows_per_position": scan_rows / max(1, n_local),
+            "escape_keys": scan_escapes,
             "layout": ("adaptive planes, chosen per position at finalize: ONE one-hot row of the position's most frequent valid symbol (two or three "
                        "rows where a second / third symbol is frequent), or 2 code planes (codes 1..3 = the 3 most frequent), the other rows as "
                        "escape keys; positions where neither pays keep 3 identity planes" if scan_planes == 1 else
@@ -814,6 +876,11 @@ def main():
         lib.silo_gpu_free(filt1)
         lib.silo_gpu_free(counts1)
         engine1.close()
+        if args.sequences == 10_000_000:
+            engine4, _, tree4, _, _ = build_engine(6_250_000, 0, 1, None, local_rank, with_genes=True)
+            reference_text = load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
+            result["also_config4_shard"] = config4_workload(engine4, tree4, reference_text, positions, aa_positions, 6_250_000, sync)
+            engine4.close()
 
     if use_dist:
         dist.barrier()

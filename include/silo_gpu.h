@@ -402,6 +402,7 @@ enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SI
        SILO_GPU_TUNE_COMPACT_INDEX = 4 /* finalize: < 0 keeps the build-time identity planes, 0 (default) re-encodes every position into its cheapest
                                           layout (one-hot rows, 2 / 3 code planes, identity planes), 2 the same without one-hot rows */,
        SILO_GPU_TUNE_KEY_COST = 6 /* finalize: > 0 = the cost of an escape key, in plane bytes, in the choice of layouts (experiments) */,
+       SILO_GPU_TUNE_SCAN_TIMING = 7 /* 1: bracket every plane-scan launch with HIP events (silo_gpu_scan_timings) */,
        SILO_GPU_TUNE_SIDE_STREAM = 5 /* the escape-key pass of a scan: 0 (default) on a side stream of the lowest priority, 1 of default priority, 2 on the caller's stream */,
        SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };
 int silo_gpu_tune(int knob, int value);
@@ -438,6 +439,19 @@ int silo_gpu_broadcast_bytes(silo_gpu_comm* comm, void* bytes_dev, size_t n_byte
 
 /* Name of the last kernel variant silo_gpu_mutations_scan launched (for roofline attribution). */
 const char* silo_gpu_last_scan_kernel(void);
+
+/* Per-launch timing of the plane scans (measurement only).  With SILO_GPU_TUNE_SCAN_TIMING set to 1, every k_scan_sliced
+ * launch of the calling thread's scans is bracketed by HIP events on the stream it is launched on; this call waits for the
+ * events of that thread's LAST scan and returns one entry per launch (at most `capacity`; *n_out = launches).  plane_rows =
+ * plane rows the launch streams (each once, row_words * 8 bytes), filters = filter rows it holds in registers. */
+typedef struct silo_gpu_scan_timing {
+   char kernel[64];       /* e.g. "k_scan_sliced<2, 2, 8, 1, 2>", as rocprofv3 names it */
+   uint64_t plane_rows;
+   uint32_t filters;
+   uint32_t blocks;
+   float ms;
+} silo_gpu_scan_timing;
+int silo_gpu_scan_timings(silo_gpu_scan_timing* out, uint32_t capacity, uint32_t* n_out);
 
 /* Thread-local description of the last error. */
 const char* silo_gpu_last_error(void);

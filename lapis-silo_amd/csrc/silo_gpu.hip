@@ -11,6 +11,7 @@
 //   B2  k_generate_synthetic            synthetic planes for the benchmarks
 // Everything is 64-bit integer AND / OR / popcount: HBM-bound, no MFMA.
 #include <hip/hip_runtime.h>
+
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -37,6 +38,7 @@ std::atomic<int> g_tune_scan_variant{0};
 std::atomic<int> g_tune_eval_leaf_batch{0};
 std::atomic<int> g_tune_compact_index{0};  // < 0: never scan the compact index (K1i), even where one was built
 std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream of the lowest priority, 1 = of default priority, 2 = the caller's stream, 3 = as 0 with the position-major keys (k_scan_escapes)
+std::atomic<int> g_tune_scan_timing{0};     // 1: HIP events around every plane-scan launch (silo_gpu_scan_timings)
 std::atomic<int> g_tune_key_cost{0};        // > 0: what an escape key costs in plane bytes in the layout choice (default KEY_COST_BYTES)
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
@@ -1721,6 +1723,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_KEY_COST) {
       return g_tune_key_cost.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_SCAN_TIMING) {
+      return g_tune_scan_timing.exchange(value);
+   }
    return -1;
 }
 
@@ -2244,6 +2249,22 @@ void cutIntoPieces(const std::vector<ScanRange>& ranges, uint32_t q_count, std::
    }
 }
 
+/// Event pairs around the plane-scan launches of this thread's last scan (SILO_GPU_TUNE_SCAN_TIMING); the events are
+/// created once and reused.
+struct ScanLaunchTiming {
+   hipEvent_t start = nullptr;
+   hipEvent_t stop = nullptr;
+   silo_gpu_scan_timing entry{};
+};
+struct ScanTimingLog {
+   std::vector<ScanLaunchTiming> launches;
+   size_t used = 0;
+};
+ScanTimingLog& scanTimingLog() {
+   thread_local ScanTimingLog log;
+   return log;
+}
+
 /// Launches k_scan_sliced for the `q_count` filters and the pieces already entered in `batch` (planes, n_positions, counts).
 template <int BITS, int NSYM, int KIND>
 int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
@@ -2285,6 +2306,28 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
       batch.first_unit[r + 1] = batch.first_unit[r] + n_tiles * ((units(r) + positions_per_block - 1) / positions_per_block);
    }
    const dim3 grid(batch.first_unit[batch.n_ranges]);
+   ScanLaunchTiming* timing = nullptr;
+   if (g_tune_scan_timing.load() == 1) {
+      ScanTimingLog& log = scanTimingLog();
+      if (log.used == log.launches.size()) {
+         ScanLaunchTiming fresh;
+         if (hipEventCreate(&fresh.start) == hipSuccess && hipEventCreate(&fresh.stop) == hipSuccess) {
+            log.launches.push_back(fresh);
+         }
+      }
+      if (log.used < log.launches.size()) {
+         timing = &log.launches[log.used++];
+         uint64_t plane_rows = 0;
+         for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+            plane_rows += KIND == KIND_ROWS ? batch.n_positions[r] : static_cast<uint64_t>(batch.n_positions[r]) * BITS;
+         }
+         std::snprintf(timing->entry.kernel, sizeof(timing->entry.kernel), "k_scan_sliced<%d, %d, %d, %u, %d>", BITS, NSYM, wide ? 8 : 4, wide ? 1u : std::min(q_count, 8u), KIND);
+         timing->entry.plane_rows = plane_rows;
+         timing->entry.filters = q_count;
+         timing->entry.blocks = grid.x;
+         HIP_TRY(hipEventRecord(timing->start, hip_stream));
+      }
+   }
 #define SILO_LAUNCH_SLICED(WPT, Q) \
    k_scan_sliced<BITS, NSYM, WPT, Q, KIND><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
    if (wide) {
@@ -2312,6 +2355,9 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    }
 #undef SILO_LAUNCH_SLICED
    HIP_TRY(hipGetLastError());
+   if (timing != nullptr) {
+      HIP_TRY(hipEventRecord(timing->stop, hip_stream));
+   }
    return SILO_GPU_OK;
 }
 
@@ -2622,15 +2668,15 @@ int scanRanges(
       return SILO_GPU_OK;
    }
    g_last_scan_kernel = q_count == 1 ? "k_scan_sliced" : "k_scan_sliced_batch";
+   scanTimingLog().used = 0;
    std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
    cutIntoPieces(ranges, q_count, pieces);
    const int divisor = g_tune_sparse_divisor.load();
-   if (const int rc = forkEscapes(ranges, filters, q_count, hip_stream); rc != SILO_GPU_OK) {
-      (void)joinSides(hip_stream);
-      return rc;
-   }
    if (divisor < 0) {
-      const int rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
+      int rc = forkEscapes(ranges, filters, q_count, hip_stream);
+      if (rc == SILO_GPU_OK) {
+         rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
+      }
       const int joined = joinSides(hip_stream);
       return rc != SILO_GPU_OK ? rc : joined;
    }
@@ -2638,7 +2684,6 @@ int scanRanges(
    SparseScratch* scratch = nullptr;
    const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
    if (acquired != SILO_GPU_OK) {
-      (void)joinSides(hip_stream);
       return acquired;
    }
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
@@ -2653,7 +2698,12 @@ int scanRanges(
       k_compact_filter<<<dim3((any_store.row_words + COMPACT_THREADS - 1) / COMPACT_THREADS, q_count), COMPACT_THREADS, 0, hip_stream>>>(
          compact, any_store.row_words, stride, scratch->sparse_sectors, scratch->sector_index
       );
-      rc = scanPiecesDense(pieces, any_store, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
+      // the escape pass is forked behind the compaction: the plane scans wait for its counters, and beside a launch that
+      // fills the device it takes ten times as long (62 instead of 6 us)
+      rc = forkEscapes(ranges, filters, q_count, hip_stream);
+      if (rc == SILO_GPU_OK) {
+         rc = scanPiecesDense(pieces, any_store, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
+      }
    }
    // the gather over the sectors of the sparse filters, over the same pieces of the same planes
    for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
@@ -3071,6 +3121,21 @@ int silo_gpu_mutations_scan_ranges(
             }
          }
       }
+   }
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_scan_timings(silo_gpu_scan_timing* out, uint32_t capacity, uint32_t* n_out) {
+   if (n_out == nullptr || (capacity != 0 && out == nullptr)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_scan_timings: bad arguments");
+   }
+   ScanTimingLog& log = scanTimingLog();
+   *n_out = static_cast<uint32_t>(log.used);
+   for (size_t k = 0; k < log.used && k < capacity; ++k) {
+      ScanLaunchTiming& launch = log.launches[k];
+      HIP_TRY(hipEventSynchronize(launch.stop));
+      HIP_TRY(hipEventElapsedTime(&launch.entry.ms, launch.start, launch.stop));
+      out[k] = launch.entry;
    }
    return SILO_GPU_OK;
 }

@@ -377,6 +377,37 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
     assert sizes[0] < sizes[2] < 0.85 * sizes[-1]  # <= 2 planes + the missing-symbol plane instead of 3 / 5 + 1
 
 
+def test_scan_timings_cover_every_plane_row(built):
+    """silo_gpu_scan_timings (what bench.py's roofline of the dominant launch rests on): with SILO_GPU_TUNE_SCAN_TIMING set,
+    a scan reports one entry per k_scan_sliced launch, named as rocprofv3 names the kernel, and the plane rows of the
+    entries add up to the rows the store holds; without the knob nothing is recorded."""
+    from silo_amd import binding
+
+    n, positions = 140000, 29
+    rng = np.random.default_rng(5)
+    sym = skewed_symbols(rng, n, positions, "nuc")
+    settle_positions(rng, sym, range(3, 17), "nuc")
+    with make_store(n, [dict(name="a", alphabet="nuc", reference=sym[0].copy())]) as store:
+        store.append_sequences(0, 0, NUC_CHARS[sym])
+        store.finalize()
+        mask = rng.random(n) < 0.4
+        ptr = store.bitset_alloc()
+        store.bitset_upload(ptr, dense.pack_bits(mask))
+        want = dense.mutation_counts(sym, mask, list(store.scan_symbols[0]))
+        store.tune(7, 1)
+        try:
+            assert np.array_equal(store.mutations_scan(0, ptr), want)
+            entries = binding.scan_timings()
+        finally:
+            store.tune(7, 0)
+        assert len(entries) >= 2  # one-hot rows and 2 code planes at least
+        assert all(e["kernel"].startswith("k_scan_sliced<") and e["ms"] > 0 and e["blocks"] > 0 and e["filters"] == 1 for e in entries)
+        assert any(e["kernel"] == "k_scan_sliced<2, 2, 8, 1, 2>" for e in entries)
+        assert sum(e["plane_rows"] for e in entries) == store.scan_rows(0, 0, positions)
+        assert np.array_equal(store.mutations_scan(0, ptr), want)
+        assert binding.scan_timings() == []
+
+
 @pytest.mark.parametrize("n", [900, 140000])
 def test_scan_over_several_ranges_in_one_call(built, n):
     """silo_gpu_mutations_scan_ranges: every filter over ranges of nucleotide and amino-acid stores of different lengths

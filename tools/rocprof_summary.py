@@ -28,10 +28,10 @@ def main():
         key = (short(row["Kernel_Name"]), int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row.get("Grid_Size", 0)))
         groups[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     lines = [f"# {tag}: per-kernel summary of `rocprofv3 --kernel-trace` (durations in µs, grouped by kernel and grid size)", "",
-             "| kernel | grid (threads) | calls | avg | min | max |", "|---|---|---|---|---|---|"]
+             "| kernel | grid (threads) | calls | avg | median | min | max |", "|---|---|---|---|---|---|---|"]
     for (name, grid), durations in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"| {name} | {grid} | {len(durations)} | {sum(durations) / len(durations) / 1e3:.1f} | "
-                     f"{min(durations) / 1e3:.1f} | {max(durations) / 1e3:.1f} |")
+                     f"{sorted(durations)[len(durations) // 2] / 1e3:.1f} | {min(durations) / 1e3:.1f} | {max(durations) / 1e3:.1f} |")
     out = os.path.join(ROOT, "profiles", f"{tag}_kernel_summary.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print("wrote", out)
