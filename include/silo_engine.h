@@ -90,7 +90,9 @@ int silo_engine_finalize(silo_engine* engine);
  * silo_gpu_broadcast_bytes, both enqueued on the HIP stream of the request thread that runs the query (per-thread
  * query streams stay in use; no host synchronisation around the collective).  The communicator must outlive the
  * engine.  Every rank has to run the same queries in the same order (SPMD): the collectives of concurrent request
- * threads are serialised per communicator, but their order across ranks is the caller's to keep.
+ * threads are serialised per communicator, but their order across ranks is the caller's to keep.  Every all-reduce of a
+ * query carries the fingerprint of the query text; ranks that ran different queries answer 500 ("the ranks of this sharded
+ * database did not run the same query") instead of mixing their counts.
  *
  * silo_engine_set_sharding / silo_engine_set_broadcast install caller-supplied collectives instead (tests back them
  * with gloo through host memory; a host with its own transport can plug it in): all_reduce sums n uint32 in place on

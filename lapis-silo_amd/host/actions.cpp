@@ -106,6 +106,29 @@ void allReduce(const Database& database, uint32_t* device_values, size_t n) {
    }
 }
 
+/// Words an all-reduce of a query carries behind its payload: the two halves of the query's fingerprint.
+constexpr size_t FINGERPRINT_WORDS = 2;
+
+/// Writes the calling thread's query fingerprint behind `n_payload` words of an all-reduce buffer (stream-ordered).
+void appendFingerprint(uint32_t* device_values, size_t n_payload, uint64_t fingerprint) {
+   const uint32_t halves[FINGERPRINT_WORDS] = {static_cast<uint32_t>(fingerprint), static_cast<uint32_t>(fingerprint >> 32)};
+   checkGpu(silo_gpu_memcpy_h2d(device_values + n_payload, halves, sizeof(halves), queryStream()), "silo_gpu_memcpy_h2d");
+}
+
+/// After the all-reduce: every rank added the same fingerprint, or the ranks ran different queries (their collectives
+/// paired up all the same and the payload is a mix) — refuse the result.
+void checkSameQuery(const Database& database, const uint32_t* summed_halves, uint64_t fingerprint) {
+   const uint32_t world = std::max<uint32_t>(1, database.shard_world);
+   const bool same = summed_halves[0] == static_cast<uint32_t>(fingerprint) * world &&
+                     summed_halves[1] == static_cast<uint32_t>(fingerprint >> 32) * world;
+   if (!same) {
+      throw DeviceException(
+         "the ranks of this sharded database did not run the same query: every rank has to run the same queries in the same order "
+         "(query fingerprints differ in the all-reduce)"
+      );
+   }
+}
+
 }  // namespace
 
 namespace {
@@ -232,10 +255,14 @@ QueryResult Aggregated::execute(const Database& database, std::vector<OperatorRe
    if (database.shard_world > 1 && !database.shard_by_position && database.all_reduce != nullptr && !database.partitions.empty()) {
       // sequence-id sharding: every rank holds different rows
       const DatabasePartition& partition = database.partitions.front();
-      DeviceBuffer buffer = partition.pool.acquire(sizeof(uint32_t));
-      checkGpu(silo_gpu_memcpy_h2d(buffer.get(), &count, sizeof(count), queryStream()), "silo_gpu_memcpy_h2d");
-      allReduce(database, buffer.as<uint32_t>(), 1);
-      checkGpu(silo_gpu_memcpy_d2h(&count, buffer.get(), sizeof(count), queryStream()), "silo_gpu_memcpy_d2h");
+      const uint64_t fingerprint = Database::queryFingerprint();
+      uint32_t words[1 + FINGERPRINT_WORDS] = {count, static_cast<uint32_t>(fingerprint), static_cast<uint32_t>(fingerprint >> 32)};
+      DeviceBuffer buffer = partition.pool.acquire(sizeof(words));
+      checkGpu(silo_gpu_memcpy_h2d(buffer.get(), words, sizeof(words), queryStream()), "silo_gpu_memcpy_h2d");
+      allReduce(database, buffer.as<uint32_t>(), 1 + FINGERPRINT_WORDS);
+      checkGpu(silo_gpu_memcpy_d2h(words, buffer.get(), sizeof(words), queryStream()), "silo_gpu_memcpy_d2h");
+      checkSameQuery(database, words + 1, fingerprint);
+      count = words[0];
    }
    std::map<std::string, std::optional<std::variant<std::string, int32_t, double>>> tuple_fields;
    tuple_fields["count"] = static_cast<int32_t>(count);
@@ -385,7 +412,8 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
    if (database.partitions.empty() || n_counts == 0 || pending->sequence_names.empty() || (bitmaps_to_evaluate.empty() && !sharded)) {
       return pending;  // nothing selected (and no other rank to contribute): no rows
    }
-   pending->table_bytes = (n_counts * sizeof(uint32_t) + 15) / 16 * 16;
+   const bool reduced = database.all_reduce != nullptr;  // the table is all-reduced, with the query's fingerprint behind it
+   pending->table_bytes = ((n_counts + (reduced ? FINGERPRINT_WORDS : 0)) * sizeof(uint32_t) + 15) / 16 * 16;
    pending->row_capacity = layout.reference_index_device != nullptr ? database.mutation_row_capacity : 0;
    const size_t list_bytes = 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(pending->row_capacity);
    pending->device_table = database.partitions.front().pool.acquire(pending->table_bytes + list_bytes);
@@ -418,7 +446,11 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
    const uint8_t* reference_index = layout.reference_index_device.get();
    const uint32_t total_positions = layout.total_positions;
    const double proportion = min_proportion;
-   const auto select_and_fetch = [&scans, device_counts, reference_index, total_positions, proportion]() {
+   scans.fingerprint = Database::queryFingerprint();
+   const auto select_and_fetch = [&scans, device_counts, reference_index, total_positions, proportion, reduced, n_counts]() {
+      if (reduced) {
+         scans.check_fetch = HostFetch(device_counts + n_counts, FINGERPRINT_WORDS * sizeof(uint32_t), queryStream());
+      }
       if (scans.row_capacity == 0) {
          scans.fetch = HostFetch(device_counts, scans.table_bytes, queryStream());
          return;
@@ -432,8 +464,9 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
       scans.fetch = HostFetch(list, 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(scans.row_capacity), queryStream());
    };
    ScanBatcher* batcher = ScanBatcher::active();
-   if (database.all_reduce != nullptr) {
-      batcher->addReduction(database, device_counts, n_counts);  // the whole query in one collective
+   if (reduced) {
+      appendFingerprint(device_counts, n_counts, scans.fingerprint);
+      batcher->addReduction(database, device_counts, n_counts + FINGERPRINT_WORDS);  // the whole query in one collective
    }
    batcher->afterFlush(select_and_fetch);  // the scans are only recorded so far
    if (own_batcher) {
@@ -457,6 +490,9 @@ QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScan
    constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
    const auto* words = static_cast<const uint32_t*>(scans.fetch.wait());
    Trace::mark("counts_on_host");
+   if (scans.check_fetch) {
+      checkSameQuery(database, static_cast<const uint32_t*>(scans.check_fetch.wait()), scans.fingerprint);
+   }
    HostFetch whole_table;
    const uint32_t* table = nullptr;
    if (scans.row_capacity == 0) {

@@ -389,6 +389,19 @@ DatabasePartition::~DatabasePartition() {
    silo_gpu_store_destroy(store);
 }
 
+uint64_t& Database::queryFingerprint() {
+   thread_local uint64_t fingerprint = 0;
+   return fingerprint;
+}
+
+uint64_t Database::fingerprintOf(const std::string& query_text) {
+   uint64_t hash = 0xCBF29CE484222325ull;
+   for (const unsigned char c : query_text) {
+      hash = (hash ^ c) * 0x100000001B3ull;
+   }
+   return hash;
+}
+
 Database::Timings& Database::lastTimings() {
    thread_local Timings timings;
    return timings;

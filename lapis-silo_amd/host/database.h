@@ -338,6 +338,11 @@ class Database {
       int64_t action_microseconds = 0;
    };
    static Timings& lastTimings();
+   /// Fingerprint (FNV-1a of the query text) of the query the calling thread is executing.  A sharded database adds it to
+   /// every all-reduce of the query: ranks that did not run the same query see sums that are not `world` times their own
+   /// fingerprint and answer 500 instead of mixing the counts of different queries (checkSameQuery in actions.cpp).
+   static uint64_t& queryFingerprint();
+   static uint64_t fingerprintOf(const std::string& query_text);
 
    template <typename SymbolType>
    [[nodiscard]] const std::map<std::string, SequenceStore<SymbolType>>& getSequenceStores() const;

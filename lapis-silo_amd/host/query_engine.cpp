@@ -149,6 +149,7 @@ class BatchWorkers {
 QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  // query_engine.cpp:30-68
    Trace::reset();
    checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");  // HIP's current device is per thread (request threads start at 0)
+   Database::queryFingerprint() = Database::fingerprintOf(query_string);
    const Query query(query_string);
    Trace::mark("parsed");
    std::vector<OperatorResult> filters;
@@ -215,6 +216,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
       }
       const actions::ScanBatcher::Checkpoint mark = batcher.checkpoint();
       try {
+         Database::queryFingerprint() = Database::fingerprintOf(queries[i]);
          pending[i] = parsed[i]->action->begin(database, std::move(filters[i]));
       } catch (...) {
          batcher.rollback(mark);  // scans recorded by the failed query point into buffers that are gone
@@ -264,6 +266,7 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
          continue;
       }
       try {
+         Database::queryFingerprint() = Database::fingerprintOf(queries[i]);
          outcomes[i].result = parsed[i]->action->finish(database, *pending[i]);
       } catch (...) {
          outcomes[i].error = std::current_exception();

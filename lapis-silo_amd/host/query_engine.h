@@ -704,6 +704,8 @@ class Mutations : public Action {
       size_t table_bytes = 0;
       uint32_t row_capacity = 0;  // 0: the host selects from the whole table
       HostFetch fetch;            // the list (or the table), enqueued right behind the scans
+      HostFetch check_fetch;      // sharded: the two fingerprint sums behind the table (checkSameQuery)
+      uint64_t fingerprint = 0;
    };
    [[nodiscard]] QueryResult collect(const Database& database, PendingScans& scans) const;
 

@@ -204,11 +204,24 @@ def main():
     batched = engine.execute_batch(queries)
     if batched != results:
         raise AssertionError(f"rank {rank}: batched results differ from one-by-one results")
+    # ranks that do NOT run the same query: their collectives pair up all the same, the query fingerprints carried by the
+    # all-reduce give it away and every rank answers 500 instead of a mix of two queries' counts
+    def differing(action):
+        return {"action": action, "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": f"B.{1 + rank % 2}", "includeSublineages": True}}
+
+    mismatched = [engine.execute_raw(differing({"type": "Mutations", "minProportion": 0.02}))]
+    if not by_position:  # Aggregated has a collective only where the ranks hold different rows
+        mismatched.append(engine.execute_raw(differing({"type": "Aggregated"})))
+    mismatched += engine.execute_batch([differing({"type": "Mutations", "minProportion": 0.1}), queries[0]])[:1]
+    refused = [status == 500 and "did not run the same query" in document.get("message", "") for status, document in mismatched]
+    after = engine.execute_raw(queries[0])  # and the engine is fine afterwards
+    gathered = [None] * world
+    dist.all_gather_object(gathered, refused + [after == results[0]])
     dist.barrier()
     if rank == 0:
         want = oracle_answers(queries)
         got = json.loads(json.dumps(results))
-        print(json.dumps({"results": results, "matches_oracle": [g == w for g, w in zip(got, want)]}), flush=True)
+        print(json.dumps({"results": results, "matches_oracle": [g == w for g, w in zip(got, want)], "mismatch_refused": gathered}), flush=True)
     engine.close()
 
 

@@ -56,6 +56,11 @@ def test_two_ranks_match_one_rank_gpu(built, shard):
     assert single["results"] == double["results"]
     # and not only with each other: rank 0 ran every query through the CPU oracle on the unsharded data
     assert all(single["matches_oracle"]) and all(double["matches_oracle"]), (single["matches_oracle"], double["matches_oracle"])
+    # two ranks that run DIFFERENT queries are refused (500) on both ranks — the all-reduce carries the query's fingerprint —
+    # and answer the next common query as before; a single rank has nobody to disagree with
+    n_cases = 2 if shard == "position" else 3
+    assert double["mismatch_refused"] == [[True] * n_cases + [True]] * 2, double["mismatch_refused"]
+    assert single["mismatch_refused"] == [[False] * n_cases + [True]], single["mismatch_refused"]
 
 
 @pytest.mark.gpu
