@@ -50,7 +50,8 @@ def load_reference_genomes(with_genes=False):
             "genes": genomes["genes"] if with_genes else []}
 
 
-def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False, nuc_positions=None):
+def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False, nuc_positions=None,
+                 lineage_order=False):
     from silo_amd import alphabet, synth
     from silo_amd.engine import Engine
 
@@ -60,6 +61,12 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
     reference = np.array([alphabet.NUCLEOTIDE.char_to_symbol[c] for c in genomes["nucleotideSequences"][0]["sequence"]], dtype=np.uint8)
     tree = synth.make_lineage_tree(N_LINEAGES)
     lineage = synth.assign_lineages(n_sequences, tree, synth.DEFAULT_SEED)
+    if lineage_order:
+        # rows laid out lineage by lineage, sublineages behind their parent (the reference partitions by Pango lineage and
+        # groups its rows by that key, preprocessor.cpp:159-227): a lineage-with-sublineages filter is then a row range
+        rank_of = np.empty(len(tree.names), dtype=np.int64)
+        rank_of[sorted(range(len(tree.names)), key=lambda k: [int(part) for part in tree.names[k].split(".")[1:]])] = np.arange(len(tree.names))
+        lineage = lineage[np.argsort(rank_of[lineage], kind="stable")]
     model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
     engine = Engine(genomes, device=device)
     if getattr(build_engine, "comm", None) is not None and (world > 1 or sharded):
@@ -877,6 +884,18 @@ def main():
         lib.silo_gpu_free(counts1)
         engine1.close()
         if args.sequences == 10_000_000:
+            # the same query where the rows lie in lineage order: column tiles without a selected row are not read
+            engine_sorted, _, _, _, _ = build_engine(args.sequences, 0, 1, None, local_rank, lineage_order=True)
+            elapsed_sorted, rows_sorted = run_steps(engine_sorted, query, args.steps, args.warmup, sync)
+            result["also_rows_in_lineage_order"] = {
+                "workload": f"the headline query on a {args.sequences}-sequence genome whose rows lie lineage by lineage (sublineages behind their parent), as the "
+                            "reference's partitioning by Pango lineage lays them out; the headline database assigns lineages to rows at random",
+                "value": args.sequences * positions / (elapsed_sorted / args.steps),
+                "unit": "positions*sequences/s",
+                "ms_per_step": elapsed_sorted / args.steps * 1e3,
+                "mutation_rows": len(rows_sorted),
+            }
+            engine_sorted.close()
             engine4, _, tree4, _, _ = build_engine(6_250_000, 0, 1, None, local_rank, with_genes=True)
             reference_text = load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
             result["also_config4_shard"] = config4_workload(engine4, tree4, reference_text, positions, aa_positions, 6_250_000, sync)

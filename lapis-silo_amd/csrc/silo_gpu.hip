@@ -348,6 +348,18 @@ constexpr uint32_t SCAN_MAX_RANGES = 32;
 // the per-filter sector counters sit 256 bytes apart: atomics on one L2 channel serialise (~12 ns each), and a dense
 // filter makes every block add to its counter
 constexpr uint32_t SPARSE_COUNTER_STRIDE = 64;
+constexpr uint32_t SECTOR_WORDS = 8;        // a 64-byte sector of a filter row
+constexpr uint32_t COMPACT_THREADS = 1024;   // words per block of k_compact_filter
+
+/// Which scan serves a filter, from the counters k_compact_filter left for it: [0] sectors with a set bit, [1] stretches of
+/// COMPACT_THREADS words with one.  The gather pays while the sectors fit its list AND cost less than the column tiles the
+/// dense scan cannot skip: it reads its sectors at about 0.6 of the dense scan's rate, so a clustered filter (rows in
+/// lineage or date order: few sectors because they are contiguous, not because they are few) stays with the dense scan.
+__device__ __forceinline__ bool takesGatherScan(const uint32_t* __restrict__ counters, uint32_t capacity) {
+   const uint32_t sectors = counters[0];
+   return sectors <= capacity && static_cast<uint64_t>(sectors) * 8u < static_cast<uint64_t>(counters[1]) * (COMPACT_THREADS / SECTOR_WORDS) * 5u;
+}
+
 
 /// One launch of the scan: up to SILO_GPU_MAX_SCAN_BATCH filters against up to SCAN_MAX_RANGES position ranges of
 /// sequence stores with the same layout (the 12 genes of an AminoAcidMutations query, the segments of a segmented
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, NSYM, WPT, Q>())
    bool dense[Q];
 #pragma unroll
    for (int q = 0; q < Q; ++q) {
-      dense[q] = batch.sparse_sectors == nullptr || batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE] > batch.sparse_capacity;
+      dense[q] = batch.sparse_sectors == nullptr || !takesGatherScan(batch.sparse_sectors + q * SPARSE_COUNTER_STRIDE, batch.sparse_capacity);
    }
    bool any_dense = false;
 #pragma unroll
@@ -449,6 +461,22 @@ __global__ __launch_bounds__(SCAN_THREADS, (scanMinBlocks<BITS, NSYM, WPT, Q>())
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
          f[q][j] = inside && dense[q] ? *reinterpret_cast<const ulonglong2*>(batch.filters[q] + word[j]) : make_ulonglong2(0, 0);
+      }
+   }
+
+   // A tile without a selected row has nothing to count: rows laid out by lineage or date (the reference partitions by a
+   // key column and orders by date, preprocessor.cpp:159-227) give lineage and date filters long runs of zero words, and such a block leaves before its first load.
+   {
+      uint64_t any_bit = 0;
+#pragma unroll
+      for (int j = 0; j < CHUNKS; ++j) {
+#pragma unroll
+         for (int q = 0; q < Q; ++q) {
+            any_bit |= f[q][j].x | f[q][j].y;
+         }
+      }
+      if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
+         return;
       }
    }
 
@@ -660,8 +688,6 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
 // the index pays while the escapes of a position cost less than streaming the plane rows it saves: a key costs about as
 // much as 40 plane bytes (7.6 M keys in 46 us, profiles/r01_compact_index.md), i.e. break-even at N/320 keys per position
 constexpr uint64_t COMPACT_ESCAPE_DIVISOR = 512;
-constexpr uint32_t SECTOR_WORDS = 8;
-constexpr uint32_t COMPACT_THREADS = 1024;
 
 __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
    const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index
@@ -694,6 +720,9 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
          total += count;
       }
       s_block_first = total != 0 ? atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE, total) : 0;
+      if (total != 0) {
+         atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE + 1, 1u);  // stretches of COMPACT_THREADS words with a set bit
+      }
    }
    __syncthreads();
    if (((leaders >> lane) & 1ull) != 0) {
@@ -712,7 +741,7 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
 ) {
    const uint32_t q = blockIdx.y;
    const uint32_t n_sectors = batch.sparse_sectors[q * SPARSE_COUNTER_STRIDE];
-   if (n_sectors == 0 || n_sectors > batch.sparse_capacity) {
+   if (n_sectors == 0 || !takesGatherScan(batch.sparse_sectors + q * SPARSE_COUNTER_STRIDE, batch.sparse_capacity)) {
       return;  // empty filter, or a dense one (k_scan_sliced has it); `capacity` is the stride of the lists
    }
    const uint32_t n_words = n_sectors * SECTOR_WORDS;
@@ -980,6 +1009,7 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
    if (key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS >= key_end) {
       return;  // (uniform) no chunk for this block
    }
+   uint64_t any_bit = 0;
    {  // this slice of the filter: 8 words (4 x 16 bytes) per thread, zeros past the end of the row
       const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
       const uint64_t* filter = args.filters[q];
@@ -989,9 +1019,12 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
          const uint32_t word = first_word + chunk * 2u;
          const ulonglong2 v = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
          *reinterpret_cast<ulonglong2*>(s_filter + chunk * 4u) = v;
+         any_bit |= v.x | v.y;
       }
    }
-   __syncthreads();
+   if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
+      return;  // no row of this slice is selected: none of its keys counts
+   }
    const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
    uint32_t* __restrict__ counts = range.counts[q];
    for (uint32_t base = key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS; base < key_end; base += gridDim.x * ESCAPE_CHUNK_KEYS) {  // uniform per block

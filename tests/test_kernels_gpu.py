@@ -312,6 +312,8 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
     sparse = np.zeros(n, bool)
     sparse[rng.choice(n, size=9, replace=False)] = True
     masks = [rng.random(n) < 0.4, sparse, np.ones(n, bool), rng.random(n) < 0.02, np.zeros(n, bool)]
+    # a clustered filter (rows in lineage or date order): whole column tiles and key slices without a selected row are skipped
+    masks[3] = (np.arange(n) >= int(n * 0.6)) & (rng.random(n) < 0.7)
     sizes = {}
     for knob in (0, 2, -1):  # re-encoded with and without one-hot rows, then the identity planes kept
         with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:

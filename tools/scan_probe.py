@@ -18,6 +18,7 @@ ap.add_argument("--rows", type=str, default="32,64,128")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--variants", type=str, default="0,10,12")
 ap.add_argument("--alphabet", type=str, default="nuc")
+ap.add_argument("--lineage-order", action="store_true", help="rows laid out lineage by lineage, sublineages behind their parent")
 ap.add_argument("--keycost", type=str, default="0", help="SILO_GPU_TUNE_KEY_COST values to try (the store is rebuilt for each)")
 ap.add_argument("--side", type=str, default="0", help="SILO_GPU_TUNE_SIDE_STREAM values to try (escape pass: 0 low-priority side stream, 1 default priority, 2 caller's stream)")
 args = ap.parse_args()
@@ -26,6 +27,10 @@ n, positions = args.sequences, args.positions
 t0 = time.time()
 tree = synth.make_lineage_tree(args.lineages)
 lineage = synth.assign_lineages(n, tree, synth.DEFAULT_SEED)
+if args.lineage_order:
+    rank_of = np.empty(len(tree.names), dtype=np.int64)
+    rank_of[sorted(range(len(tree.names)), key=lambda k: [int(part) for part in tree.names[k].split(".")[1:]])] = np.arange(len(tree.names))
+    lineage = lineage[np.argsort(rank_of[lineage], kind="stable")]
 ref = synth.random_reference(positions, "nuc", 1)
 model = synth.make_model(n, ref, "nuc", tree, lineage)
 print(f"model built in {time.time() - t0:.1f}s", flush=True)
