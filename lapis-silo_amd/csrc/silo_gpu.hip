@@ -27,6 +27,7 @@
 #include "../../include/silo_gpu.h"
 #include "bitprog.h"
 #include "internal.h"
+#include "layout_choice.h"
 
 namespace {
 
@@ -102,14 +103,14 @@ uint32_t missingSymbol(uint32_t alphabet) {
 // ------------------------------------------------------------------------------------------------
 enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
 
-// Layout of a position in the adaptive code planes (code_map[p][0]): the number of code planes, and whether the codes are
-// the identity (code = index of the valid mutation symbol + 1, no escapes: the position keeps its full planes).
-constexpr uint8_t LAYOUT_IDENTITY = 0x80;
+// Layout of a position in the adaptive planes (code_map[p][0], layout_choice.h): the number of plane rows, and whether they
+// are identity code planes (code = index of the valid mutation symbol + 1, no escapes: the position keeps its full planes) ...
+using silo_gpu_layout::LAYOUT_IDENTITY;
 // ... or ONE-HOT rows: the low bits give k = 1..3 rows, row j holds exactly the rows of the position's j-th most frequent
 // valid symbol (code_map[p][1 + j]); every other valid symbol of a row is an escape key.  Rows of one-hot positions need no
 // joint decoding — each is one AND + popcount under the filter — so positions with different k form ONE run for the scan.
-constexpr uint8_t LAYOUT_ONE_HOT = 0x40;
-constexpr uint32_t CODE_MAP_STRIDE = 8;  // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
+using silo_gpu_layout::LAYOUT_ONE_HOT;
+using silo_gpu_layout::CODE_MAP_STRIDE;  // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
 
 struct SeqStoreDev {
    // BUILD-TIME bit-sliced planes [P][n_bits][Wp]: bit b of the CODE of every row's symbol at the position, where the code
@@ -840,24 +841,25 @@ __global__ __launch_bounds__(256, (BITS <= 3 ? (NSYM <= 5 ? 5 : 4) : 4)) void k_
 }
 
 // ------------------------------------------------------------------------------------------------
-// The adaptive code planes.  At almost every position of a real alignment three symbols cover all but a handful of rows
-// (the reference symbol, the gap or a lineage's substitution, one more), so a finalized store does not keep the
-// ceil(log2(|valid| + 1)) code planes of the build (3 nucleotide, 5 amino-acid) everywhere: finalize() picks, per
-// POSITION, the cheapest of
+// The adaptive planes.  At almost every position of a real alignment ONE symbol has nearly every row, and where not, three
+// symbols cover all but a handful (the reference symbol, the gap or a lineage's substitution, one more), so a finalized store
+// does not keep the ceil(log2(|valid| + 1)) code planes of the build (3 nucleotide, 5 amino-acid) everywhere: finalize() picks,
+// per POSITION, the cheapest of
+//    one-hot rows: 1, 2 or 3 rows, row j = the rows of the position's j-th most frequent valid symbol,
 //    2 planes: codes 1..3 = the three most frequent valid symbols of the position,
 //    3 planes: codes 1..7 = the seven most frequent (amino acids only: for nucleotides that is the full set),
 //    the full identity planes,
-// where the rows whose valid symbol got no code become explicit keys ("escapes": position << 37 | scan symbol << 32 |
-// sequence, sorted).  Cost model (chooseLayouts, on the host from the unfiltered totals), in bytes the Mutations scan has
-// to move: planes x row bytes + KEY_COST_BYTES per escape (a key costs what ~40 plane bytes cost: 7.6 M keys in 46 us
-// against 6.7 TB/s, profiles/r01_compact_index.md), the 22-symbol decode of the full amino-acid planes weighted by what it
-// costs in VALU time, and a charge per change of layout between neighbouring positions: a scan launch takes runs of ONE
-// layout, and a run of a few positions costs its blocks the filter tile and the pipeline ramp all over again.  The build-time planes are
-// freed afterwards: at 10 M sequences the nucleotide store shrinks from 112 GB to 75 GB of code planes (+ 37 GB for the
-// missing-symbol plane) and every consumer — the scan, the sparse-filter gather, filter leaves, FastaAligned — reads the
-// adaptive planes.
+// where the rows whose valid symbol the position does not store become explicit keys ("escapes": position << 37 | scan
+// symbol << 32 | sequence, sorted; a second copy slice-major for the scan's escape pass).  Cost model (chooseLayouts in
+// layout_choice.h, on the host from the unfiltered totals), in bytes the Mutations scan has to move: rows x row bytes +
+// KEY_COST_BYTES per escape, the 22-symbol decode of the full amino-acid planes weighted by what it costs in VALU time, and a
+// charge per change of layout between neighbouring positions: a scan launch takes runs of ONE layout (one-hot positions of
+// any number of rows are one layout: a run of rows), and a run of a few positions costs its blocks the filter tile and the
+// pipeline ramp all over again.  The build-time planes are freed afterwards: at 10 M sequences the nucleotide store shrinks
+// from 112 GB to 38 GB of plane rows (+ 37 GB for the missing-symbol plane) and every consumer — the scan, the
+// sparse-filter gather, filter leaves, FastaAligned — reads the adaptive planes.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t KEY_COST_BYTES = 16;
+using silo_gpu_layout::KEY_COST_BYTES;
 
 /// Re-encodes the build-time planes of every position into its adaptive layout; rows without a code go, with an atomic
 /// cursor per (position, symbol), into that counter's exactly sized slice of the key list (sorted afterwards).
@@ -2764,116 +2766,6 @@ int scanRanges(
    return rc != SILO_GPU_OK ? rc : joined;
 }
 
-/// The layout of every position of a sequence store (see "The adaptive code planes" above) from the unfiltered totals:
-/// code_map[p][0] = code planes (| LAYOUT_IDENTITY) or one-hot rows (| LAYOUT_ONE_HOT), code_map[p][c] = the scan symbol of
-/// code c (of one-hot row c - 1); escape_count[p][s] = rows of symbol s at p that get neither.  A small dynamic program over
-/// the positions: the cost of a position under each of the four layouts plus RUN_COST for every change of layout between
-/// neighbours (one-hot positions of 1, 2 or 3 rows are ONE layout: a run of rows).
-void chooseLayouts(
-   const std::vector<uint32_t>& totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint64_t row_bytes, bool allow_one_hot,
-   std::vector<uint8_t>& code_map, std::vector<uint32_t>& escape_count
-) {
-   enum { TWO_PLANES = 0, THREE_PLANES = 1, IDENTITY = 2, ONE_HOT = 3, N_LAYOUTS = 4 };
-   constexpr uint64_t NEVER = ~0ull >> 2;
-   const uint64_t key_cost = g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES;
-   const uint64_t run_cost = 2 * row_bytes;
-   std::vector<uint8_t> best(static_cast<size_t>(positions) * 7, 0xFF);   // the seven most frequent valid symbols, most frequent first
-   std::vector<uint8_t> one_hot_rows(positions, 1);                       // rows of the position as a one-hot one
-   std::vector<uint64_t> cost(static_cast<size_t>(positions) * N_LAYOUTS);
-   for (uint32_t p = 0; p < positions; ++p) {
-      const uint32_t* count = totals.data() + static_cast<size_t>(p) * n_scan;
-      uint64_t total = 0;
-      for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-         total += count[symbol];
-      }
-      uint32_t taken = 0;
-      uint64_t carried[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rows carried by the k most frequent
-      for (int k = 0; k < 7; ++k) {
-         uint32_t pick = 0xFFu;
-         uint32_t pick_count = 0;
-         for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {  // ties keep the lower symbol index in front
-            if (((taken >> symbol) & 1u) == 0 && count[symbol] > pick_count) {
-               pick = symbol;
-               pick_count = count[symbol];
-            }
-         }
-         best[static_cast<size_t>(p) * 7 + k] = static_cast<uint8_t>(pick);
-         carried[k + 1] = carried[k] + pick_count;
-         if (pick != 0xFFu) {
-            taken |= 1u << pick;
-         }
-      }
-      uint64_t* position_cost = cost.data() + static_cast<size_t>(p) * N_LAYOUTS;
-      position_cost[TWO_PLANES] = 2 * row_bytes + key_cost * (total - carried[3]);
-      // three mapped planes only pay where the identity layout has more (amino acids)
-      position_cost[THREE_PLANES] = n_bits > 3 ? 3 * row_bytes + key_cost * (total - carried[7]) : NEVER;
-      // the scan of 5 identity planes decodes 22 symbols per word and runs VALU-bound at ~0.87 of the rate of the mapped layouts
-      position_cost[IDENTITY] = n_bits > 3 ? n_bits * row_bytes * 115 / 100 : n_bits * row_bytes;
-      // k rows, one per symbol: one row where one symbol has (nearly) all rows — most positions of a real alignment
-      position_cost[ONE_HOT] = NEVER;
-      for (uint32_t k = 1; allow_one_hot && k <= 3; ++k) {
-         const uint64_t with_k = k * row_bytes + key_cost * (total - carried[k]);
-         if (with_k < position_cost[ONE_HOT]) {
-            position_cost[ONE_HOT] = with_k;
-            one_hot_rows[p] = static_cast<uint8_t>(k);
-         }
-      }
-   }
-   std::vector<uint64_t> reach(static_cast<size_t>(positions) * N_LAYOUTS);  // cheapest way to encode positions [0, p] with p in that layout
-   std::vector<uint8_t> from(static_cast<size_t>(positions) * N_LAYOUTS);
-   for (uint32_t p = 0; p < positions; ++p) {
-      for (int layout = 0; layout < N_LAYOUTS; ++layout) {
-         uint64_t before = 0;
-         uint8_t previous = static_cast<uint8_t>(layout);
-         if (p > 0) {
-            before = NEVER;
-            for (int other = 0; other < N_LAYOUTS; ++other) {
-               const uint64_t candidate = reach[static_cast<size_t>(p - 1) * N_LAYOUTS + other] + (other == layout ? 0 : run_cost);
-               if (candidate < before) {
-                  before = candidate;
-                  previous = static_cast<uint8_t>(other);
-               }
-            }
-         }
-         reach[static_cast<size_t>(p) * N_LAYOUTS + layout] = std::min(NEVER, before + cost[static_cast<size_t>(p) * N_LAYOUTS + layout]);
-         from[static_cast<size_t>(p) * N_LAYOUTS + layout] = previous;
-      }
-   }
-   code_map.assign(static_cast<size_t>(positions) * CODE_MAP_STRIDE, 0xFF);
-   escape_count.assign(static_cast<size_t>(positions) * n_scan, 0);
-   int layout = 0;
-   for (int other = 1; other < N_LAYOUTS && positions > 0; ++other) {
-      if (reach[static_cast<size_t>(positions - 1) * N_LAYOUTS + other] < reach[static_cast<size_t>(positions - 1) * N_LAYOUTS + layout]) {
-         layout = other;
-      }
-   }
-   for (uint32_t p = positions; p-- > 0;) {
-      uint8_t* map = code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
-      if (layout == IDENTITY) {
-         map[0] = static_cast<uint8_t>(n_bits | LAYOUT_IDENTITY);
-         for (uint32_t code = 1; code < CODE_MAP_STRIDE; ++code) {
-            map[code] = static_cast<uint8_t>(code - 1 < n_scan && code < (1u << n_bits) ? code - 1 : 0xFFu);
-         }
-      } else {
-         const uint32_t coded = layout == ONE_HOT ? one_hot_rows[p] : (layout == TWO_PLANES ? 3 : 7);
-         map[0] = static_cast<uint8_t>(layout == ONE_HOT ? (one_hot_rows[p] | LAYOUT_ONE_HOT) : (layout == TWO_PLANES ? 2 : 3));
-         uint32_t coded_mask = 0;
-         for (uint32_t code = 1; code <= coded; ++code) {
-            map[code] = best[static_cast<size_t>(p) * 7 + code - 1];
-            if (map[code] != 0xFFu) {
-               coded_mask |= 1u << map[code];
-            }
-         }
-         for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
-            if (((coded_mask >> symbol) & 1u) == 0) {
-               escape_count[static_cast<size_t>(p) * n_scan + symbol] = totals[static_cast<size_t>(p) * n_scan + symbol];
-            }
-         }
-      }
-      layout = from[static_cast<size_t>(p) * N_LAYOUTS + layout];
-   }
-}
-
 /// finalize(): derive the adaptive code planes of one sequence store (see chooseLayouts) and release its build-time
 /// planes — or keep those as they are when re-encoding would not pay (short rows), is switched off
 /// (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit next to them.
@@ -2945,9 +2837,9 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    std::vector<uint8_t> code_map;
    std::vector<uint32_t> counts;  // escape keys per (position, symbol)
    // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows (the layouts before one-hot rows, for comparisons)
-   chooseLayouts(
-      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2, code_map,
-      counts
+   silo_gpu_layout::chooseLayouts(
+      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2,
+      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, code_map, counts
    );
    SILO_LAYOUT_TRY(hipMalloc(&d_code_map, code_map.size()));
    SILO_LAYOUT_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));

@@ -111,7 +111,7 @@ def build_host_tools(force=False):
     logic_src = os.path.join(ROOT, "tests", "host_tools", "host_logic.cpp")
     logic_target = os.path.join(LIB, "libhost_logic.so")
     engine_lib = os.path.join(LIB, "libsilo_engine.so")
-    if os.path.exists(logic_src) and os.path.exists(engine_lib) and (force or _newer(logic_target, [logic_src, engine_lib])):
+    if os.path.exists(logic_src) and os.path.exists(engine_lib) and (force or _newer(logic_target, [logic_src, engine_lib, os.path.join(CSRC, "layout_choice.h")])):
         _run(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-I", INCLUDE, "-I", HOST, logic_src, "-o", logic_target, "-L", LIB,
               "-lsilo_engine", "-lsilo_gpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB])
     return target

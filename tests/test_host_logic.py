@@ -237,3 +237,74 @@ def test_fasta_reader_vectors(host_logic):
             assert status == -1 and case["error"] in text, (case["cite"], text)
         else:
             assert status >= 0 and json.loads(text) == case["records"], (case["cite"], text)
+
+
+# ---- the layout of the adaptive planes (csrc/layout_choice.h: host code of the device library) -----------------------------
+def choose_layouts(host_logic, totals, n_bits, sequences, one_hot=True, key_cost=0):
+    import ctypes
+
+    import numpy as np
+
+    totals = np.ascontiguousarray(totals, dtype=np.uint32)
+    positions, n_scan = totals.shape
+    code_map = np.zeros((positions, 8), dtype=np.uint8)
+    escapes = np.zeros((positions, n_scan), dtype=np.uint32)
+    host_logic.t_choose_layouts.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+    host_logic.t_choose_layouts.restype = None
+    host_logic.t_choose_layouts(totals.ctypes.data, n_scan, n_bits, positions, sequences, int(one_hot), key_cost, code_map.ctypes.data, escapes.ctypes.data)
+    rows = code_map[:, 0] & 0x3F
+    kind = np.where(code_map[:, 0] & 0x80, "identity", np.where(code_map[:, 0] & 0x40, "one-hot", "codes"))
+    return rows, kind, code_map, escapes
+
+
+def test_layout_choice_follows_the_cost_model(host_logic):
+    """One row where one symbol has nearly every row, two where a second symbol is frequent, 2 code planes where three are
+    and the neighbours agree, identity planes where nothing pays; every row a position does not store is an escape key."""
+    import numpy as np
+
+    n = 10_000_000
+    settled = [n - 2000, 900, 600, 300, 200]           # one symbol, 2 000 other rows
+    two = [n // 2, n // 2 - 3000, 1500, 1000, 500]     # two frequent symbols
+    three = [n // 3, n // 3, n // 3 - 600, 400, 200]   # three
+    flat = [n // 5] * 5                                # all five
+    totals = np.array([settled] * 40 + [two] + [settled] * 40 + [three] * 30 + [flat] * 3 + [settled] * 20, dtype=np.uint32)
+    rows, kind, code_map, escapes = choose_layouts(host_logic, totals, 3, n)
+    assert list(kind[:81]) == ["one-hot"] * 81 and list(rows[:40]) == [1] * 40 and rows[40] == 2 and list(rows[41:81]) == [1] * 40
+    assert list(kind[81:111]) == ["codes"] * 30 and list(rows[81:111]) == [2] * 30       # a run of its own: cheaper than 3 rows each
+    assert list(kind[111:114]) == ["identity"] * 3 and list(rows[111:114]) == [3] * 3
+    assert list(kind[114:]) == ["one-hot"] * 20
+    assert code_map[0, 1] == 0 and code_map[40, 1] == 0 and code_map[40, 2] == 1 and list(code_map[90, 1:4]) == [0, 1, 2]
+    assert list(escapes[0]) == [0, 900, 600, 300, 200] and list(escapes[40]) == [0, 0, 1500, 1000, 500]
+    assert list(escapes[90]) == [0, 0, 0, 400, 200] and not escapes[111:114].any()
+    # a single position with three frequent symbols between settled ones: not worth a run of its own (2 x row bytes each way)
+    totals = np.array([settled] * 10 + [three] + [settled] * 10, dtype=np.uint32)
+    rows, kind, _, _ = choose_layouts(host_logic, totals, 3, n)
+    assert list(kind) == ["one-hot"] * 21 and rows[10] == 3
+    # without one-hot rows (SILO_GPU_TUNE_COMPACT_INDEX 2): two code planes everywhere
+    rows, kind, _, escapes = choose_layouts(host_logic, totals, 3, n, one_hot=False)
+    assert list(kind) == ["codes"] * 21 and list(rows) == [2] * 21 and list(escapes[0]) == [0, 0, 0, 300, 200]
+    # the key cost moves the boundary between one row and two: 40 000 rows of a second symbol are keys at 16 B, a row at 40 B
+    second = [n - 41000, 40000, 500, 300, 200]
+    assert choose_layouts(host_logic, np.array([second] * 8, dtype=np.uint32), 3, n)[0].tolist() == [1] * 8
+    assert choose_layouts(host_logic, np.array([second] * 8, dtype=np.uint32), 3, n, key_cost=40)[0].tolist() == [2] * 8
+
+
+def test_layout_choice_on_the_real_alignment(host_logic):
+    """The 1 000 real SARS-CoV-2 sequences of exampleDataset1000Sequences, counted per position and scaled to 10 M rows:
+    the layout choice of the device library gives them 1.03 plane rows per position — what the synthetic model gets."""
+    import numpy as np
+
+    from tests import test_config1_dataset
+
+    _, _, sequences = test_config1_dataset.load()
+    rows_ = [s for s in sequences if s is not None]
+    matrix = np.frombuffer("".join(rows_).encode(), dtype=np.uint8).reshape(len(rows_), -1)
+    totals = np.stack([(matrix == ord(c)).sum(axis=0) for c in "-ACGT"], axis=1).astype(np.uint32) * 10_000
+    rows, kind, _, escapes = choose_layouts(host_logic, totals, 3, 10_000_000)
+    per_position = rows.sum() / len(rows)
+    keys = int(escapes.sum())
+    print(f"plane rows per position {per_position:.4f}; one-hot {np.mean(kind == 'one-hot'):.4f}, codes {np.mean(kind == 'codes'):.4f}, "
+          f"identity {np.mean(kind == 'identity'):.4f}; escape keys {keys / 1e6:.1f} M = {keys / totals.sum():.2e} of the cells")
+    assert 1.0 <= per_position < 1.06 and np.mean(rows == 1) > 0.95 and np.mean(kind == "identity") < 0.001
+    assert keys < 0.002 * totals.sum()

@@ -357,6 +357,15 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             assert np.array_equal(store.mutations_scan(0, None), want[2])
             for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
                 assert np.array_equal(got, table), knob
+            # the escape pass on the caller's stream (2) and over the position-major keys (3: what stores of more than 64 slices use)
+            for mode in (2, 3):
+                store.tune(5, mode)
+                try:
+                    assert np.array_equal(store.mutations_scan(0, ptrs[0]), want[0]) and np.array_equal(store.mutations_scan(0, ptrs[3], 2, 27), want[3][2:27]), (knob, mode)
+                    for got, table in zip(store.mutations_scan_batch(0, ptrs[:3], 0, positions), want):
+                        assert np.array_equal(got, table), (knob, mode)
+                finally:
+                    store.tune(5, 0)
             assert np.array_equal(store.mutations_scan(0, ptrs[0], 3, 20), dense.mutation_counts(sym, masks[0], scan_symbols, 3, 20))
             tables = store.mutations_scan_ranges([(0, 0, positions), (1, 0, 11), (0, 5, 6), (0, 13, 14), (0, 12, 15), (0, 8, 23), (1, 4, 6)], ptrs[:3])
             for q in range(3):
