@@ -3246,6 +3246,7 @@ int silo_gpu_bitset_alloc(const silo_gpu_store* store, uint64_t** out_dev) {
    const size_t bytes = static_cast<size_t>(store->row_words) * sizeof(uint64_t);
    HIP_TRY(hipMalloc(out_dev, bytes));
    HIP_TRY(hipMemset(*out_dev, 0, bytes));
+   HIP_TRY(hipStreamSynchronize(nullptr));  // the fill is enqueued on the null stream; the caller's stream would not wait for it
    return SILO_GPU_OK;
 }
 
@@ -3423,6 +3424,12 @@ int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot) {
    hipError_t err = hipMalloc(&slot->d_shards, device_bytes);
    if (err == hipSuccess) {
       err = hipMemset(slot->d_shards, 0, device_bytes);
+   }
+   if (err == hipSuccess) {
+      // hipMemset of device memory only ENQUEUES a fill on the null stream, and the slot's first launch comes on a
+      // non-blocking stream, which does not wait for the null stream: on a busy device the fill could land in the middle of
+      // that launch and wipe tickets already taken ("the kernel finished without delivering its total")
+      err = hipStreamSynchronize(nullptr);
    }
    if (err == hipSuccess) {
       slot->d_ticket = reinterpret_cast<uint32_t*>(slot->d_shards + SILO_GPU_COUNT_SHARDS);

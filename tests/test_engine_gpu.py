@@ -197,6 +197,50 @@ def test_concurrent_clients_get_sequential_results(engines):
             assert got == expected[k], json.dumps(queries[k])
 
 
+def test_first_count_queries_of_new_threads_on_a_busy_device(engines):
+    """A thread's count slot (k_filter_eval hands its total to the host through it) is created by the thread's first filter ->
+    count query.  Its counters are zeroed by a fill on the null stream, which the thread's own non-blocking stream does not
+    wait for: with the device busy the fill used to land inside the first launch now and then ("the kernel finished without
+    delivering its total", tools/soak.py).  Fresh threads, their first queries while other threads keep the device busy."""
+    import threading
+
+    engine, _ = engines
+    rng = random.Random(7)
+    counts = [{"action": {"type": "Aggregated"}, "filterExpression": random_expression(rng, 3)} for _ in range(6)]
+    scans = [{"action": {"type": "Mutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
+             {"action": {"type": "AminoAcidMutations", "minProportion": 0.0}, "filterExpression": {"type": "Not", "child": {"type": "False"}}}]
+    expected = [engine.execute_raw(q) for q in counts]
+    stop = threading.Event()
+    failures = []
+
+    def load():
+        while not stop.is_set():
+            for q in scans:
+                engine.execute_raw(q)
+
+    def newcomer(index):
+        for k in range(len(counts)):
+            got = engine.execute_raw(counts[(k + index) % len(counts)])
+            if got != expected[(k + index) % len(counts)]:
+                failures.append((index, k, got))
+
+    background = [threading.Thread(target=load) for _ in range(3)]
+    for t in background:
+        t.start()
+    try:
+        for wave in range(6):  # 48 threads, each with a count slot of its own
+            fresh = [threading.Thread(target=newcomer, args=(wave * 8 + i,)) for i in range(8)]
+            for t in fresh:
+                t.start()
+            for t in fresh:
+                t.join()
+    finally:
+        stop.set()
+        for t in background:
+            t.join()
+    assert not failures, failures[:3]
+
+
 def test_full_filter_uses_cached_totals_and_matches_scan(engines):
     engine, oracle_db = engines
     query = {"action": {"type": "Mutations", "minProportion": 0.0, "sequenceName": "main"}, "filterExpression": {"type": "True"}}

@@ -13,12 +13,17 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "lapis-silo_amd")]
 import bench  # noqa: E402
+from silo_amd import binding  # noqa: E402
+bench.binding = binding
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sequences", type=int, default=1_000_000)
 ap.add_argument("--seconds", type=float, default=60.0)
 ap.add_argument("--threads", type=int, default=8)
+ap.add_argument("--side", type=int, default=0, help="SILO_GPU_TUNE_SIDE_STREAM (escape pass: 0 side stream, 2 caller's stream, 3 position-major keys)")
+ap.add_argument("--batch-share", type=float, default=0.05)
 args = ap.parse_args()
+bench.binding.load_library().silo_gpu_tune(5, args.side)
 
 engine, model, tree, lineage, window = bench.build_engine(args.sequences, 0, 1, None, 0, with_genes=True, with_metadata=True)
 rng = random.Random(1)
@@ -65,9 +70,17 @@ stop_at = time.perf_counter() + args.seconds
 def client(index):
     local = random.Random(100 + index)
     while time.perf_counter() < stop_at and not errors:
-        if local.random() < 0.05:
-            if engine.execute_batch_text(batch) != expected_batch:
-                errors.append(("batch", index))
+        if local.random() < args.batch_share:
+            got = engine.execute_batch_text(batch)
+            if got != expected_batch:
+                wrong = [k for k, (a, b) in enumerate(zip(got, expected_batch)) if a != b]
+                detail = ""
+                if wrong:
+                    a, b = json.loads(got[wrong[0]][1]), json.loads(expected_batch[wrong[0]][1])
+                    rows_a, rows_b = a.get("queryResult", a), b.get("queryResult", b)
+                    differing = [(x, y) for x, y in zip(rows_a, rows_b) if x != y][:3] if isinstance(rows_a, list) else (a, b)
+                    detail = f"rows {len(rows_a) if isinstance(rows_a, list) else '-'} vs {len(rows_b) if isinstance(rows_b, list) else '-'}; first differences {differing}"
+                errors.append(("batch", index, wrong, detail))
         else:
             k = local.randrange(len(queries))
             if engine.execute_text(queries[k]) != expected[k]:
