@@ -682,13 +682,10 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
 // for a few hundred rows must not pay for 112 GB.  k_compact_filter lists the 64-byte SECTORS (8 consecutive words —
 // the unit HBM delivers) of the filter that hold a set bit, at most `capacity` of them (the total is counted
 // regardless); when they fit, k_scan_gather reads only those sectors of every plane and k_scan_sliced skips the
-// filter.  The decision is taken on the device from the counter: no host round trip.  Measured at 10 M sequences
-// (profiles/r01_sparse_filters.md): ~1 µs per listed sector against 16.5 ms for the dense scan, hence the default
-// capacity of row_words / 16 sectors.
+// filter.  The decision is taken on the device from the counters (takesGatherScan): no host round trip.  Measured at 10 M
+// sequences (profiles/r01_sparse_filters.md, r02_one_hot_rows.md): ~0.9 µs per listed sector of the genome against 6 ms for
+// the dense scan, hence the default capacity of row_words / 16 sectors.
 // ------------------------------------------------------------------------------------------------
-// the index pays while the escapes of a position cost less than streaming the plane rows it saves: a key costs about as
-// much as 40 plane bytes (7.6 M keys in 46 us, profiles/r01_compact_index.md), i.e. break-even at N/320 keys per position
-constexpr uint64_t COMPACT_ESCAPE_DIVISOR = 512;
 
 __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
    const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index
