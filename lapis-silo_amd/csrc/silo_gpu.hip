@@ -150,11 +150,6 @@ __host__ __device__ inline uint64_t* planePtr(const SeqStoreDev& s, uint32_t pos
    return nullptr;
 }
 
-/// The build-time planes of a position (append / generate / the re-encoding at finalize).
-__host__ __device__ inline const uint64_t* scanPlanes(const SeqStoreDev& s, uint32_t position) {
-   return s.scan + static_cast<size_t>(position) * s.n_bits * s.row_words;
-}
-
 /// Where a position sits in the adaptive planes and how its codes read.
 struct PositionLayout {
    const uint64_t* rows;  // first plane row

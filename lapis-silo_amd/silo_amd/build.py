@@ -33,6 +33,8 @@ def _run(cmd):
     if proc.returncode != 0:
         sys.stderr.write(proc.stdout + proc.stderr)
         raise RuntimeError("build step failed: " + " ".join(cmd))
+    if "warning:" in proc.stderr:  # the builds are warning-free (-Wall -Wextra): a new warning should be seen
+        sys.stderr.write(proc.stderr)
     return proc
 
 
