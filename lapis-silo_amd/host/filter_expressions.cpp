@@ -22,17 +22,6 @@ RowSpace rowsOf(const DatabasePartition& partition) {
    return {partition.sequence_count, &partition};
 }
 
-std::string join(const std::vector<std::string>& parts, const std::string& separator) {
-   std::string out;
-   for (size_t i = 0; i < parts.size(); ++i) {
-      if (i != 0) {
-         out += separator;
-      }
-      out += parts[i];
-   }
-   return out;
-}
-
 // nucleotide_symbol_equals.cpp:28-73
 using NS = Nucleotide::Symbol;
 const std::array<std::vector<NS>, Nucleotide::COUNT> AMBIGUITY_NUC_SYMBOLS{{
