@@ -458,7 +458,7 @@ int silo_engine_execute_batch(const silo_engine* engine, const char* const* quer
    std::exception_ptr whole_batch_error;
    try {
       const silo::query_engine::QueryEngine query_engine(engine->database);
-      outcomes = query_engine.executeQueries(queries);
+      outcomes = query_engine.executeQueries(queries, true);
    } catch (...) {  // a failed shared launch fails every query of the batch
       whole_batch_error = std::current_exception();
       outcomes.assign(n_queries, {});
@@ -471,7 +471,7 @@ int silo_engine_execute_batch(const silo_engine* engine, const char* const* quer
          if (error != nullptr) {
             std::rethrow_exception(error);
          }
-         out_jsons[i] = duplicate(silo::query_engine::toJsonText(outcomes[i].result));
+         out_jsons[i] = duplicate(outcomes[i].json);
          out_http_statuses[i] = 200;
       } catch (const silo::QueryParseException& ex) {
          out_jsons[i] = duplicate(errorDocument("Bad request", ex.what()));

@@ -192,7 +192,7 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
    return rows;
 }
 
-std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries) const {
+std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries, bool render_json) const {
    Trace::reset();
    checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");
    std::vector<BatchOutcome> outcomes(queries.size());
@@ -298,6 +298,9 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
       try {
          Database::queryFingerprint() = database.all_reduce != nullptr ? Database::fingerprintOf(queries[i]) : 0;
          outcomes[i].result = parsed[i]->action->finish(database, *pending[i]);
+         if (render_json) {  // here rather than after the batch: the device is still busy with the scans of the queries behind this one
+            outcomes[i].json = toJsonText(outcomes[i].result);
+         }
       } catch (...) {
          outcomes[i].error = std::current_exception();
       }

@@ -739,11 +739,12 @@ class QueryEngine {
    /// exactly as for a single query, silo_api/query_handler.cpp:42-73).
    struct BatchOutcome {
       QueryResult result;
+      std::string json;  // the response body, when executeQueries was asked to render it (while later queries' scans still run)
       std::exception_ptr error;
    };
    /// Executes a batch of independent queries: filters are evaluated per query, then the Mutations scans of all
    /// queries that read the same sequence store are issued together, several filters per pass over the planes.
-   [[nodiscard]] std::vector<BatchOutcome> executeQueries(const std::vector<std::string>& queries) const;
+   [[nodiscard]] std::vector<BatchOutcome> executeQueries(const std::vector<std::string>& queries, bool render_json = false) const;
 };
 
 }  // namespace query_engine
