@@ -991,9 +991,12 @@ struct EscapeSliceArgs {
    } ranges[ESCAPE_MAX_RANGES];
 };
 
-__global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(const EscapeSliceArgs args) {
-   __shared__ uint32_t s_filter[ESCAPE_SLICE_WORDS32];
-   const uint32_t q = blockIdx.z;
+/// FILTERS = filters a block serves with one pass over its keys (1, or 2 for batches: two 64 KiB filter slices in LDS, half the
+/// key traffic per filter); blockIdx.z = first filter / FILTERS.
+template <int FILTERS>
+__global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
+   extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32]
+   const uint32_t first_filter = blockIdx.z * FILTERS;
    const uint32_t lane = threadIdx.x & 63u;
    const uint32_t slice = blockIdx.y % args.n_slices;
    const EscapeSliceArgs::Range& range = args.ranges[blockIdx.y / args.n_slices];
@@ -1004,15 +1007,17 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
       return;  // (uniform) no chunk for this block
    }
    uint64_t any_bit = 0;
-   {  // this slice of the filter: 8 words (4 x 16 bytes) per thread, zeros past the end of the row
+#pragma unroll
+   for (int f = 0; f < FILTERS; ++f) {  // this slice of every filter: 8 words (4 x 16 bytes) per thread, zeros past the end of the row (and for a filter past the last)
       const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
-      const uint64_t* filter = args.filters[q];
+      const bool present = first_filter + f < n_filters;
+      const uint64_t* filter = args.filters[present ? first_filter + f : first_filter];
 #pragma unroll
       for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS; ++j) {
          const uint32_t chunk = j * ESCAPE_SLICE_THREADS + threadIdx.x;  // 16-byte chunk of the slice
          const uint32_t word = first_word + chunk * 2u;
-         const ulonglong2 v = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
-         *reinterpret_cast<ulonglong2*>(s_filter + chunk * 4u) = v;
+         const ulonglong2 v = present && word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
+         *reinterpret_cast<ulonglong2*>(s_filter + f * ESCAPE_SLICE_WORDS32 + chunk * 4u) = v;
          any_bit |= v.x | v.y;
       }
    }
@@ -1020,7 +1025,6 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
       return;  // no row of this slice is selected: none of its keys counts
    }
    const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
-   uint32_t* __restrict__ counts = range.counts[q];
    for (uint32_t base = key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS; base < key_end; base += gridDim.x * ESCAPE_CHUNK_KEYS) {  // uniform per block
       uint64_t key[ESCAPE_KEYS_IN_FLIGHT];
 #pragma unroll
@@ -1032,18 +1036,22 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
       for (uint32_t k = 0; k < ESCAPE_KEYS_IN_FLIGHT; ++k) {
          const bool valid = key[k] != ~0ull;  // (no key is all ones: the symbol field holds at most 21)
          const uint32_t local = valid ? static_cast<uint32_t>(key[k]) - slice_first_row : 0u;
-         bool pending = valid && ((s_filter[local >> 5] >> (local & 31u)) & 1u) != 0;
          // keys of one (position, symbol) sit together: one atomic per distinct counter and wave, not per key
          const uint32_t counter = (static_cast<uint32_t>(key[k] >> 37) - range.pos_begin) * args.out_symbols + (static_cast<uint32_t>(key[k] >> 32) & 31u);
-         for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
-            const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
-            const uint32_t leader_counter = __shfl(counter, leader);
-            const uint64_t same = __ballot(pending && counter == leader_counter);
-            if (lane == leader) {
-               atomicAdd(&counts[leader_counter], static_cast<uint32_t>(__popcll(same)));
-            }
-            if (counter == leader_counter) {
-               pending = false;
+#pragma unroll
+         for (int f = 0; f < FILTERS; ++f) {
+            bool pending = valid && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (local >> 5)] >> (local & 31u)) & 1u) != 0;
+            uint32_t* __restrict__ counts = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
+            for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
+               const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
+               const uint32_t leader_counter = __shfl(counter, leader);
+               const uint64_t same = __ballot(pending && counter == leader_counter);
+               if (lane == leader) {
+                  atomicAdd(&counts[leader_counter], static_cast<uint32_t>(__popcll(same)));
+               }
+               if (counter == leader_counter) {
+                  pending = false;
+               }
             }
          }
       }
@@ -2582,8 +2590,25 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          return SILO_GPU_OK;
       }
       // at most two chunks per block: short blocks keep the launch balanced whatever the slices hold
-      const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, q_count);
-      k_scan_escapes_sliced<<<grid, ESCAPE_SLICE_THREADS, 0, hip_stream>>>(sliced);
+      static std::once_flag lds_once;
+      std::call_once(lds_once, [] {  // two filter slices: 128 KiB of LDS, beyond what a kernel may ask for by default
+         (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(k_scan_escapes_sliced<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            2 * ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
+         );
+         (void)hipFuncSetAttribute(
+            reinterpret_cast<const void*>(k_scan_escapes_sliced<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
+         );
+      });
+      const size_t slice_bytes = ESCAPE_SLICE_WORDS32 * sizeof(uint32_t);
+      if (q_count == 1) {
+         const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, 1);
+         k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, slice_bytes, hip_stream>>>(sliced, q_count);
+      } else {  // a batch: two filters per pass over the keys
+         const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, (q_count + 1) / 2);
+         k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, 2 * slice_bytes, hip_stream>>>(sliced, q_count);
+      }
       HIP_TRY(hipGetLastError());
       n_sliced = 0;
       most_chunks = 0;
