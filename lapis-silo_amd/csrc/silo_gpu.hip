@@ -965,10 +965,11 @@ __global__ __launch_bounds__(256) void k_scan_escapes(
 /// The escape pass over the SLICE-major copy of the keys.  A key costs one filter-bit lookup, and 64 lanes looking up 64
 /// rows of a 1.25 MB filter pull 64 cache lines through the L2 for 64 bits (45 M keys: 5.8 GB of line traffic, 0.28 ms —
 /// as much as 40 plane bytes per key).  Here a block owns one slice of the rows, copies that slice of the filter into LDS
-/// (64 KiB for 2^19 rows) and streams the slice's keys of the scanned positions against it: a lookup is an LDS read.
-constexpr uint32_t ESCAPE_SLICE_SHIFT = 19;                    // 2^19 rows = 8192 filter words = 64 KiB of LDS
+/// (16 KiB for 2^17 rows) and streams the slice's keys of the scanned positions against it: a lookup is an LDS read.
+constexpr uint32_t ESCAPE_SLICE_SHIFT = 17;                    // 2^17 rows = 2048 filter words = 16 KiB of LDS per filter
 constexpr uint32_t ESCAPE_SLICE_WORDS32 = (1u << ESCAPE_SLICE_SHIFT) / 32u;
-constexpr uint32_t ESCAPE_MAX_SLICES = 64;
+constexpr uint32_t ESCAPE_SLICE_BITS = 8;                      // sequence bits that number the slices
+constexpr uint32_t ESCAPE_MAX_SLICES = 1u << ESCAPE_SLICE_BITS;  // 33.5 M rows
 constexpr uint32_t ESCAPE_SLICE_THREADS = 1024;
 constexpr uint32_t ESCAPE_KEYS_IN_FLIGHT = 16;                 // per thread: the key loads of a chunk are all issued before the first is used
 constexpr uint32_t ESCAPE_CHUNK_KEYS = ESCAPE_SLICE_THREADS * ESCAPE_KEYS_IN_FLIGHT;
@@ -991,8 +992,8 @@ struct EscapeSliceArgs {
    } ranges[ESCAPE_MAX_RANGES];
 };
 
-/// FILTERS = filters a block serves with one pass over its keys (1, or 2 for batches: two 64 KiB filter slices in LDS, half the
-/// key traffic per filter); blockIdx.z = first filter / FILTERS.
+/// FILTERS = filters a block serves with ONE pass over its keys (1, 2, 4 or 8: a batch of 8 filters keeps 8 x 16 KiB of filter
+/// slices in LDS and reads every key once, not once per filter); blockIdx.z = first filter / FILTERS.
 template <int FILTERS>
 __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
    extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32]
@@ -1008,7 +1009,7 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
    }
    uint64_t any_bit = 0;
 #pragma unroll
-   for (int f = 0; f < FILTERS; ++f) {  // this slice of every filter: 8 words (4 x 16 bytes) per thread, zeros past the end of the row (and for a filter past the last)
+   for (int f = 0; f < FILTERS; ++f) {  // this slice of every filter: 16 bytes per thread, zeros past the end of the row (and for a filter past the last)
       const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
       const bool present = first_filter + f < n_filters;
       const uint64_t* filter = args.filters[present ? first_filter + f : first_filter];
@@ -2591,23 +2592,20 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       }
       // at most two chunks per block: short blocks keep the launch balanced whatever the slices hold
       static std::once_flag lds_once;
-      std::call_once(lds_once, [] {  // two filter slices: 128 KiB of LDS, beyond what a kernel may ask for by default
+      std::call_once(lds_once, [] {  // eight filter slices: 128 KiB of LDS, beyond what a kernel may ask for by default
          (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(k_scan_escapes_sliced<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            2 * ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
-         );
-         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(k_scan_escapes_sliced<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
+            reinterpret_cast<const void*>(k_scan_escapes_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            8 * ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
          );
       });
       const size_t slice_bytes = ESCAPE_SLICE_WORDS32 * sizeof(uint32_t);
-      if (q_count == 1) {
-         const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, 1);
-         k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, slice_bytes, hip_stream>>>(sliced, q_count);
-      } else {  // a batch: two filters per pass over the keys
-         const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, (q_count + 1) / 2);
-         k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, 2 * slice_bytes, hip_stream>>>(sliced, q_count);
+      const uint32_t per_block = q_count <= 1 ? 1 : (q_count <= 2 ? 2 : (q_count <= 4 ? 4 : 8));  // filters per pass over the keys
+      const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
+      switch (per_block) {
+         case 1: k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, slice_bytes, hip_stream>>>(sliced, q_count); break;
+         case 2: k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, 2 * slice_bytes, hip_stream>>>(sliced, q_count); break;
+         case 4: k_scan_escapes_sliced<4><<<grid, ESCAPE_SLICE_THREADS, 4 * slice_bytes, hip_stream>>>(sliced, q_count); break;
+         default: k_scan_escapes_sliced<8><<<grid, ESCAPE_SLICE_THREADS, 8 * slice_bytes, hip_stream>>>(sliced, q_count); break;
       }
       HIP_TRY(hipGetLastError());
       n_sliced = 0;
@@ -2948,7 +2946,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
          discardSliced();
          SILO_LAYOUT_TRY(status);
       }
-      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + 6); rc != SILO_GPU_OK) {
+      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + ESCAPE_SLICE_BITS); rc != SILO_GPU_OK) {
          discardSliced();
          discard();
          return rc;

@@ -247,7 +247,7 @@ def test_config3_scan_at_10m_adaptive_planes_identity_planes_and_c_port_agree(fu
 
 def test_config3_amino_acid_scan_at_10m_layouts_and_c_port_agree(built):
     """The amino-acid leg of configs[3] at its full size: the 12 genes of 10 M sequences re-encoded at finalize (one-hot rows,
-    2 / 3 code planes, identity planes — whatever each position got, 230 M escape keys in 20 slices) against the same genes
+    2 / 3 code planes, identity planes — whatever each position got, 230 M escape keys in 77 slices) against the same genes
     kept on their 5 identity planes (k_scan_sliced<5,22>: another layout, another kernel, no keys), whole genes; windows of S
     and E against the C port of the reference algorithm; the AminoAcidMutations query of the bench on both engines."""
     from silo_amd import alphabet

@@ -290,7 +290,7 @@ def settle_positions(rng, sym, columns, alphabet, second=0.0002):
         sym[:, p] = rng.choice(table.count, size=len(sym), p=probs / probs.sum())
 
 
-@pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc"), (1200003, "nuc")])  # the last: 3 slices of escape keys
+@pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc"), (1200003, "nuc")])  # the last: 10 slices of escape keys
 def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
     """finalize() re-encodes alignment-like data per position into one-hot rows (1-3 symbols) or 2 code planes (3 symbols)
     + escape keys, and releases the build-time planes; knob 2 leaves the one-hot rows out, with the re-encoding switched off
@@ -357,7 +357,7 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             assert np.array_equal(store.mutations_scan(0, None), want[2])
             for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
                 assert np.array_equal(got, table), knob
-            # the escape pass on the caller's stream (2) and over the position-major keys (3: what stores of more than 64 slices use)
+            # the escape pass on the caller's stream (2) and over the position-major keys (3: what stores of more than 256 slices use)
             for mode in (2, 3):
                 store.tune(5, mode)
                 try:
