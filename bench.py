@@ -842,7 +842,7 @@ def main():
             "mutation_rows": len(rows_aa_full),
         }
         result["config"]["database"] = (f"one database on one GPU: nucleotide genome ({scan_rows} plane rows) + 12 genes ({sum(rows_per_gene.values())} plane rows) "
-                                        f"+ the missing-symbol planes, {engine.partition_store(0).device_bytes / 1e9:.1f} GB of HBM")
+                                        f"+ the runs of the missing symbol, {engine.partition_store(0).device_bytes / 1e9:.1f} GB of HBM")
         if not args.no_client_threads:
             result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
         result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)

@@ -402,6 +402,7 @@ enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SI
        SILO_GPU_TUNE_COMPACT_INDEX = 4 /* finalize: < 0 keeps the build-time identity planes, 0 (default) re-encodes every position into its cheapest
                                           layout (one-hot rows, 2 / 3 code planes, identity planes), 2 the same without one-hot rows */,
        SILO_GPU_TUNE_KEY_COST = 6 /* finalize: > 0 = the cost of an escape key, in plane bytes, in the choice of layouts (experiments) */,
+       SILO_GPU_TUNE_MISSING_RUNS = 8 /* finalize: < 0 keeps the plane of the missing symbol (N / X) instead of turning it into runs */,
        SILO_GPU_TUNE_SCAN_TIMING = 7 /* 1: bracket every plane-scan launch with HIP events (silo_gpu_scan_timings) */,
        SILO_GPU_TUNE_SIDE_STREAM = 5 /* the escape-key pass of a scan: 0 (default) on a side stream of the lowest priority, 1 of default priority, 2 on the caller's stream */,
        SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };

@@ -15,6 +15,9 @@ int silo_gpu_internal_sort_keys(uint64_t* keys_dev, size_t n);
 /// The same by the key bits [begin_bit, end_bit) only; stable (keys equal in those bits keep their order).
 int silo_gpu_internal_sort_keys_by_bits(uint64_t* keys_dev, size_t n, int begin_bit, int end_bit);
 
+/// Sorts n (64-bit key, 32-bit value) pairs in device memory by key, ascending, in place; synchronises the null stream.
+int silo_gpu_internal_sort_pairs(uint64_t* keys_dev, uint32_t* values_dev, size_t n);
+
 #define SILO_HIP_TRY(expr)                                                                                  \
    do {                                                                                                     \
       hipError_t err_ = (expr);                                                                             \

@@ -40,6 +40,7 @@ std::atomic<int> g_tune_eval_leaf_batch{0};
 std::atomic<int> g_tune_compact_index{0};  // < 0: never scan the compact index (K1i), even where one was built
 std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream of the lowest priority, 1 = of default priority, 2 = the caller's stream, 3 = as 0 with the position-major keys (k_scan_escapes)
 std::atomic<int> g_tune_scan_timing{0};     // 1: HIP events around every plane-scan launch (silo_gpu_scan_timings)
+std::atomic<int> g_tune_missing_runs{0};    // < 0: finalize keeps the plane of the missing symbol instead of turning it into runs
 std::atomic<int> g_tune_key_cost{0};        // > 0: what an escape key costs in plane bytes in the layout choice (default KEY_COST_BYTES)
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
@@ -101,7 +102,12 @@ uint32_t missingSymbol(uint32_t alphabet) {
 // ------------------------------------------------------------------------------------------------
 // device-side description of one sequence store (passed to kernels by value)
 // ------------------------------------------------------------------------------------------------
-enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2 };
+enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2, PLANE_RUNS = 3 };
+
+// PLANE_RUNS: after finalize the missing symbol (N / X: amplicon drop-outs, unsequenced ends — long runs of a row, 0.5 % of
+// the cells but a plane per position, half of a finished nucleotide store) is kept as the sorted list of its runs — positions
+// [start, end) of one sequence — instead: the reference keeps it row-wise too (missing_symbol_bitmaps,
+// sequence_store.cpp:153-190).  A position's plane is materialised from the runs when a filter leaf asks for it.
 
 // Layout of a position in the adaptive planes (code_map[p][0], layout_choice.h): the number of plane rows, and whether they
 // are identity code planes (code = index of the valid mutation symbol + 1, no escapes: the position keeps its full planes) ...
@@ -119,7 +125,10 @@ struct SeqStoreDev {
    // finalize re-encodes them into the adaptive planes below and frees them (scan == nullptr from then on) unless the
    // store keeps them as they are (short rows, compact layouts switched off): then planes == scan.
    uint64_t* scan;
-   uint64_t* extra;  // [n_extra][P][Wp]
+   uint64_t* extra;  // [n_extra][P][Wp]; nullptr once the missing symbol's plane has become runs (kind PLANE_RUNS)
+   const uint64_t* missing_run_keys;  // sequence << 32 | start, ascending
+   const uint32_t* missing_run_ends;  // the run's end (exclusive)
+   uint32_t n_missing_runs;
    // ADAPTIVE code planes, what every consumer reads after finalize.  Position p owns plane rows
    // [row_of[p], row_of[p + 1]) of `planes`: B = 2 or 3 planes carrying the codes 1..2^B-1 of the position's most frequent
    // valid symbols (code_map), every other valid symbol of a row listed in `escapes`; or the n_bits identity planes.
@@ -220,6 +229,9 @@ struct SeqStoreHost {
    // cardinalities for a full filter (mutations.cpp:98-136); computed by one scan on first use
    uint32_t* d_totals = nullptr;
    bool totals_ready = false;
+   // the runs of the missing symbol (PLANE_RUNS), owned
+   uint64_t* d_missing_run_keys = nullptr;
+   uint32_t* d_missing_run_ends = nullptr;
    // The adaptive code planes of the finalized store (see SeqStoreDev and buildLayout).
    struct Run {  // consecutive positions of one layout: a scan launch takes runs of ONE layout
       uint32_t begin;
@@ -1573,6 +1585,110 @@ __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence
    }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The runs of the missing symbol.  k_missing_runs walks the plane [P][Wp] of the symbol along the positions: a wave owns one
+// word column (64 consecutive sequences, one per lane), the 8 waves of a block the 8 columns of a 64-byte sector, so that the
+// block reads every sector of the plane once.  WRITE = false counts the runs, WRITE = true emits them (sequence << 32 |
+// start, end) through one atomic cursor; they are sorted afterwards.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t RUN_BLOCK_THREADS = 512;
+
+template <bool WRITE>
+__global__ __launch_bounds__(RUN_BLOCK_THREADS) void k_missing_runs(
+   const uint64_t* __restrict__ plane, uint32_t positions, uint32_t row_words, unsigned long long* __restrict__ n_runs, uint64_t* __restrict__ run_keys,
+   uint32_t* __restrict__ run_ends, unsigned long long capacity
+) {
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t word = blockIdx.x * (RUN_BLOCK_THREADS / 64) + (threadIdx.x >> 6);
+   if (word >= row_words) {
+      return;  // (uniform per wave)
+   }
+   const uint32_t sequence = word * 64u + lane;
+   bool in_run = false;
+   uint32_t start = 0;
+   uint32_t counted = 0;
+   const auto emit = [&](bool ends_here, uint32_t end) {
+      if constexpr (WRITE) {
+         const uint64_t ending = __ballot(ends_here);
+         if (ending != 0) {
+            unsigned long long first = 0;
+            if (lane == static_cast<uint32_t>(__builtin_ctzll(ending))) {
+               first = atomicAdd(n_runs, static_cast<unsigned long long>(__popcll(ending)));
+            }
+            first = __shfl(first, __builtin_ctzll(ending));
+            const unsigned long long slot = first + static_cast<unsigned long long>(__popcll(ending & ((1ull << lane) - 1ull)));
+            if (ends_here && slot < capacity) {
+               run_keys[slot] = (static_cast<uint64_t>(sequence) << 32) | start;
+               run_ends[slot] = end;
+            }
+         }
+      } else {
+         counted += ends_here ? 1u : 0u;
+      }
+   };
+   constexpr uint32_t AHEAD = 8;  // plane words in flight per wave
+   for (uint32_t base = 0; base < positions; base += AHEAD) {
+      uint64_t words[AHEAD];
+#pragma unroll
+      for (uint32_t k = 0; k < AHEAD; ++k) {
+         const uint32_t p = min(base + k, positions - 1u);
+         words[k] = plane[static_cast<size_t>(p) * row_words + word];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < AHEAD; ++k) {
+         const uint32_t p = base + k;
+         const bool inside = p < positions;  // (uniform) the last group may reach past the end: no state changes there
+         const bool set = inside && ((words[k] >> lane) & 1ull) != 0;
+         emit(inside && in_run && !set, p);
+         if (set && !in_run) {
+            start = p;
+         }
+         in_run = inside ? set : in_run;
+      }
+   }
+   emit(in_run, positions);
+   if constexpr (!WRITE) {
+      const uint32_t wave_total = waveSumToLane63(counted);
+      if (lane == 63u && wave_total != 0) {
+         atomicAdd(n_runs, static_cast<unsigned long long>(wave_total));
+      }
+   }
+}
+
+/// The plane of the missing symbol at one position out of its runs: one thread per run (`out` zeroed beforehand).
+__global__ __launch_bounds__(256) void k_runs_to_plane(
+   const uint64_t* __restrict__ run_keys, const uint32_t* __restrict__ run_ends, uint32_t n_runs, uint32_t position, uint64_t* __restrict__ out
+) {
+   const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+   if (run >= n_runs) {
+      return;
+   }
+   const uint64_t key = run_keys[run];
+   if (static_cast<uint32_t>(key) <= position && position < run_ends[run]) {
+      const uint32_t sequence = static_cast<uint32_t>(key >> 32);
+      atomicOr(reinterpret_cast<unsigned long long*>(out + (sequence >> 6)), 1ull << (sequence & 63u));
+   }
+}
+
+/// Does `sequence` have the missing symbol at `position`?  The last run that starts at or before the cell decides.
+__device__ __forceinline__ bool missingInRuns(const SeqStoreDev& store, uint32_t sequence, uint32_t position) {
+   const uint64_t cell = (static_cast<uint64_t>(sequence) << 32) | position;
+   uint32_t lo = 0, hi = store.n_missing_runs;
+   while (lo < hi) {  // first run whose (sequence, start) is beyond the cell
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (store.missing_run_keys[mid] <= cell) {
+         lo = mid + 1;
+      } else {
+         hi = mid;
+      }
+   }
+   if (lo == 0) {
+      return false;
+   }
+   const uint64_t key = store.missing_run_keys[lo - 1];
+   return static_cast<uint32_t>(key >> 32) == sequence && position < store.missing_run_ends[lo - 1];
+}
+
 // FastaAligned: one thread per (requested row, position) looks the row's bit up in every dense plane of the
 // position; a cell no dense plane claims holds a sparsely stored symbol (IUPAC code) and is found by binary search
 // for position << 37 | symbol << 32 | sequence in the sorted sparse keys.  A gather (one 8-byte word per plane),
@@ -1596,6 +1712,12 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
    for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
       if (store.kind[symbol] == PLANE_SCAN) {
          if (store.index[symbol] == coded_index) {
+            found = symbol;
+         }
+         continue;
+      }
+      if (store.kind[symbol] == PLANE_RUNS) {
+         if (missingInRuns(store, sequence, position)) {
             found = symbol;
          }
          continue;
@@ -1762,6 +1884,9 @@ int silo_gpu_tune(int knob, int value) {
    if (knob == SILO_GPU_TUNE_SCAN_TIMING) {
       return g_tune_scan_timing.exchange(value);
    }
+   if (knob == SILO_GPU_TUNE_MISSING_RUNS) {
+      return g_tune_missing_runs.exchange(value);
+   }
    return -1;
 }
 
@@ -1879,6 +2004,8 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_sparse);
       (void)hipFree(seqstore.d_sparse_count);
       (void)hipFree(seqstore.d_totals);
+      (void)hipFree(seqstore.d_missing_run_keys);
+      (void)hipFree(seqstore.d_missing_run_ends);
       (void)hipFree(seqstore.layout.planes);
       (void)hipFree(seqstore.layout.d_row_of);
       (void)hipFree(seqstore.layout.d_row_target);
@@ -2154,6 +2281,69 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
 
 namespace {
 /// Sorts the sparse keys of one sequence store and re-encodes its build-time planes into the adaptive code planes.
+/// finalize(): the plane of the missing symbol becomes the list of its runs (PLANE_RUNS) where that takes less than a quarter
+/// of the plane — always, for data whose missing cells come in runs — and the plane is released.
+int compactMissingPlane(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   SeqStoreDev& dev = seqstore.dev;
+   if (dev.n_extra != 1 || dev.extra == nullptr || dev.kind[dev.missing_symbol] != PLANE_EXTRA || dev.positions == 0 || g_tune_missing_runs.load() < 0) {
+      return SILO_GPU_OK;
+   }
+   const size_t plane_bytes = static_cast<size_t>(dev.positions) * dev.row_words * sizeof(uint64_t);
+   unsigned long long* d_count = nullptr;
+   HIP_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
+   const auto count_runs = [&](bool write, uint64_t* keys, uint32_t* ends, unsigned long long capacity, unsigned long long* out) -> int {
+      HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned long long)));
+      const uint32_t blocks = (dev.row_words + RUN_BLOCK_THREADS / 64 - 1) / (RUN_BLOCK_THREADS / 64);
+      if (write) {
+         k_missing_runs<true><<<blocks, RUN_BLOCK_THREADS>>>(dev.extra, dev.positions, dev.row_words, d_count, keys, ends, capacity);
+      } else {
+         k_missing_runs<false><<<blocks, RUN_BLOCK_THREADS>>>(dev.extra, dev.positions, dev.row_words, d_count, keys, ends, capacity);
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpy(out, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      return SILO_GPU_OK;
+   };
+   unsigned long long n_runs = 0;
+   int rc = count_runs(false, nullptr, nullptr, 0, &n_runs);
+   if (rc != SILO_GPU_OK || n_runs >= (1ull << 32) || n_runs * (sizeof(uint64_t) + sizeof(uint32_t)) > plane_bytes / 4) {
+      (void)hipFree(d_count);
+      return rc;  // scattered missing cells: the plane stays
+   }
+   uint64_t* d_keys = nullptr;
+   uint32_t* d_ends = nullptr;
+   const size_t slots = std::max<size_t>(n_runs, 1);
+   hipError_t status = hipMalloc(&d_keys, slots * sizeof(uint64_t));
+   status = status != hipSuccess ? status : hipMalloc(&d_ends, slots * sizeof(uint32_t));
+   if (status == hipSuccess) {
+      unsigned long long written = 0;
+      rc = count_runs(true, d_keys, d_ends, n_runs, &written);
+      if (rc == SILO_GPU_OK && written != n_runs) {
+         rc = fail(SILO_GPU_ERR_HIP, "runs of the missing symbol: the two passes over the plane disagree");
+      }
+      if (rc == SILO_GPU_OK) {
+         rc = silo_gpu_internal_sort_pairs(d_keys, d_ends, n_runs);  // by (sequence, start)
+      }
+   }
+   (void)hipFree(d_count);
+   if (status != hipSuccess || rc != SILO_GPU_OK) {
+      (void)hipFree(d_keys);
+      (void)hipFree(d_ends);
+      HIP_TRY(status);
+      return rc;
+   }
+   (void)hipFree(dev.extra);
+   dev.extra = nullptr;
+   store->device_bytes -= plane_bytes;
+   store->device_bytes += slots * (sizeof(uint64_t) + sizeof(uint32_t));
+   seqstore.d_missing_run_keys = d_keys;
+   seqstore.d_missing_run_ends = d_ends;
+   dev.missing_run_keys = d_keys;
+   dev.missing_run_ends = d_ends;
+   dev.n_missing_runs = static_cast<uint32_t>(n_runs);
+   dev.kind[dev.missing_symbol] = PLANE_RUNS;
+   return SILO_GPU_OK;
+}
+
 int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
    if (seqstore.layout.built) {
       return SILO_GPU_OK;
@@ -2175,7 +2365,10 @@ int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
       HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
    }
    seqstore.finalized = true;
-   return buildLayout(store, seqstore);
+   if (const int rc = buildLayout(store, seqstore); rc != SILO_GPU_OK) {
+      return rc;
+   }
+   return compactMissingPlane(store, seqstore);
 }
 }  // namespace
 
@@ -3383,6 +3576,15 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
             k_scatter_sparse<<<(end - begin + 255) / 256, 256, 0, hip_stream>>>(seqstore.layout.d_escapes, begin, end, dst_dev);
             HIP_TRY(hipGetLastError());
          }
+      }
+      return SILO_GPU_OK;
+   }
+   if (seqstore.dev.kind[symbol] == PLANE_RUNS) {  // the missing symbol: its runs that cover the position
+      HIP_TRY(hipMemsetAsync(dst_dev, 0, static_cast<size_t>(store->row_words) * sizeof(uint64_t), hip_stream));
+      const uint32_t n_runs = seqstore.dev.n_missing_runs;
+      if (n_runs > 0) {
+         k_runs_to_plane<<<(n_runs + 255) / 256, 256, 0, hip_stream>>>(seqstore.dev.missing_run_keys, seqstore.dev.missing_run_ends, n_runs, position, dst_dev);
+         HIP_TRY(hipGetLastError());
       }
       return SILO_GPU_OK;
    }

@@ -35,3 +35,37 @@ int silo_gpu_internal_sort_keys_by_bits(uint64_t* keys_dev, size_t n, int begin_
    SILO_HIP_TRY(status);
    return SILO_GPU_OK;
 }
+
+int silo_gpu_internal_sort_pairs(uint64_t* keys_dev, uint32_t* values_dev, size_t n) {
+   if (n < 2) {
+      return SILO_GPU_OK;
+   }
+   uint64_t* sorted_keys = nullptr;
+   uint32_t* sorted_values = nullptr;
+   void* scratch = nullptr;
+   size_t scratch_bytes = 0;
+   hipError_t status = hipMalloc(&sorted_keys, n * sizeof(uint64_t));
+   if (status == hipSuccess) {
+      status = hipMalloc(&sorted_values, n * sizeof(uint32_t));
+   }
+   if (status == hipSuccess) {
+      status = hipcub::DeviceRadixSort::SortPairs(nullptr, scratch_bytes, keys_dev, sorted_keys, values_dev, sorted_values, n, 0, 64, nullptr);
+   }
+   if (status == hipSuccess) {
+      status = hipMalloc(&scratch, scratch_bytes);
+   }
+   if (status == hipSuccess) {
+      status = hipcub::DeviceRadixSort::SortPairs(scratch, scratch_bytes, keys_dev, sorted_keys, values_dev, sorted_values, n, 0, 64, nullptr);
+   }
+   if (status == hipSuccess) {
+      status = hipMemcpy(keys_dev, sorted_keys, n * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+   }
+   if (status == hipSuccess) {
+      status = hipMemcpy(values_dev, sorted_values, n * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+   }
+   (void)hipFree(scratch);
+   (void)hipFree(sorted_keys);
+   (void)hipFree(sorted_values);
+   SILO_HIP_TRY(status);
+   return SILO_GPU_OK;
+}

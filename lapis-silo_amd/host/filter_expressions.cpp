@@ -87,6 +87,11 @@ std::unique_ptr<Operator> symbolPlane(
    const uint64_t* plane = store.getBitmap(position, symbol);
    if (symbol == SymbolType::SYMBOL_MISSING) {
       // nucleotide_symbol_equals.cpp:131-143 / aa_symbol_equals.cpp:55-62
+      if (plane == nullptr) {  // the store keeps the missing symbol as runs: the position's plane is built when the operator is lowered
+         return std::make_unique<operators::BitmapSelection>(
+            store.seqstore_id, position - store.position_begin, static_cast<uint32_t>(symbol), rows, operators::BitmapSelection::CONTAINS, position
+         );
+      }
       return std::make_unique<operators::BitmapSelection>(plane, rows, operators::BitmapSelection::CONTAINS, position);
    }
    if (plane == nullptr) {

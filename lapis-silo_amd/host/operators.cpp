@@ -516,16 +516,22 @@ uint32_t BitmapProducer::lower(ProgramBuilder& builder) const {
 
 // ---- BitmapSelection (bitmap_selection.cpp:33-71) -----------------------------------------------
 std::unique_ptr<Operator> BitmapSelection::copy() const {
-   return std::make_unique<BitmapSelection>(missing_plane, rows, comparator, value);
+   auto out = std::make_unique<BitmapSelection>(*this);
+   return out;
 }
 std::unique_ptr<Operator> BitmapSelection::negate() const {
-   return std::make_unique<BitmapSelection>(missing_plane, rows, comparator == CONTAINS ? NOT_CONTAINS : CONTAINS, value);
+   auto out = std::make_unique<BitmapSelection>(*this);
+   out->comparator = comparator == CONTAINS ? NOT_CONTAINS : CONTAINS;
+   return out;
 }
-const uint64_t* BitmapSelection::storedColumn(ProgramBuilder& /*builder*/) const {
-   return comparator == CONTAINS ? missing_plane : nullptr;
+const uint64_t* BitmapSelection::storedColumn(ProgramBuilder& builder) const {
+   if (comparator != CONTAINS) {
+      return nullptr;
+   }
+   return materialise ? builder.sparsePointer(seqstore_id, local_position, symbol) : missing_plane;
 }
 uint32_t BitmapSelection::lower(ProgramBuilder& builder) const {
-   const uint32_t operand = SILO_GPU_LEAF_OPERAND + builder.leaf(missing_plane);
+   const uint32_t operand = SILO_GPU_LEAF_OPERAND + (materialise ? builder.sparseLeaf(seqstore_id, local_position, symbol) : builder.leaf(missing_plane));
    if (comparator == CONTAINS) {
       return operand;
    }

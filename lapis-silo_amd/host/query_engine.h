@@ -233,6 +233,11 @@ class BitmapSelection : public Operator {
    enum Comparator { CONTAINS, NOT_CONTAINS };
    BitmapSelection(const uint64_t* missing_plane, RowSpace rows, Comparator comparator, uint32_t value)
        : Operator(rows), missing_plane(missing_plane), comparator(comparator), value(value) {}
+   /// The missing symbol of a store that keeps it as runs (no resident plane): the position's plane is materialised, and
+   /// cached, when the operator is lowered — like a sparsely stored symbol of an IndexScan.
+   BitmapSelection(uint32_t seqstore_id, uint32_t local_position, uint32_t symbol, RowSpace rows, Comparator comparator, uint32_t value)
+       : Operator(rows), missing_plane(nullptr), comparator(comparator), value(value), materialise(true), seqstore_id(seqstore_id),
+         local_position(local_position), symbol(symbol) {}
    Type type() const override { return BITMAP_SELECTION; }
    std::string toString() const override { return "BitmapSelection"; }
    std::unique_ptr<Operator> copy() const override;
@@ -244,6 +249,10 @@ class BitmapSelection : public Operator {
    const uint64_t* missing_plane;
    Comparator comparator;
    uint32_t value;  // the position, kept for parity with the reference's constructor
+   bool materialise = false;
+   uint32_t seqstore_id = 0;
+   uint32_t local_position = 0;
+   uint32_t symbol = 0;
 };
 
 class Complement : public Operator {

@@ -773,6 +773,52 @@ def test_filter_eval_batch_matches_numpy_and_single_launches(built, n):
             store.filter_eval_batch(programs + [(b.encode(b.OP_AND, 0, 5, 6), leaves, 2)])
 
 
+@pytest.mark.parametrize("n,alphabet,positions,run_share", [(70000, "nuc", 397, 0.5), (6000, "aa", 4, 0.0005), (150001, "nuc", 512, 0.5)])
+def test_missing_symbol_becomes_runs(built, n, alphabet, positions, run_share):
+    """finalize() turns the plane of the missing symbol (N / X) into the sorted list of its runs and releases the plane: runs
+    at the first and at the last position, rows that are missing throughout (null genomes), single cells, neighbouring runs;
+    position counts that are and are not multiples of the kernel's look-ahead.  Every position's plane (filter leaves),
+    FastaAligned and the scan answer as with the plane kept (SILO_GPU_TUNE_MISSING_RUNS < 0)."""
+    rng = np.random.default_rng(n + positions)
+    sym = random_symbols(rng, n, positions, alphabet)
+    missing = 15 if alphabet == "nuc" else 24
+    chars = NUC_CHARS if alphabet == "nuc" else AA_CHARS
+    sym[sym == missing] = 1  # the missing cells are placed below
+    start = rng.integers(0, positions, size=n)
+    length = rng.geometric(0.2, size=n)
+    has_run = rng.random(n) < run_share
+    columns = np.arange(positions)[None, :]
+    in_run = has_run[:, None] & (columns >= start[:, None]) & (columns < (start + length)[:, None])
+    second = (has_run & (rng.random(n) < 0.2))[:, None] & (columns >= (start + length + 1)[:, None]) & (columns < (start + length + 3)[:, None])
+    sym[in_run | second] = missing
+    sym[rng.random((n, positions)) < 0.001] = missing      # single cells
+    sym[rng.choice(n, size=7, replace=False)] = missing     # missing throughout
+    sym[:3, 0] = missing
+    sym[3:6, positions - 1] = missing
+    mask = rng.random(n) < 0.5
+    answers = {}
+    for knob in (0, -1):
+        with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy())]) as store:
+            store.tune(8, knob)
+            try:
+                store.append_sequences(0, 0, chars[sym])
+                store.finalize()
+            finally:
+                store.tune(8, 0)
+            assert (store.plane(0, 0, missing) is None) == (knob == 0)  # no resident plane once it has become runs
+            for position in sorted(set(range(0, positions, 7)) | {1, positions - 2, positions - 1}):
+                got = store.plane_download(0, position, missing)
+                want = dense.pack_bits(sym[:, position] == missing)
+                assert np.array_equal(got[: len(want)], want) and not got[len(want):].any(), (knob, position)
+            picked = np.concatenate([np.arange(8), rng.choice(n, size=60, replace=False), np.nonzero((sym == missing).all(axis=1))[0]]).astype(np.uint32)
+            assert np.array_equal(store.reconstruct_sequences(0, picked), chars[sym[picked]])
+            ptr = store.bitset_alloc()
+            store.bitset_upload(ptr, dense.pack_bits(mask))
+            assert np.array_equal(store.mutations_scan(0, ptr), dense.mutation_counts(sym, mask, list(store.scan_symbols[0])))
+            answers[knob] = store.device_bytes
+    assert answers[0] < answers[-1]
+
+
 def test_append_from_unaligned_pageable_memory_in_back_to_back_batches(built):
     """Regression test for the path behind round 1's GPU memory-access fault: silo_gpu_store_append_sequences
     fed from PAGEABLE host memory at an address that is not even 2-byte aligned, rows of a length that is not a multiple
