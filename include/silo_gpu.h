@@ -111,6 +111,19 @@ int silo_gpu_store_import_position(
    uint32_t flipped_symbol, uint32_t deleted_symbol
 );
 
+/* Two-pass build of a sequence store — for stores too large to hold their build-time planes beside the finished ones (the
+ * build-time planes are 3 / 5 per position; a finished nucleotide store about one): stream the sequences TWICE.
+ *   silo_gpu_store_build_pass(store, id, 1)   before the first sequence: the appends / generate calls that follow only COUNT
+ *                                             the valid symbols per position (no plane is allocated);
+ *   silo_gpu_store_build_pass(store, id, 2)   after all sequences have been seen once: the layout of every position is chosen
+ *                                             from the counts, the adaptive planes are allocated, and the same appends /
+ *                                             generate calls, repeated, write every row straight into them;
+ *   silo_gpu_store_finalize / _finalize_seqstore as usual (the escape keys are sorted; the missing symbol becomes runs).
+ * A store that would keep its identity planes anyway (short rows, compact_scan_index off) simply builds them in the second
+ * pass.  silo_gpu_store_build_mode: 0 ordinary, 1 counting, 2 encoding.  The roaring import is not available in this mode. */
+int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int pass);
+int silo_gpu_store_build_mode(const silo_gpu_store* store, uint32_t seqstore_id);
+
 /* Sorts the sparse triples gathered by append/generate; call once after the last append and
  * before any query.  (The reference's optimizeBitmaps, sequence_store.cpp:192-211, has no dense
  * analogue: flipped/deleted bitmaps are storage tricks) */

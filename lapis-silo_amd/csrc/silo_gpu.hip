@@ -103,6 +103,7 @@ uint32_t missingSymbol(uint32_t alphabet) {
 // device-side description of one sequence store (passed to kernels by value)
 // ------------------------------------------------------------------------------------------------
 enum : uint8_t { PLANE_SPARSE = 0, PLANE_SCAN = 1, PLANE_EXTRA = 2, PLANE_RUNS = 3 };
+enum : uint32_t { BUILD_PLANES = 0, BUILD_COUNT = 1, BUILD_ENCODE = 2 };
 
 // PLANE_RUNS: after finalize the missing symbol (N / X: amplicon drop-outs, unsequenced ends — long runs of a row, 0.5 % of
 // the cells but a plane per position, half of a finished nucleotide store) is kept as the sorted list of its runs — positions
@@ -129,6 +130,17 @@ struct SeqStoreDev {
    const uint64_t* missing_run_keys;  // sequence << 32 | start, ascending
    const uint32_t* missing_run_ends;  // the run's end (exclusive)
    uint32_t n_missing_runs;
+   // Two-pass build (silo_gpu_store_build_pass): BUILD_COUNT only counts the valid symbols per position (enc_counts
+   // [P][n_scan]); BUILD_ENCODE writes every row straight into its position's adaptive layout, chosen from those counts —
+   // no build-time planes at all.
+   uint32_t build_mode;
+   uint32_t* enc_counts;
+   const uint8_t* enc_code_map;
+   const uint32_t* enc_row_of;
+   uint64_t* enc_planes;
+   const uint32_t* enc_first;   // [P * n_scan + 1] first escape key of a (position, symbol)
+   uint32_t* enc_cursor;        // [P * n_scan] keys written so far
+   uint64_t* enc_escapes;
    // ADAPTIVE code planes, what every consumer reads after finalize.  Position p owns plane rows
    // [row_of[p], row_of[p + 1]) of `planes`: B = 2 or 3 planes carrying the codes 1..2^B-1 of the position's most frequent
    // valid symbols (code_map), every other valid symbol of a row listed in `escapes`; or the n_bits identity planes.
@@ -232,6 +244,9 @@ struct SeqStoreHost {
    // the runs of the missing symbol (PLANE_RUNS), owned
    uint64_t* d_missing_run_keys = nullptr;
    uint32_t* d_missing_run_ends = nullptr;
+   // a two-pass build between its passes / during the second (silo_gpu_store_build_pass): the layout in the making
+   struct LayoutWork;
+   std::shared_ptr<LayoutWork> work;
    // The adaptive code planes of the finalized store (see SeqStoreDev and buildLayout).
    struct Run {  // consecutive positions of one layout: a scan launch takes runs of ONE layout
       uint32_t begin;
@@ -264,6 +279,35 @@ struct SeqStoreHost {
    } layout;
 };
 
+/// A layout in the making (between planLayout and finishLayout): the host tables, the device arrays the finished store will
+/// own, and the two the encoders need on top (first key and cursor of every (position, symbol)).
+struct SeqStoreHost::LayoutWork {
+   std::vector<uint8_t> code_map;
+   std::vector<uint32_t> row_of, row_target, escape_first, escape_first_symbol;
+   std::vector<Run> runs;
+   uint64_t total_rows = 0, total_escapes = 0;
+   size_t plane_bytes = 0, escape_bytes = 0;
+   uint8_t* d_code_map = nullptr;
+   uint32_t* d_cursor = nullptr;
+   uint32_t* d_first = nullptr;
+   uint32_t* d_row_of = nullptr;
+   uint32_t* d_row_target = nullptr;
+   uint32_t* d_escape_first = nullptr;
+   uint64_t* d_planes = nullptr;
+   uint64_t* d_escapes = nullptr;
+   void discard() {
+      (void)hipFree(d_row_target);
+      (void)hipFree(d_code_map);
+      (void)hipFree(d_cursor);
+      (void)hipFree(d_first);
+      (void)hipFree(d_row_of);
+      (void)hipFree(d_escape_first);
+      (void)hipFree(d_planes);
+      (void)hipFree(d_escapes);
+      *this = LayoutWork{};
+   }
+};
+
 }  // namespace
 
 struct silo_gpu_store {
@@ -292,6 +336,8 @@ struct silo_gpu_store {
 namespace {
 
 int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore);  // the adaptive code planes, defined next to the scan launchers
+bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev);
+int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool* fits);
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -1301,17 +1347,61 @@ __device__ __forceinline__ void emitWord(
    const uint32_t lane = threadIdx.x & 63u;
    // valid mutation symbols: the bits of their code go to the bit-sliced scan planes
    const bool is_scan = symbol < store.n_symbols && store.kind[symbol] == PLANE_SCAN;
-   const uint32_t code = is_scan ? static_cast<uint32_t>(store.index[symbol]) + 1u : 0u;
-   uint64_t* scan_word = store.scan + static_cast<size_t>(position) * store.n_bits * store.row_words + word;
-   for (uint32_t bit = 0; bit < store.n_bits; ++bit) {
-      const uint64_t mask = __ballot(((code >> bit) & 1u) != 0);
+   const auto put = [&](uint64_t* dst, uint64_t mask) {  // one word of a plane row, by lane 0
       if (mask != 0 && lane == 0) {
-         uint64_t* dst = scan_word + static_cast<size_t>(bit) * store.row_words;
          if (whole_word) {
             *dst = mask;
          } else {
             atomicOr(reinterpret_cast<unsigned long long*>(dst), static_cast<unsigned long long>(mask));
          }
+      }
+   };
+   if (store.build_mode == BUILD_COUNT) {  // first pass of a two-pass build: how many rows have which valid symbol here
+      const uint32_t scan_index = is_scan ? store.index[symbol] : 0xFFu;
+      for (uint64_t remaining = __ballot(is_scan); remaining != 0;) {
+         const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(remaining));
+         const uint32_t leader_index = __shfl(scan_index, leader);
+         const uint64_t same = __ballot(is_scan && scan_index == leader_index);
+         if (lane == leader) {
+            atomicAdd(store.enc_counts + static_cast<size_t>(position) * store.n_scan + leader_index, static_cast<uint32_t>(__popcll(same)));
+         }
+         remaining &= ~same;
+      }
+      return;
+   }
+   if (store.build_mode == BUILD_ENCODE) {  // second pass: straight into the position's adaptive layout
+      const uint8_t* map = store.enc_code_map + static_cast<size_t>(position) * CODE_MAP_STRIDE;
+      const uint32_t rows_here = map[0] & 0x3Fu;
+      const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
+      const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
+      const uint32_t scan_index = is_scan ? store.index[symbol] : 0xFFu;
+      uint32_t code = 0;  // the code (or 1 + one-hot row) of this lane's symbol here, 0 = not stored
+      if (is_scan) {
+         if (identity) {
+            code = scan_index + 1u;
+         } else {
+            const uint32_t n_codes = one_hot ? rows_here + 1u : (1u << rows_here);
+            for (uint32_t candidate = 1; candidate < n_codes; ++candidate) {
+               code = map[candidate] == scan_index ? candidate : code;
+            }
+         }
+      }
+      uint64_t* rows = store.enc_planes + static_cast<size_t>(store.enc_row_of[position]) * store.row_words + word;
+      for (uint32_t row = 0; row < rows_here; ++row) {
+         put(rows + static_cast<size_t>(row) * store.row_words, __ballot(one_hot ? code == row + 1u : ((code >> row) & 1u) != 0));
+      }
+      if (is_scan && code == 0) {  // a valid symbol the position does not store: an escape key in the symbol's slice of the list
+         const size_t counter = static_cast<size_t>(position) * store.n_scan + scan_index;
+         const uint32_t slot = store.enc_first[counter] + atomicAdd(store.enc_cursor + counter, 1u);
+         if (slot < store.enc_first[counter + 1]) {  // (more rows than the first pass counted: dropped, the cursor tells)
+            store.enc_escapes[slot] = (static_cast<uint64_t>(position) << 37) | (static_cast<uint64_t>(scan_index) << 32) | (static_cast<uint64_t>(word) * 64u + lane);
+         }
+      }
+   } else {
+      const uint32_t code = is_scan ? static_cast<uint32_t>(store.index[symbol]) + 1u : 0u;
+      uint64_t* scan_word = store.scan + static_cast<size_t>(position) * store.n_bits * store.row_words + word;
+      for (uint32_t bit = 0; bit < store.n_bits; ++bit) {
+         put(scan_word + static_cast<size_t>(bit) * store.row_words, __ballot(((code >> bit) & 1u) != 0));
       }
    }
    // every other symbol: its own plane (extra) or the sorted key list (sparse)
@@ -1826,10 +1916,11 @@ int ensureBuildPlanes(silo_gpu_store* store, SeqStoreHost& seqstore) {
       );
    }
    SeqStoreDev& dev = seqstore.dev;
-   if (dev.scan != nullptr || dev.extra != nullptr) {
-      return SILO_GPU_OK;
+   if (dev.scan != nullptr || dev.extra != nullptr || dev.build_mode == BUILD_COUNT) {
+      return SILO_GPU_OK;  // (the counting pass of a two-pass build writes no plane at all)
    }
-   const size_t scan_bytes = static_cast<size_t>(dev.positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
+   // the encoding pass of a two-pass build writes the valid symbols straight into the adaptive planes: only the extra planes are built
+   const size_t scan_bytes = dev.build_mode == BUILD_ENCODE ? 0 : static_cast<size_t>(dev.positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
    const size_t extra_bytes = static_cast<size_t>(dev.positions) * dev.n_extra * dev.row_words * sizeof(uint64_t);
    if (scan_bytes > 0) {
       HIP_TRY(hipMalloc(&dev.scan, scan_bytes));
@@ -2006,6 +2097,9 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.d_totals);
       (void)hipFree(seqstore.d_missing_run_keys);
       (void)hipFree(seqstore.d_missing_run_ends);
+      if (seqstore.work) {  // a two-pass build that was never finalized
+         seqstore.work->discard();
+      }
       (void)hipFree(seqstore.layout.planes);
       (void)hipFree(seqstore.layout.d_row_of);
       (void)hipFree(seqstore.layout.d_row_target);
@@ -2059,7 +2153,7 @@ int silo_gpu_store_append_sequences(
       return rc;
    }
    seqstore.finalized = false;
-   seqstore.totals_ready = false;
+   seqstore.totals_ready = seqstore.dev.build_mode == BUILD_ENCODE;  // (the counts of the first pass ARE the totals)
    const uint32_t positions = seqstore.dev.positions;
    const uint32_t pitch = positions;  // rows stay contiguous: ONE host-to-device copy per batch
 
@@ -2160,7 +2254,7 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
       return rc;
    }
    seqstore.finalized = false;
-   seqstore.totals_ready = false;
+   seqstore.totals_ready = seqstore.dev.build_mode == BUILD_ENCODE;
    const uint32_t n = store->sequence_count;
    const uint32_t positions = seqstore.dev.positions;
 
@@ -2348,6 +2442,9 @@ int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
    if (seqstore.layout.built) {
       return SILO_GPU_OK;
    }
+   if (seqstore.dev.build_mode == BUILD_COUNT) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "the sequence store is in the counting pass of a two-pass build: the encoding pass has to follow before finalize");
+   }
    if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {  // a store that never received a sequence: all-zero planes
       return rc;
    }
@@ -2371,6 +2468,70 @@ int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
    return compactMissingPlane(store, seqstore);
 }
 }  // namespace
+
+int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int pass) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || (pass != 1 && pass != 2)) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_build_pass: bad arguments (pass 1 = counting, 2 = encoding)");
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   HIP_TRY(hipSetDevice(store->device));
+   SeqStoreHost& seqstore = store->seqstores[seqstore_id];
+   SeqStoreDev& dev = seqstore.dev;
+   if (seqstore.layout.built) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_build_pass: the sequence store is finalized");
+   }
+   const size_t n_counters = static_cast<size_t>(dev.positions) * dev.n_scan;
+   if (pass == 1) {
+      if (dev.scan != nullptr || dev.extra != nullptr || dev.build_mode != BUILD_PLANES) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_build_pass: the counting pass has to come before any sequence of the store");
+      }
+      if (seqstore.d_totals == nullptr) {
+         HIP_TRY(hipMalloc(&seqstore.d_totals, std::max<size_t>(n_counters, 1) * sizeof(uint32_t)));
+      }
+      HIP_TRY(hipMemset(seqstore.d_totals, 0, std::max<size_t>(n_counters, 1) * sizeof(uint32_t)));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      seqstore.totals_ready = false;
+      dev.enc_counts = seqstore.d_totals;
+      dev.build_mode = BUILD_COUNT;
+      return SILO_GPU_OK;
+   }
+   if (dev.build_mode != BUILD_COUNT) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_build_pass: the encoding pass follows the counting pass");
+   }
+   HIP_TRY(hipDeviceSynchronize());  // every count of the first pass has landed
+   dev.build_mode = BUILD_PLANES;
+   dev.enc_counts = nullptr;
+   seqstore.totals_ready = true;
+   if (!reencodes(store, dev)) {
+      seqstore.totals_ready = false;
+      return SILO_GPU_OK;  // a store that keeps its identity planes: the second pass builds them the ordinary way
+   }
+   auto work = std::make_shared<SeqStoreHost::LayoutWork>();
+   bool fits = false;
+   if (const int rc = planLayout(seqstore, *work, true, &fits); rc != SILO_GPU_OK) {
+      return rc;
+   }
+   if (!fits) {
+      seqstore.totals_ready = false;
+      return SILO_GPU_OK;
+   }
+   dev.enc_code_map = work->d_code_map;
+   dev.enc_row_of = work->d_row_of;
+   dev.enc_planes = work->d_planes;
+   dev.enc_first = work->d_first;
+   dev.enc_cursor = work->d_cursor;
+   dev.enc_escapes = work->d_escapes;
+   dev.build_mode = BUILD_ENCODE;
+   seqstore.work = std::move(work);
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_store_build_mode(const silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size()) {
+      return -1;
+   }
+   return static_cast<int>(store->seqstores[seqstore_id].dev.build_mode);
+}
 
 int silo_gpu_store_finalize(silo_gpu_store* store) {
    if (store == nullptr) {
@@ -2977,24 +3138,210 @@ int scanRanges(
 /// finalize(): derive the adaptive code planes of one sequence store (see chooseLayouts) and release its build-time
 /// planes — or keep those as they are when re-encoding would not pay (short rows), is switched off
 /// (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit next to them.
+/// Every position of the store keeps its n_bits identity planes, where they are (short rows, re-encoding switched off, or no room).
+int keepBuildPlanes(SeqStoreHost& seqstore) {
+   SeqStoreDev& dev = seqstore.dev;
+   seqstore.layout.runs.assign(1, SeqStoreHost::Run{0, dev.positions, static_cast<uint8_t>(dev.n_bits), true, false});
+   dev.planes = dev.scan;
+   dev.row_of = nullptr;
+   dev.code_map = nullptr;
+   dev.escapes = nullptr;
+   dev.escape_first = nullptr;
+   seqstore.layout.built = true;
+   return SILO_GPU_OK;
+}
+
+/// Is this a store finalize re-encodes (5 nucleotide / 22 amino-acid scan symbols, rows of at least one column tile)?
+bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev) {
+   const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
+   return (nucleotide || (dev.n_bits == 5 && dev.n_scan == 22)) && dev.row_words >= SCAN_THREADS * 4 && dev.positions != 0 && store->sequence_count != 0 &&
+          g_tune_compact_index.load() >= 0;
+}
+
+#define SILO_LAYOUT_TRY(expr)                                                       \
+   do {                                                                             \
+      const hipError_t status_ = (expr);                                            \
+      if (status_ != hipSuccess) {                                                  \
+         work.discard();                                                            \
+         HIP_TRY(status_);                                                          \
+      }                                                                             \
+   } while (0)
+
+/// From the totals of the store (seqstore.d_totals): the layout of every position, the tables that describe it and the device
+/// arrays of the finished store — the plane rows zeroed when `zero_planes` (an encoder that only sets bits).  *fits = false
+/// (nothing allocated) when no position would be re-encoded or the arrays do not fit.
+int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool* fits) {
+   SeqStoreDev& dev = seqstore.dev;
+   const uint32_t positions = dev.positions;
+   const size_t n_counters = static_cast<size_t>(positions) * dev.n_scan;
+   *fits = false;
+   std::vector<uint32_t> totals(n_counters);
+   HIP_TRY(hipMemcpy(totals.data(), seqstore.d_totals, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   std::vector<uint32_t> counts;  // escape keys per (position, symbol)
+   // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows (the layouts before one-hot rows, for comparisons)
+   silo_gpu_layout::chooseLayouts(
+      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2,
+      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, work.code_map, counts
+   );
+   work.row_of.assign(positions + 1, 0);
+   work.escape_first.assign(positions + 1, 0);
+   work.escape_first_symbol.assign(n_counters + 1, 0);
+   bool any_encoded = false;
+   for (uint32_t p = 0; p < positions; ++p) {
+      const uint8_t* map = work.code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
+      const uint8_t bits = map[0] & 0x3Fu;
+      const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
+      const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
+      any_encoded = any_encoded || !identity;
+      work.row_of[p] = static_cast<uint32_t>(work.total_rows);
+      work.total_rows += bits;
+      for (uint32_t row = 0; row < bits; ++row) {  // a row without a symbol (no valid symbol at the position at all) is empty: any counter of the position
+         work.row_target.push_back(one_hot ? p * dev.n_scan + (map[1 + row] != 0xFFu ? map[1 + row] : 0u) : 0xFFFFFFFFu);
+      }
+      work.escape_first[p] = static_cast<uint32_t>(work.total_escapes);
+      for (uint32_t symbol = 0; symbol < dev.n_scan; ++symbol) {
+         work.escape_first_symbol[static_cast<size_t>(p) * dev.n_scan + symbol] = static_cast<uint32_t>(work.total_escapes);
+         work.total_escapes += counts[static_cast<size_t>(p) * dev.n_scan + symbol];
+      }
+      const uint8_t run_bits = one_hot ? 0 : bits;
+      if (work.runs.empty() || work.runs.back().bits != run_bits || work.runs.back().identity != identity || work.runs.back().one_hot != one_hot) {
+         work.runs.push_back(SeqStoreHost::Run{p, p + 1, run_bits, identity, one_hot});
+      } else {
+         work.runs.back().end = p + 1;
+      }
+   }
+   work.row_of[positions] = static_cast<uint32_t>(work.total_rows);
+   work.escape_first[positions] = static_cast<uint32_t>(work.total_escapes);
+   work.escape_first_symbol[n_counters] = static_cast<uint32_t>(work.total_escapes);
+   work.plane_bytes = static_cast<size_t>(work.total_rows) * dev.row_words * sizeof(uint64_t);
+   work.escape_bytes = std::max<uint64_t>(work.total_escapes, 1) * sizeof(uint64_t);
+   size_t free_bytes = 0, total_bytes = 0;
+   HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+   // the sort of the keys needs as much again as the keys, their slice-major copy as well
+   if (!any_encoded || work.total_rows >= (uint64_t{1} << 32) || work.total_escapes >= (uint64_t{1} << 32) ||
+       free_bytes < work.plane_bytes + 4 * work.escape_bytes + (size_t{1} << 30)) {
+      work = SeqStoreHost::LayoutWork{};
+      return SILO_GPU_OK;
+   }
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_code_map, work.code_map.size()));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_cursor, n_counters * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_planes, work.plane_bytes));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_escapes, work.escape_bytes));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_first, work.escape_first_symbol.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_row_of, work.row_of.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_escape_first, work.escape_first.size() * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_row_target, std::max<size_t>(work.row_target.size(), 1) * sizeof(uint32_t)));
+   SILO_LAYOUT_TRY(hipMemcpy(work.d_code_map, work.code_map.data(), work.code_map.size(), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(work.d_first, work.escape_first_symbol.data(), work.escape_first_symbol.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(work.d_row_of, work.row_of.data(), work.row_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(work.d_row_target, work.row_target.data(), work.row_target.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemcpy(work.d_escape_first, work.escape_first.data(), work.escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   SILO_LAYOUT_TRY(hipMemset(work.d_cursor, 0, n_counters * sizeof(uint32_t)));
+   if (zero_planes) {
+      SILO_LAYOUT_TRY(hipMemset(work.d_planes, 0, work.plane_bytes));
+   }
+   SILO_LAYOUT_TRY(hipStreamSynchronize(nullptr));  // the fills are only enqueued (null stream)
+   *fits = true;
+   return SILO_GPU_OK;
+}
+
+/// The planned layout becomes the store: the keys are sorted (and copied slice-major for the scan's escape pass), the
+/// encoders' tables and any build-time planes are released, the device description switches to the adaptive planes.
+int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work) {
+   SeqStoreDev& dev = seqstore.dev;
+   SeqStoreHost::Layout& layout = seqstore.layout;
+   const uint32_t positions = dev.positions;
+   if (const int rc = silo_gpu_internal_sort_keys(work.d_escapes, work.total_escapes); rc != SILO_GPU_OK) {  // ascending: (position, symbol, sequence)
+      work.discard();
+      return rc;
+   }
+   // the slice-major copy of the keys for the scan's escape pass, and where each position's keys begin in every slice
+   uint64_t* d_escapes_sliced = nullptr;
+   uint32_t* d_slice_first = nullptr;
+   std::vector<uint32_t> slice_first;
+   const uint32_t n_slices = (store->sequence_count + (1u << ESCAPE_SLICE_SHIFT) - 1) >> ESCAPE_SLICE_SHIFT;
+   if (work.total_escapes > 0 && n_slices <= ESCAPE_MAX_SLICES) {
+      const size_t n_entries = static_cast<size_t>(n_slices) * (positions + 1);
+      const auto discardSliced = [&]() {
+         (void)hipFree(d_escapes_sliced);
+         (void)hipFree(d_slice_first);
+      };
+      hipError_t status = hipMalloc(&d_escapes_sliced, work.escape_bytes);
+      status = status != hipSuccess ? status : hipMalloc(&d_slice_first, n_entries * sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMemcpy(d_escapes_sliced, work.d_escapes, work.total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+      if (status != hipSuccess) {
+         discardSliced();
+         SILO_LAYOUT_TRY(status);
+      }
+      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, work.total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + ESCAPE_SLICE_BITS); rc != SILO_GPU_OK) {
+         discardSliced();
+         work.discard();
+         return rc;
+      }
+      k_slice_index<<<static_cast<uint32_t>((n_entries + 255) / 256), 256>>>(
+         d_escapes_sliced, static_cast<uint32_t>(work.total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
+      );
+      slice_first.resize(n_entries);
+      status = hipGetLastError();
+      status = status != hipSuccess ? status : hipMemcpy(slice_first.data(), d_slice_first, n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (status != hipSuccess) {
+         discardSliced();
+         SILO_LAYOUT_TRY(status);
+      }
+   }
+   (void)hipFree(work.d_first);
+   (void)hipFree(work.d_cursor);
+   work.d_first = nullptr;
+   work.d_cursor = nullptr;
+   if (dev.scan != nullptr) {  // the adaptive planes take over; the build-time planes go
+      const size_t build_bytes = static_cast<size_t>(positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
+      (void)hipFree(dev.scan);
+      dev.scan = nullptr;
+      store->device_bytes -= build_bytes;
+   }
+   layout.planes = work.d_planes;
+   layout.d_row_of = work.d_row_of;
+   layout.d_row_target = work.d_row_target;
+   layout.d_code_map = work.d_code_map;
+   layout.d_escapes = work.d_escapes;
+   layout.d_escapes_sliced = d_escapes_sliced;
+   layout.d_slice_first = d_slice_first;
+   layout.slice_shift = ESCAPE_SLICE_SHIFT;
+   layout.n_slices = d_escapes_sliced != nullptr ? n_slices : 0;
+   layout.slice_first = std::move(slice_first);
+   layout.d_escape_first = work.d_escape_first;
+   layout.row_of = std::move(work.row_of);
+   layout.code_map = std::move(work.code_map);
+   layout.escape_first = std::move(work.escape_first);
+   layout.escape_first_symbol = std::move(work.escape_first_symbol);
+   layout.runs = std::move(work.runs);
+   layout.device_bytes = work.plane_bytes + work.escape_bytes * (d_escapes_sliced != nullptr ? 2 : 1) + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
+                         work.total_rows * sizeof(uint32_t);
+   store->device_bytes += layout.device_bytes;
+   dev.planes = layout.planes;
+   dev.row_of = layout.d_row_of;
+   dev.code_map = layout.d_code_map;
+   dev.escapes = layout.d_escapes;
+   dev.escape_first = layout.d_escape_first;
+   layout.built = true;
+   work = SeqStoreHost::LayoutWork{};  // everything it owned is the store's now
+   return SILO_GPU_OK;
+}
+
+/// finalize(): derive the adaptive planes of one sequence store from its build-time planes and release those — or keep them as
+/// they are when re-encoding would not pay (short rows), is switched off (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit
+/// next to them.  A store built in two passes has been encoded already: only the keys remain to be put in order.
 int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SeqStoreDev& dev = seqstore.dev;
    SeqStoreHost::Layout& layout = seqstore.layout;
    const uint32_t positions = dev.positions;
-   const auto keepBuildPlanes = [&]() {  // every position: the n_bits identity planes, where they are
-      layout.runs.assign(1, SeqStoreHost::Run{0, positions, static_cast<uint8_t>(dev.n_bits), true, false});
-      dev.planes = dev.scan;
-      dev.row_of = nullptr;
-      dev.code_map = nullptr;
-      dev.escapes = nullptr;
-      dev.escape_first = nullptr;
-      layout.built = true;
-      return SILO_GPU_OK;
-   };
-   const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
-   if ((!nucleotide && !(dev.n_bits == 5 && dev.n_scan == 22)) || dev.row_words < SCAN_THREADS * 4 || positions == 0 || store->sequence_count == 0 ||
-       g_tune_compact_index.load() < 0) {
-      return keepBuildPlanes();
+   if (dev.build_mode == BUILD_ENCODE) {
+      HIP_TRY(hipDeviceSynchronize());
+      dev.build_mode = BUILD_PLANES;
+      return finishLayout(store, seqstore, *seqstore.work);
+   }
+   if (!reencodes(store, dev)) {
+      return keepBuildPlanes(seqstore);
    }
    // the unfiltered totals decide the codes (and are what a full filter adds later on)
    const size_t n_counters = static_cast<size_t>(positions) * dev.n_scan;
@@ -3014,182 +3361,27 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
       HIP_TRY(hipStreamSynchronize(nullptr));
       seqstore.totals_ready = true;
    }
-   uint8_t* d_code_map = nullptr;
-   uint32_t* d_count = nullptr;  // escapes per (position, symbol), later the cursors of the encoder
-   uint32_t* d_first = nullptr;
-   uint32_t* d_row_of = nullptr;
-   uint32_t* d_row_target = nullptr;
-   uint32_t* d_escape_first = nullptr;
-   uint64_t* d_planes = nullptr;
-   uint64_t* d_escapes = nullptr;
-   const auto discard = [&]() {
-      (void)hipFree(d_row_target);
-      (void)hipFree(d_code_map);
-      (void)hipFree(d_count);
-      (void)hipFree(d_first);
-      (void)hipFree(d_row_of);
-      (void)hipFree(d_escape_first);
-      (void)hipFree(d_planes);
-      (void)hipFree(d_escapes);
-   };
-#define SILO_LAYOUT_TRY(expr)                                                       \
-   do {                                                                             \
-      const hipError_t status_ = (expr);                                            \
-      if (status_ != hipSuccess) {                                                  \
-         discard();                                                                 \
-         HIP_TRY(status_);                                                          \
-      }                                                                             \
-   } while (0)
-   std::vector<uint32_t> totals(n_counters);
-   SILO_LAYOUT_TRY(hipMemcpy(totals.data(), seqstore.d_totals, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost));
-   std::vector<uint8_t> code_map;
-   std::vector<uint32_t> counts;  // escape keys per (position, symbol)
-   // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows (the layouts before one-hot rows, for comparisons)
-   silo_gpu_layout::chooseLayouts(
-      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2,
-      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, code_map, counts
-   );
-   SILO_LAYOUT_TRY(hipMalloc(&d_code_map, code_map.size()));
-   SILO_LAYOUT_TRY(hipMalloc(&d_count, n_counters * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMemcpy(d_code_map, code_map.data(), code_map.size(), hipMemcpyHostToDevice));
-   std::vector<uint32_t> row_of(positions + 1, 0);
-   std::vector<uint32_t> row_target;  // of the one-hot rows
-   std::vector<uint32_t> escape_first(positions + 1, 0);
-   std::vector<uint32_t> escape_first_symbol(n_counters + 1, 0);
-   std::vector<SeqStoreHost::Run> runs;
-   uint64_t total_escapes = 0;
-   uint64_t total_rows = 0;
-   bool any_encoded = false;
-   for (uint32_t p = 0; p < positions; ++p) {
-      const uint8_t* map = code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
-      const uint8_t bits = map[0] & 0x3Fu;
-      const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
-      const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
-      any_encoded = any_encoded || !identity;
-      row_of[p] = static_cast<uint32_t>(total_rows);
-      total_rows += bits;
-      for (uint32_t row = 0; row < bits; ++row) {  // a row without a symbol (no valid symbol at the position at all) is empty: any counter of the position
-         row_target.push_back(one_hot ? p * dev.n_scan + (map[1 + row] != 0xFFu ? map[1 + row] : 0u) : 0xFFFFFFFFu);
-      }
-      escape_first[p] = static_cast<uint32_t>(total_escapes);
-      for (uint32_t symbol = 0; symbol < dev.n_scan; ++symbol) {
-         escape_first_symbol[static_cast<size_t>(p) * dev.n_scan + symbol] = static_cast<uint32_t>(total_escapes);
-         total_escapes += counts[static_cast<size_t>(p) * dev.n_scan + symbol];
-      }
-      const uint8_t run_bits = one_hot ? 0 : bits;
-      if (runs.empty() || runs.back().bits != run_bits || runs.back().identity != identity || runs.back().one_hot != one_hot) {
-         runs.push_back(SeqStoreHost::Run{p, p + 1, run_bits, identity, one_hot});
-      } else {
-         runs.back().end = p + 1;
-      }
+   SeqStoreHost::LayoutWork work;
+   bool fits = false;
+   if (const int rc = planLayout(seqstore, work, false, &fits); rc != SILO_GPU_OK) {
+      return rc;
    }
-   row_of[positions] = static_cast<uint32_t>(total_rows);
-   escape_first[positions] = static_cast<uint32_t>(total_escapes);
-   escape_first_symbol[n_counters] = static_cast<uint32_t>(total_escapes);
-   const size_t plane_bytes = static_cast<size_t>(total_rows) * dev.row_words * sizeof(uint64_t);
-   const size_t escape_bytes = std::max<uint64_t>(total_escapes, 1) * sizeof(uint64_t);
-   size_t free_bytes = 0, total_bytes = 0;
-   SILO_LAYOUT_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
-   // both representations are resident until the re-encoding is done; the sort of the keys needs as much again as the keys
-   if (!any_encoded || total_rows >= (uint64_t{1} << 32) || total_escapes >= (uint64_t{1} << 32) ||
-       free_bytes < plane_bytes + 4 * escape_bytes + (size_t{1} << 30)) {
-      discard();
-      return keepBuildPlanes();
+   if (!fits) {
+      return keepBuildPlanes(seqstore);
    }
-   SILO_LAYOUT_TRY(hipMalloc(&d_planes, plane_bytes));
-   SILO_LAYOUT_TRY(hipMalloc(&d_escapes, escape_bytes));
-   SILO_LAYOUT_TRY(hipMalloc(&d_first, escape_first_symbol.size() * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMalloc(&d_row_of, row_of.size() * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMalloc(&d_escape_first, escape_first.size() * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMemcpy(d_first, escape_first_symbol.data(), escape_first_symbol.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-   SILO_LAYOUT_TRY(hipMemcpy(d_row_of, row_of.data(), row_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-   SILO_LAYOUT_TRY(hipMalloc(&d_row_target, std::max<size_t>(row_target.size(), 1) * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMemcpy(d_row_target, row_target.data(), row_target.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-   SILO_LAYOUT_TRY(hipMemcpy(d_escape_first, escape_first.data(), escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-   SILO_LAYOUT_TRY(hipMemset(d_count, 0, n_counters * sizeof(uint32_t)));
    {
       const dim3 grid((dev.row_words + 255) / 256, positions);
-      if (nucleotide) {
-         k_encode_adaptive<3><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, d_code_map, d_row_of, d_first, d_count, d_planes, d_escapes);
+      if (dev.n_bits == 3) {
+         k_encode_adaptive<3><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, work.d_code_map, work.d_row_of, work.d_first, work.d_cursor, work.d_planes, work.d_escapes);
       } else {
-         k_encode_adaptive<5><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, d_code_map, d_row_of, d_first, d_count, d_planes, d_escapes);
+         k_encode_adaptive<5><<<grid, 256>>>(dev.scan, dev.row_words, dev.n_scan, work.d_code_map, work.d_row_of, work.d_first, work.d_cursor, work.d_planes, work.d_escapes);
       }
       SILO_LAYOUT_TRY(hipGetLastError());
       SILO_LAYOUT_TRY(hipDeviceSynchronize());
    }
-   if (const int rc = silo_gpu_internal_sort_keys(d_escapes, total_escapes); rc != SILO_GPU_OK) {  // ascending: (position, symbol, sequence)
-      discard();
-      return rc;
-   }
-   // the slice-major copy of the keys for the scan's escape pass, and where each position's keys begin in every slice
-   uint64_t* d_escapes_sliced = nullptr;
-   uint32_t* d_slice_first = nullptr;
-   std::vector<uint32_t> slice_first;
-   const uint32_t n_slices = (store->sequence_count + (1u << ESCAPE_SLICE_SHIFT) - 1) >> ESCAPE_SLICE_SHIFT;
-   if (total_escapes > 0 && n_slices <= ESCAPE_MAX_SLICES) {
-      const size_t n_entries = static_cast<size_t>(n_slices) * (positions + 1);
-      const auto discardSliced = [&]() {
-         (void)hipFree(d_escapes_sliced);
-         (void)hipFree(d_slice_first);
-      };
-      hipError_t status = hipMalloc(&d_escapes_sliced, escape_bytes);
-      status = status != hipSuccess ? status : hipMalloc(&d_slice_first, n_entries * sizeof(uint32_t));
-      status = status != hipSuccess ? status : hipMemcpy(d_escapes_sliced, d_escapes, total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
-      if (status != hipSuccess) {
-         discardSliced();
-         SILO_LAYOUT_TRY(status);
-      }
-      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + ESCAPE_SLICE_BITS); rc != SILO_GPU_OK) {
-         discardSliced();
-         discard();
-         return rc;
-      }
-      k_slice_index<<<static_cast<uint32_t>((n_entries + 255) / 256), 256>>>(
-         d_escapes_sliced, static_cast<uint32_t>(total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
-      );
-      slice_first.resize(n_entries);
-      status = hipGetLastError();
-      status = status != hipSuccess ? status : hipMemcpy(slice_first.data(), d_slice_first, n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost);
-      if (status != hipSuccess) {
-         discardSliced();
-         SILO_LAYOUT_TRY(status);
-      }
-   }
-#undef SILO_LAYOUT_TRY
-   (void)hipFree(d_first);
-   (void)hipFree(d_count);
-   // the adaptive planes take over; the build-time planes go
-   const size_t build_bytes = static_cast<size_t>(positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
-   (void)hipFree(dev.scan);
-   dev.scan = nullptr;
-   store->device_bytes -= build_bytes;
-   layout.planes = d_planes;
-   layout.d_row_of = d_row_of;
-   layout.d_row_target = d_row_target;
-   layout.d_code_map = d_code_map;
-   layout.d_escapes = d_escapes;
-   layout.d_escapes_sliced = d_escapes_sliced;
-   layout.d_slice_first = d_slice_first;
-   layout.slice_shift = ESCAPE_SLICE_SHIFT;
-   layout.n_slices = d_escapes_sliced != nullptr ? n_slices : 0;
-   layout.slice_first = std::move(slice_first);
-   layout.d_escape_first = d_escape_first;
-   layout.row_of = std::move(row_of);
-   layout.code_map = std::move(code_map);
-   layout.escape_first = std::move(escape_first);
-   layout.escape_first_symbol = std::move(escape_first_symbol);
-   layout.runs = std::move(runs);
-   layout.device_bytes = plane_bytes + escape_bytes * (d_escapes_sliced != nullptr ? 2 : 1) + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
-                         total_rows * sizeof(uint32_t);
-   store->device_bytes += layout.device_bytes;
-   dev.planes = d_planes;
-   dev.row_of = d_row_of;
-   dev.code_map = d_code_map;
-   dev.escapes = d_escapes;
-   dev.escape_first = d_escape_first;
-   layout.built = true;
-   return SILO_GPU_OK;
+   return finishLayout(store, seqstore, work);
 }
+#undef SILO_LAYOUT_TRY
 
 }  // namespace
 
@@ -4344,8 +4536,8 @@ int silo_gpu_store_import_missing_rows(
    if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {
       return rc;
    }
-   if (seqstore.dev.kind[seqstore.dev.missing_symbol] != PLANE_EXTRA) {
-      return fail(SILO_GPU_ERR_UNSUPPORTED, "silo_gpu_store_import_missing_rows: the missing symbol has no column plane in this store");
+   if (seqstore.dev.kind[seqstore.dev.missing_symbol] != PLANE_EXTRA || seqstore.dev.build_mode != BUILD_PLANES) {
+      return fail(SILO_GPU_ERR_UNSUPPORTED, "silo_gpu_store_import_missing_rows: the missing symbol has no column plane in this store (or the store is being built in two passes)");
    }
    seqstore.totals_ready = false;
    // the row-wise bitmaps hold POSITIONS (a few runs per row): their directory and values are read on the host
@@ -4419,6 +4611,9 @@ int silo_gpu_store_import_position(
    const auto valid_symbol = [&](uint32_t symbol) { return symbol == SILO_GPU_SYMBOL_NONE || (symbol < dev.n_symbols && symbol != dev.missing_symbol); };
    if (position >= dev.positions || !valid_symbol(flipped_symbol) || !valid_symbol(deleted_symbol)) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_import_position: position or flipped / deleted symbol out of range");
+   }
+   if (seqstore.dev.build_mode != BUILD_PLANES) {
+      return fail(SILO_GPU_ERR_UNSUPPORTED, "silo_gpu_store_import_position: the store is being built in two passes");
    }
    if (const int rc = ensureBuildPlanes(store, seqstore); rc != SILO_GPU_OK) {
       return rc;

@@ -773,6 +773,61 @@ def test_filter_eval_batch_matches_numpy_and_single_launches(built, n):
             store.filter_eval_batch(programs + [(b.encode(b.OP_AND, 0, 5, 6), leaves, 2)])
 
 
+@pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (1000, "nuc")])
+def test_two_pass_build_gives_the_same_store(built, n, alphabet):
+    """silo_gpu_store_build_pass: the sequences streamed twice — counted, then written straight into the adaptive planes chosen
+    from the counts, without build-time planes — give the store that finalize re-encodes out of build-time planes: the same
+    layout, the same keys, the same answers.  Batches with unaligned boundaries (shared words), IUPAC codes and missing
+    symbols; a store of short rows keeps its identity planes either way."""
+    rng = np.random.default_rng(n + 23)
+    positions = 61
+    sym = skewed_symbols(rng, n, positions, alphabet)
+    settle_positions(rng, sym, list(range(5, 30)) + list(range(40, 58)), alphabet)
+    sym[:, 33] = rng.integers(0, 16 if alphabet == "nuc" else 25, size=n)  # a position that keeps its identity planes
+    chars = NUC_CHARS if alphabet == "nuc" else AA_CHARS
+    table_size = 16 if alphabet == "nuc" else 25
+    cuts = [0, n // 3 + 17, 2 * n // 3 + 5, n]
+    masks = [rng.random(n) < 0.4, np.ones(n, bool), rng.random(n) < 0.001]
+    stores = []
+    try:
+        for two_pass in (False, True):
+            store = make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy())])
+            stores.append(store)
+            if two_pass:
+                store.build_pass(0, 1)
+                assert store.build_mode(0) == 1
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    store.append_sequences(0, a, chars[sym[a:b]])
+                store.build_pass(0, 2)
+                assert store.build_mode(0) == (2 if n >= 65536 else 0)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                store.append_sequences(0, a, chars[sym[a:b]])
+            store.finalize()
+            assert store.build_mode(0) == 0
+        one, two = stores
+        assert two.scan_rows(0, 0, positions) == one.scan_rows(0, 0, positions) and two.scan_escapes(0) == one.scan_escapes(0)
+        assert [two.scan_rows(0, p, p + 1) for p in range(positions)] == [one.scan_rows(0, p, p + 1) for p in range(positions)]
+        assert two.device_bytes == one.device_bytes
+        scan_symbols = list(one.scan_symbols[0])
+        for mask in masks:
+            want = dense.mutation_counts(sym, mask, scan_symbols)
+            for store in stores:
+                ptr = store.bitset_alloc()
+                store.bitset_upload(ptr, dense.pack_bits(mask))
+                assert np.array_equal(store.mutations_scan(0, ptr), want)
+        assert np.array_equal(two.mutations_scan(0, None), dense.mutation_counts(sym, masks[1], scan_symbols))  # the cached totals = the first pass's counts
+        for position in (0, 7, 33, 50, positions - 1):
+            for symbol in range(table_size):
+                want_plane = dense.pack_bits(sym[:, position] == symbol)
+                got = two.plane_download(0, position, symbol)
+                assert np.array_equal(got[: len(want_plane)], want_plane) and not got[len(want_plane):].any(), (position, symbol)
+        picked = rng.choice(n, size=50, replace=False).astype(np.uint32)
+        assert np.array_equal(two.reconstruct_sequences(0, picked), chars[sym[picked]])
+    finally:
+        for store in stores:
+            store.close()
+
+
 @pytest.mark.parametrize("n,alphabet,positions,run_share", [(70000, "nuc", 397, 0.5), (6000, "aa", 4, 0.0005), (150001, "nuc", 512, 0.5)])
 def test_missing_symbol_becomes_runs(built, n, alphabet, positions, run_share):
     """finalize() turns the plane of the missing symbol (N / X) into the sorted list of its runs and releases the plane: runs
