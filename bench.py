@@ -51,7 +51,7 @@ def load_reference_genomes(with_genes=False):
 
 
 def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False, nuc_positions=None,
-                 lineage_order=False):
+                 lineage_order=False, two_pass=False):
     from silo_amd import alphabet, synth
     from silo_amd.engine import Engine
 
@@ -69,6 +69,8 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
         lineage = lineage[np.argsort(rank_of[lineage], kind="stable")]
     model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
     engine = Engine(genomes, device=device)
+    if two_pass:  # the generator runs twice per store: counted, then written straight into the adaptive planes (no build-time planes)
+        engine.set_option("two_pass_build", 1)
     if getattr(build_engine, "comm", None) is not None and (world > 1 or sharded):
         engine.set_comm(build_engine.comm, True)  # native RCCL all-reduce / broadcast on the engine's streams
     elif world > 1 or sharded:
@@ -896,6 +898,24 @@ def main():
                 "mutation_rows": len(rows_sorted),
             }
             engine_sorted.close()
+            # how far one GPU goes: 25 M sequences, the genome built in two passes (counted, then written straight into the
+            # adaptive planes: the 3 build-time planes per position would not fit beside the finished store)
+            big_n = 25_000_000
+            t_build = time.perf_counter()
+            engine_big, _, _, _, _ = build_engine(big_n, 0, 1, None, local_rank, two_pass=True)
+            build_seconds = time.perf_counter() - t_build
+            elapsed_big, rows_big = run_steps(engine_big, query, max(5, args.steps // 2), args.warmup, sync)
+            result["also_25m_sequences"] = {
+                "workload": f"the headline query on {big_n} sequences x {positions} nt on the same single GPU, the store built in two passes of the generator "
+                            "(silo_gpu_store_build_pass: no build-time planes)",
+                "value": big_n * positions / (elapsed_big / max(5, args.steps // 2)),
+                "unit": "positions*sequences/s",
+                "ms_per_step": elapsed_big / max(5, args.steps // 2) * 1e3,
+                "device_GB": engine_big.partition_store(0).device_bytes / 1e9,
+                "build_seconds": build_seconds,
+                "mutation_rows": len(rows_big),
+            }
+            engine_big.close()
             engine4, _, tree4, _, _ = build_engine(6_250_000, 0, 1, None, local_rank, with_genes=True)
             reference_text = load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
             result["also_config4_shard"] = config4_workload(engine4, tree4, reference_text, positions, aa_positions, 6_250_000, sync)

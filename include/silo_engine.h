@@ -50,6 +50,10 @@ int silo_engine_append_sequences(
 int silo_engine_generate_synthetic(
    silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, const silo_gpu_synth_desc* synth
 );
+/* Two-pass build of one sequence store (silo_gpu_store_build_pass): pass 1 before its first sequences — the appends that follow
+ * are only counted —, pass 2 before the same appends are repeated — they are written straight into the store's adaptive planes.
+ * With option "two_pass_build" = 1 silo_engine_generate_synthetic does both passes by itself. */
+int silo_engine_build_pass(silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, int pass);
 
 /* A pango lineage metadata column: one raw (possibly aliased) value per row, NULL or "" = null. */
 int silo_engine_set_lineage_column(silo_engine* engine, int partition, const char* column, const char* const* values, uint32_t n_rows);

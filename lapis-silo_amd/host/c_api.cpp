@@ -150,6 +150,19 @@ int silo_engine_append_sequences(
    return status == 0 ? 0 : fail(status, silo_gpu_last_error());
 }
 
+int silo_engine_build_pass(silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, int pass) {
+   silo::DatabasePartition* part = partitionOf(engine, partition);
+   if (part == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such partition");
+   }
+   const int id = seqstoreId(*part, sequence_name, is_amino_acid);
+   if (id < 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
+   }
+   const int status = silo_gpu_store_build_pass(part->store, static_cast<uint32_t>(id), pass);
+   return status == 0 ? 0 : fail(status, silo_gpu_last_error());
+}
+
 int silo_engine_generate_synthetic(silo_engine* engine, int partition, const char* sequence_name, int is_amino_acid, const silo_gpu_synth_desc* synth) {
    silo::DatabasePartition* part = partitionOf(engine, partition);
    if (part == nullptr) {
@@ -159,7 +172,13 @@ int silo_engine_generate_synthetic(silo_engine* engine, int partition, const cha
    if (id < 0) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
    }
-   int status = silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
+   int status = 0;
+   if (engine->database.two_pass_build) {  // count, choose the layout of every position, then generate straight into it
+      status = silo_gpu_store_build_pass(part->store, static_cast<uint32_t>(id), 1);
+      status = status != 0 ? status : silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
+      status = status != 0 ? status : silo_gpu_store_build_pass(part->store, static_cast<uint32_t>(id), 2);
+   }
+   status = status != 0 ? status : silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
    if (status == 0) {
       // the generator fills the whole sequence store in this one call: re-encode it now, so that the build-time planes of
       // the stores of a partition (112 GB for the nucleotide genome at 10 M sequences) are never resident together
@@ -347,6 +366,10 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
    }
    if (std::strcmp(name, "compat_remove_quirk") == 0 && (value == 0 || value == 1)) {
       engine->database.compat_remove_quirk = value == 1;  // SILO_COMPAT_REMOVE_QUIRK, see filter_expressions.cpp
+      return 0;
+   }
+   if (std::strcmp(name, "two_pass_build") == 0 && (value == 0 || value == 1)) {
+      engine->database.two_pass_build = value == 1;
       return 0;
    }
    if (std::strcmp(name, "compact_scan_index") == 0 && (value == 0 || value == 1)) {

@@ -317,6 +317,9 @@ class Database {
    /// Mutations selects its result rows on the device into a list of this many cells; a query that selects more
    /// (minProportion 0 over a large filter) fetches the whole count table instead. 0 = always fetch the table.
    uint32_t mutation_row_capacity = 4096;
+   /// Option "two_pass_build": generated (and directory-loaded) sequence stores are streamed twice — counted, then written
+   /// straight into their adaptive planes — instead of being built in 3 / 5 identity planes per position and re-encoded.
+   bool two_pass_build = false;
    /// SILO_COMPAT_REMOVE_QUIRK: HasNucleotideMutation / HasAminoAcidMutation keep the reference's
    /// std::remove-without-erase behaviour (filter_expressions.cpp, dropSymbol).  Default on: parity is judged against
    /// the reference as it is.

@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
-    "silo_engine_generate_synthetic", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
+    "silo_engine_generate_synthetic", "silo_engine_build_pass", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
     "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_comm", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_evaluate_filter", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
@@ -43,6 +43,7 @@ def load_library():
     lib.silo_engine_add_partition.argtypes = [vp, ctypes.c_uint32]
     lib.silo_engine_append_sequences.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
     lib.silo_engine_generate_synthetic.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(binding.SynthDesc)]
+    lib.silo_engine_build_pass.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.silo_engine_set_lineage_column.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32]
     lib.silo_engine_set_lineage_column_ids.argtypes = [
         vp, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, vp, ctypes.c_uint32]
@@ -185,6 +186,11 @@ class Engine:
             arrays[2].ctypes.data_as(binding.c_u32p), arrays[3].ctypes.data_as(binding.c_u32p), arrays[4].ctypes.data_as(binding.c_u32p),
             arrays[5].ctypes.data_as(binding.c_u8p), model.private_threshold, model.ambiguous_threshold, begin, model.positions)
         _check(self.lib.silo_engine_generate_synthetic(self.handle, partition, name.encode(), int(is_aa), ctypes.byref(desc)))
+
+    def build_pass(self, partition, name, is_aa, which):
+        """Two-pass build of a sequence store: 1 = the appends that follow are only counted, 2 = repeated, they are written
+        straight into the adaptive planes (silo_engine_build_pass)."""
+        _check(self.lib.silo_engine_build_pass(self.handle, partition, name.encode(), int(is_aa), which))
 
     def set_lineage_column(self, partition, column, values):
         array = (ctypes.c_char_p * len(values))(*[None if v is None else v.encode() for v in values])

@@ -161,3 +161,28 @@ def test_compact_scan_index_option(built):
         lib.silo_gpu_tune(4, 0)
     assert answers[0] == answers[1] and answers[0][0] == 200
     assert sizes[0] < 0.8 * sizes[1]
+
+
+def test_two_pass_build_option_gives_the_same_database(built):
+    """silo_engine_set_option("two_pass_build", 1): the generator runs twice per sequence store — counted, then written
+    straight into the adaptive planes — and the database answers like the one built in identity planes and re-encoded:
+    same bytes on the device, same responses (Mutations, AminoAcidMutations, filters on stored, escaped and missing symbols)."""
+    import bench
+
+    queries = [
+        bench.make_query(),
+        json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.02}, "filterExpression": {"type": "True"}}),
+        json.dumps({"action": {"type": "Aggregated"}, "filterExpression": {"type": "And", "children": [
+            {"type": "Maybe", "child": {"type": "NucleotideEquals", "position": 241, "symbol": "T"}},
+            {"type": "Not", "child": {"type": "NucleotideEquals", "position": 5000, "symbol": "N"}},
+            {"type": "N-Of", "numberOfMatchers": 1, "matchExactly": False, "children": [
+                {"type": "HasNucleotideMutation", "position": 12000}, {"type": "AminoAcidEquals", "sequenceName": "S", "position": 614, "symbol": "G"}]}]}}),
+        json.dumps({"action": {"type": "FastaAligned", "sequenceName": "main", "limit": 3, "orderByFields": ["pango_lineage"]}, "filterExpression": {"type": "True"}}),
+    ]
+    answers, sizes = [], []
+    for two_pass in (False, True):
+        with bench.build_engine(150_000, 0, 1, None, 0, with_genes=True, two_pass=two_pass)[0] as engine:
+            sizes.append(engine.partition_store(0).device_bytes)
+            answers.append([engine.execute_text(q.encode() if isinstance(q, str) else q) for q in queries])
+    assert answers[0] == answers[1] and all(status == 200 for status, _ in answers[0][:3])
+    assert sizes[0] == sizes[1]
