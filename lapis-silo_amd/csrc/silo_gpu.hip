@@ -141,6 +141,12 @@ struct SeqStoreDev {
    const uint32_t* enc_first;   // [P * n_scan + 1] first escape key of a (position, symbol)
    uint32_t* enc_cursor;        // [P * n_scan] keys written so far
    uint64_t* enc_escapes;
+   // ... and the missing symbol goes straight to its runs (no plane): counted in the first pass, written in the second
+   uint32_t runs_at_build;
+   unsigned long long* enc_run_count;  // the count, then the cursor
+   uint64_t* enc_run_keys;
+   uint32_t* enc_run_ends;
+   unsigned long long enc_run_capacity;
    // ADAPTIVE code planes, what every consumer reads after finalize.  Position p owns plane rows
    // [row_of[p], row_of[p + 1]) of `planes`: B = 2 or 3 planes carrying the codes 1..2^B-1 of the position's most frequent
    // valid symbols (code_map), every other valid symbol of a row listed in `escapes`; or the n_bits identity planes.
@@ -247,6 +253,7 @@ struct SeqStoreHost {
    // a two-pass build between its passes / during the second (silo_gpu_store_build_pass): the layout in the making
    struct LayoutWork;
    std::shared_ptr<LayoutWork> work;
+   unsigned long long* d_run_count = nullptr;  // runs of the missing symbol counted / written while the store is built in two passes
    // The adaptive code planes of the finalized store (see SeqStoreDev and buildLayout).
    struct Run {  // consecutive positions of one layout: a scan launch takes runs of ONE layout
       uint32_t begin;
@@ -1415,7 +1422,7 @@ __device__ __forceinline__ void emitWord(
          continue;
       }
       if (kind == PLANE_EXTRA) {
-         if (lane == 0) {
+         if (lane == 0 && store.runs_at_build == 0) {  // (two-pass build: the missing symbol goes to its runs, the kernels track them)
             uint64_t* dst = planePtr(store, position, s) + word;
             if (whole_word) {
                *dst = mask;
@@ -1430,6 +1437,57 @@ __device__ __forceinline__ void emitWord(
                            (static_cast<uint64_t>(word) * 64u + lane);
          }
       }
+   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Runs of the missing symbol while a store is built in two passes (SeqStoreDev::runs_at_build): a lane of the build kernels
+// walks ONE sequence along the positions of its wave's stretch, so a run is seen from its first to its last position; the
+// counting pass counts the runs, the encoding pass writes them (sequence << 32 | start, end) through the same counter.  A
+// run that crosses the end of a stretch is listed in pieces — in both passes alike.
+// ------------------------------------------------------------------------------------------------
+struct MissingRunTracker {
+   bool in_run = false;
+   uint32_t start = 0;
+};
+
+/// Called by every lane of the wave: a run of `sequence` ends at `end` (exclusive) in the lanes where `ends_here`.
+__device__ __forceinline__ void emitMissingRun(const SeqStoreDev& store, bool ends_here, uint32_t start, uint32_t end, uint64_t sequence) {
+   const uint64_t ending = __ballot(ends_here);
+   if (ending == 0) {
+      return;
+   }
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(ending));
+   unsigned long long first = 0;
+   if (lane == leader) {
+      first = atomicAdd(store.enc_run_count, static_cast<unsigned long long>(__popcll(ending)));
+   }
+   if (store.build_mode == BUILD_ENCODE) {
+      first = __shfl(first, leader);
+      const unsigned long long slot = first + static_cast<unsigned long long>(__popcll(ending & ((1ull << lane) - 1ull)));
+      if (ends_here && slot < store.enc_run_capacity) {
+         store.enc_run_keys[slot] = (sequence << 32) | start;
+         store.enc_run_ends[slot] = end;
+      }
+   }
+}
+
+__device__ __forceinline__ void trackMissingRun(const SeqStoreDev& store, MissingRunTracker& tracker, uint32_t position, bool missing, uint64_t sequence) {
+   if (store.runs_at_build == 0) {
+      return;
+   }
+   emitMissingRun(store, tracker.in_run && !missing, tracker.start, position, sequence);
+   if (missing && !tracker.in_run) {
+      tracker.start = position;
+   }
+   tracker.in_run = missing;
+}
+
+__device__ __forceinline__ void flushMissingRun(const SeqStoreDev& store, MissingRunTracker& tracker, uint32_t end, uint64_t sequence) {
+   if (store.runs_at_build != 0) {
+      emitMissingRun(store, tracker.in_run, tracker.start, end, sequence);
+      tracker.in_run = false;
    }
 }
 
@@ -1477,6 +1535,7 @@ __global__ __launch_bounds__(256) void k_transpose_sequences(
    const uint32_t pos_begin = blockIdx.y * TRANSPOSE_POSITIONS_PER_WAVE;
    const uint32_t pos_end = min(store.positions, pos_begin + TRANSPOSE_POSITIONS_PER_WAVE);
    const uint8_t* row = chars + static_cast<size_t>(local) * pitch;
+   MissingRunTracker missing_run;
    for (uint32_t p4 = pos_begin; p4 < pos_end; p4 += 4) {
       uint32_t packed = 0;
       if (active && !null_genome) {  // rows are contiguous (pitch = positions, any alignment): byte loads, served from L1
@@ -1497,9 +1556,11 @@ __global__ __launch_bounds__(256) void k_transpose_sequences(
                atomicOr(error_flag, 1u);
             }
          }
+         trackMissingRun(store, missing_run, p4 + k, symbol == store.missing_symbol, sequence);
          emitWord(store, p4 + k, word, symbol, whole_word, sparse, sparse_count, sparse_capacity);
       }
    }
+   flushMissingRun(store, missing_run, pos_end, sequence);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1554,6 +1615,7 @@ __global__ __launch_bounds__(256) void k_generate_synthetic(
 
    const uint32_t pos_begin = blockIdx.y * SYNTH_POSITIONS_PER_WAVE;
    const uint32_t pos_end = min(store.positions, pos_begin + SYNTH_POSITIONS_PER_WAVE);
+   MissingRunTracker missing_run;
    for (uint32_t local = pos_begin; local < pos_end; ++local) {
       const uint32_t p = args.position_offset + local;  // global genome position
       uint32_t symbol;
@@ -1575,8 +1637,10 @@ __global__ __launch_bounds__(256) void k_generate_synthetic(
       if (!active) {
          symbol = SILO_GPU_SYMBOL_NONE;
       }
+      trackMissingRun(store, missing_run, local, symbol == store.missing_symbol, sequence);
       emitWord(store, local, word, symbol, /*whole_word=*/true, sparse, sparse_count, sparse_capacity);
    }
+   flushMissingRun(store, missing_run, pos_end, sequence);
 }
 
 __global__ __launch_bounds__(256) void k_bitset_from_lineages(
@@ -1921,7 +1985,7 @@ int ensureBuildPlanes(silo_gpu_store* store, SeqStoreHost& seqstore) {
    }
    // the encoding pass of a two-pass build writes the valid symbols straight into the adaptive planes: only the extra planes are built
    const size_t scan_bytes = dev.build_mode == BUILD_ENCODE ? 0 : static_cast<size_t>(dev.positions) * dev.n_bits * dev.row_words * sizeof(uint64_t);
-   const size_t extra_bytes = static_cast<size_t>(dev.positions) * dev.n_extra * dev.row_words * sizeof(uint64_t);
+   const size_t extra_bytes = dev.runs_at_build != 0 ? 0 : static_cast<size_t>(dev.positions) * dev.n_extra * dev.row_words * sizeof(uint64_t);
    if (scan_bytes > 0) {
       HIP_TRY(hipMalloc(&dev.scan, scan_bytes));
       HIP_TRY(hipMemset(dev.scan, 0, scan_bytes));
@@ -2100,6 +2164,7 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       if (seqstore.work) {  // a two-pass build that was never finalized
          seqstore.work->discard();
       }
+      (void)hipFree(seqstore.d_run_count);
       (void)hipFree(seqstore.layout.planes);
       (void)hipFree(seqstore.layout.d_row_of);
       (void)hipFree(seqstore.layout.d_row_target);
@@ -2379,6 +2444,23 @@ namespace {
 /// of the plane — always, for data whose missing cells come in runs — and the plane is released.
 int compactMissingPlane(silo_gpu_store* store, SeqStoreHost& seqstore) {
    SeqStoreDev& dev = seqstore.dev;
+   if (dev.runs_at_build != 0) {  // a two-pass build wrote the runs while the rows streamed in: they only have to be put in order
+      dev.runs_at_build = 0;
+      unsigned long long written = 0;
+      HIP_TRY(hipMemcpy(&written, seqstore.d_run_count, sizeof(written), hipMemcpyDeviceToHost));
+      if (written != dev.enc_run_capacity) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: the second pass did not bring the rows the first pass counted (runs of the missing symbol differ)");
+      }
+      if (const int rc = silo_gpu_internal_sort_pairs(seqstore.d_missing_run_keys, seqstore.d_missing_run_ends, written); rc != SILO_GPU_OK) {
+         return rc;
+      }
+      store->device_bytes += std::max<size_t>(written, 1) * (sizeof(uint64_t) + sizeof(uint32_t));
+      dev.missing_run_keys = seqstore.d_missing_run_keys;
+      dev.missing_run_ends = seqstore.d_missing_run_ends;
+      dev.n_missing_runs = static_cast<uint32_t>(written);
+      dev.kind[dev.missing_symbol] = PLANE_RUNS;
+      return SILO_GPU_OK;
+   }
    if (dev.n_extra != 1 || dev.extra == nullptr || dev.kind[dev.missing_symbol] != PLANE_EXTRA || dev.positions == 0 || g_tune_missing_runs.load() < 0) {
       return SILO_GPU_OK;
    }
@@ -2493,6 +2575,16 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
       seqstore.totals_ready = false;
       dev.enc_counts = seqstore.d_totals;
       dev.build_mode = BUILD_COUNT;
+      // the missing symbol, where it is the store's only extra plane, is counted (and then written) as runs right away
+      dev.runs_at_build = dev.n_extra == 1 && dev.kind[dev.missing_symbol] == PLANE_EXTRA && dev.index[dev.missing_symbol] == 0 && g_tune_missing_runs.load() >= 0 ? 1 : 0;
+      if (dev.runs_at_build != 0) {
+         if (seqstore.d_run_count == nullptr) {
+            HIP_TRY(hipMalloc(&seqstore.d_run_count, sizeof(unsigned long long)));
+         }
+         HIP_TRY(hipMemset(seqstore.d_run_count, 0, sizeof(unsigned long long)));
+         HIP_TRY(hipStreamSynchronize(nullptr));
+         dev.enc_run_count = seqstore.d_run_count;
+      }
       return SILO_GPU_OK;
    }
    if (dev.build_mode != BUILD_COUNT) {
@@ -2502,6 +2594,8 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
    dev.build_mode = BUILD_PLANES;
    dev.enc_counts = nullptr;
    seqstore.totals_ready = true;
+   const bool runs_counted = dev.runs_at_build != 0;
+   dev.runs_at_build = 0;
    if (!reencodes(store, dev)) {
       seqstore.totals_ready = false;
       return SILO_GPU_OK;  // a store that keeps its identity planes: the second pass builds them the ordinary way
@@ -2514,6 +2608,25 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
    if (!fits) {
       seqstore.totals_ready = false;
       return SILO_GPU_OK;
+   }
+   if (runs_counted) {  // the runs of the missing symbol: exactly as many slots as the first pass counted
+      unsigned long long n_runs = 0;
+      HIP_TRY(hipMemcpy(&n_runs, seqstore.d_run_count, sizeof(n_runs), hipMemcpyDeviceToHost));
+      if (n_runs < (1ull << 32)) {
+         const size_t slots = std::max<size_t>(n_runs, 1);
+         hipError_t status = hipMalloc(&seqstore.d_missing_run_keys, slots * sizeof(uint64_t));
+         status = status != hipSuccess ? status : hipMalloc(&seqstore.d_missing_run_ends, slots * sizeof(uint32_t));
+         status = status != hipSuccess ? status : hipMemset(seqstore.d_run_count, 0, sizeof(unsigned long long));
+         status = status != hipSuccess ? status : hipStreamSynchronize(nullptr);
+         if (status != hipSuccess) {
+            work->discard();
+            HIP_TRY(status);
+         }
+         dev.enc_run_keys = seqstore.d_missing_run_keys;
+         dev.enc_run_ends = seqstore.d_missing_run_ends;
+         dev.enc_run_capacity = n_runs;
+         dev.runs_at_build = 1;
+      }
    }
    dev.enc_code_map = work->d_code_map;
    dev.enc_row_of = work->d_row_of;
