@@ -495,6 +495,14 @@ class StoreWriter {
       }
    }
 
+   /// Two-pass build (silo_gpu_store_build_pass): 1 before the rows are fed the first time (they are only counted), 2 before
+   /// they are fed again (they are written straight into the adaptive planes); the row cursor starts over.
+   void beginPass(int pass) {
+      flush();
+      checkGpu(silo_gpu_store_build_pass(store, seqstore_id, pass), "silo_gpu_store_build_pass");
+      next_row = 0;
+   }
+
    void flush() {
       if (is_null.empty()) {
          return;
@@ -850,6 +858,9 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             metadata_writer.rowDone();
          }
       }
+      // "twoPassBuild: true" in preprocessing_config.yaml (no reference analogue): every sequence store is fed twice — counted,
+      // then written straight into its adaptive planes — for inputs whose build-time planes would not fit beside the finished store
+      const bool two_pass = setting("twoPassBuild", "false") == "true";
       const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const std::string& prefix) {
          for (auto& [name, writer] : writers) {
             const auto path = findWithCompression(root / (prefix + name + ".fasta"));
@@ -857,11 +868,18 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
                throw PreprocessingException("no sequence file " + prefix + name + ".fasta[.zst|.xz] in " + directory);
             }
             const auto records = readFasta(*path);
-            for (const std::string& key : keys) {
-               const auto found = records.find(key);
-               writer.add(found == records.end() ? nullptr : &found->second, summary);
+            DatasetSummary counted_before;  // the first of two passes must not count the null sequences twice
+            for (int pass = two_pass ? 1 : 2; pass <= 2; ++pass) {
+               if (two_pass) {
+                  writer.beginPass(pass);
+               }
+               DatasetSummary& target = pass == 2 ? summary : counted_before;
+               for (const std::string& key : keys) {
+                  const auto found = records.find(key);
+                  writer.add(found == records.end() ? nullptr : &found->second, target);
+               }
+               writer.flush();
             }
-            writer.flush();
          }
       };
       feed(nuc_writers, setting("nucleotideSequencePrefix", "nuc_"));

@@ -100,6 +100,24 @@ def test_tsv_and_fasta_directory(built):
 
 
 @pytest.mark.gpu
+def test_tsv_and_fasta_directory_in_two_passes(built, tmp_path):
+    """twoPassBuild: true in preprocessing_config.yaml: every sequence store of the directory is fed twice (counted, then
+    written by silo_gpu_store_build_pass's second pass) — the same summary, the same goldens."""
+    from silo_amd.engine import Engine
+
+    for name in os.listdir(EXAMPLE):
+        source = os.path.join(EXAMPLE, name)
+        if name == "preprocessing_config.yaml":
+            with open(source) as handle, open(os.path.join(str(tmp_path), name), "w") as out:
+                out.write(handle.read().rstrip("\n") + "\ntwoPassBuild: true\n")
+        else:
+            os.symlink(source, os.path.join(str(tmp_path), name))
+    with Engine.from_directory(str(tmp_path)) as engine:
+        assert engine.summary == {"sequenceCount": 100, "nucleotideStores": 2, "aminoAcidStores": 12, "lineageColumns": 1, "nullSequences": 0}
+        run_goldens(engine)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("compression", ["zst", "xz", "none"])
 def test_ndjson_directory(built, tmp_path, compression):
     from silo_amd.engine import Engine
