@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(256) void k_scan_escapes(
 /// (16 KiB for 2^17 rows) and streams the slice's keys of the scanned positions against it: a lookup is an LDS read.
 constexpr uint32_t ESCAPE_SLICE_SHIFT = 17;                    // 2^17 rows = 2048 filter words = 16 KiB of LDS per filter
 constexpr uint32_t ESCAPE_SLICE_WORDS32 = (1u << ESCAPE_SLICE_SHIFT) / 32u;
-constexpr uint32_t ESCAPE_SLICE_BITS = 8;                      // sequence bits that number the slices
-constexpr uint32_t ESCAPE_MAX_SLICES = 1u << ESCAPE_SLICE_BITS;  // 33.5 M rows
+constexpr uint32_t ESCAPE_SLICE_BITS = 9;                      // sequence bits that number the slices
+constexpr uint32_t ESCAPE_MAX_SLICES = 1u << ESCAPE_SLICE_BITS;  // 67 M rows
 constexpr uint32_t ESCAPE_SLICE_THREADS = 1024;
 constexpr uint32_t ESCAPE_KEYS_IN_FLIGHT = 16;                 // per thread: the key loads of a chunk are all issued before the first is used
 constexpr uint32_t ESCAPE_CHUNK_KEYS = ESCAPE_SLICE_THREADS * ESCAPE_KEYS_IN_FLIGHT;

@@ -357,7 +357,7 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             assert np.array_equal(store.mutations_scan(0, None), want[2])
             for got, table in zip(store.mutations_scan_batch(0, ptrs, 0, positions), want):
                 assert np.array_equal(got, table), knob
-            # the escape pass on the caller's stream (2) and over the position-major keys (3: what stores of more than 256 slices use)
+            # the escape pass on the caller's stream (2) and over the position-major keys (3: what stores of more than 512 slices use)
             for mode in (2, 3):
                 store.tune(5, mode)
                 try:
