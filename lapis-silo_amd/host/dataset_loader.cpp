@@ -685,13 +685,16 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
       aa_writers.emplace_back(name, StoreWriter(partition.store, store.seqstore_id, store.reference_sequence.size(), name));
    }
 
+   // "twoPassBuild: true" in preprocessing_config.yaml (no reference analogue): every sequence store is fed twice — counted,
+   // then written straight into its adaptive planes — for inputs whose build-time planes would not fit beside the finished store
+   const bool two_pass = setting("twoPassBuild", "false") == "true";
    if (from_ndjson) {  // preprocessor.cpp:87-131: one JSON object per line
       LineReader reader(input_path);
       std::string line;
       bool first_record = true;
       // One JSON object per record; normally one per line, but the reference's reader (DuckDB read_json) also takes objects
       // spread over several lines (testBaseData/ndjsonFiles/oneline_*.json.zst): lines are joined until the braces balance.
-      const auto next_record = [&reader](std::string& record_text) {
+      const auto next_record = [](LineReader& reader, std::string& record_text) {
          record_text.clear();
          std::string part;
          int depth = 0;
@@ -730,7 +733,40 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          }
          return !record_text.empty();
       };
-      while (next_record(line)) {
+      // the aligned sequences of one record, to the writers of every sequence store
+      const auto feed_sequences = [&](const json::Value& record, DatasetSummary& target) {
+         static const json::Value missing_section;
+         const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const char* section) {
+            const json::Value& sequences = record.contains(section) ? record[section] : missing_section;
+            for (auto& [name, writer] : writers) {
+               if (sequences.contains(name) && sequences[name].is_string()) {
+                  writer.add(&sequences[name].as_string(), target);
+               } else {
+                  writer.add(nullptr, target);  // null genome: missing at every position (sequence_store.cpp:166-169)
+               }
+            }
+         };
+         feed(nuc_writers, "alignedNucleotideSequences");
+         feed(aa_writers, "alignedAminoAcidSequences");
+      };
+      if (two_pass) {  // the file is read twice: the first time the sequences are only counted
+         const auto begin_pass = [&](int pass) {
+            for (auto& [name, writer] : nuc_writers) {
+               writer.beginPass(pass);
+            }
+            for (auto& [name, writer] : aa_writers) {
+               writer.beginPass(pass);
+            }
+         };
+         begin_pass(1);
+         LineReader counting_reader(input_path);
+         DatasetSummary counted_before;
+         while (next_record(counting_reader, line)) {
+            feed_sequences(json::parse(line), counted_before);
+         }
+         begin_pass(2);
+      }
+      while (next_record(reader, line)) {
          const json::Value record = json::parse(line);
          if (first_record) {
             // sequence_info.cpp:91-157 (SequenceInfo::validate): the sequence names of the FIRST record and of the
@@ -799,19 +835,7 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             }
          }
          metadata_writer.rowDone();
-         const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const char* section) {
-            static const json::Value missing_section;
-            const json::Value& sequences = record.contains(section) ? record[section] : missing_section;
-            for (auto& [name, writer] : writers) {
-               if (sequences.contains(name) && sequences[name].is_string()) {
-                  writer.add(&sequences[name].as_string(), summary);
-               } else {
-                  writer.add(nullptr, summary);  // null genome: missing at every position (sequence_store.cpp:166-169)
-               }
-            }
-         };
-         feed(nuc_writers, "alignedNucleotideSequences");
-         feed(aa_writers, "alignedAminoAcidSequences");
+         feed_sequences(record, summary);
          if (record.contains("unalignedNucleotideSequences") && record["unalignedNucleotideSequences"].is_object()) {
             const json::Value& unaligned = record["unalignedNucleotideSequences"];
             for (const auto& [name, store] : partition.nuc_sequences) {
@@ -858,9 +882,6 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
             metadata_writer.rowDone();
          }
       }
-      // "twoPassBuild: true" in preprocessing_config.yaml (no reference analogue): every sequence store is fed twice — counted,
-      // then written straight into its adaptive planes — for inputs whose build-time planes would not fit beside the finished store
-      const bool two_pass = setting("twoPassBuild", "false") == "true";
       const auto feed = [&](std::vector<std::pair<std::string, StoreWriter>>& writers, const std::string& prefix) {
          for (auto& [name, writer] : writers) {
             const auto path = findWithCompression(root / (prefix + name + ".fasta"));

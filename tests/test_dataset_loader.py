@@ -129,6 +129,24 @@ def test_ndjson_directory(built, tmp_path, compression):
 
 
 @pytest.mark.gpu
+def test_ndjson_directory_in_two_passes(built, tmp_path):
+    """twoPassBuild: true with ndjson input: the file is read twice — the aligned sequences counted, then every record handled
+    as usual with the sequences written by the second pass (null genomes included) — the same summary, the same goldens."""
+    from silo_amd.engine import Engine
+
+    write_ndjson_dataset(str(tmp_path), "zst")
+    with open(os.path.join(str(tmp_path), "preprocessing_config.yaml"), "a") as config:
+        config.write("twoPassBuild: true\n")
+    with Engine.from_directory(str(tmp_path)) as engine:
+        assert engine.summary["sequenceCount"] == 100
+        two_pass_summary = dict(engine.summary)
+        run_goldens(engine)
+    write_ndjson_dataset(str(tmp_path), "zst")
+    with Engine.from_directory(str(tmp_path)) as engine:
+        assert engine.summary == two_pass_summary  # (null sequences are not counted twice)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scenario", ["fastaFilesWithMissingSequences", "ndjsonWithNullSequences", "ndjsonWithSqlKeywordField", "tsvWithSqlKeywordField"])
 def test_reference_preprocessing_scenarios(built, scenario):
     """src/silo/preprocessing/preprocessor.test.cpp:31-130: the reference's own input directories (missing segments and
