@@ -359,7 +359,8 @@ int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev);
  * filter_dev == NULL means the full filter: like the reference, which then reads stored cardinalities
  * instead of intersecting (mutations.cpp:98-136), the totals of the unfiltered store are computed by one
  * scan on first use, kept on the device and added from then on (invalidated by append / generate).
- * A filter whose set bits fall into few 64-byte sectors (<= row_words / 16 by default, SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR)
+ * A filter whose set bits fall into few 64-byte sectors (<= row_words / 16 by default, SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR; and
+ * fewer than the column tiles the dense scan cannot skip are worth: a clustered filter stays with the dense scan)
  * is served by a gather over just those sectors of the planes (K1s) — decided on the device, same counts, so that the
  * scan gets cheaper with the filter as roaring's and_cardinality does (mutations.cpp:139-164). */
 int silo_gpu_mutations_scan(
@@ -417,7 +418,7 @@ enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SI
        SILO_GPU_TUNE_KEY_COST = 6 /* finalize: > 0 = the cost of an escape key, in plane bytes, in the choice of layouts (experiments) */,
        SILO_GPU_TUNE_MISSING_RUNS = 8 /* finalize: < 0 keeps the plane of the missing symbol (N / X) instead of turning it into runs */,
        SILO_GPU_TUNE_SCAN_TIMING = 7 /* 1: bracket every plane-scan launch with HIP events (silo_gpu_scan_timings) */,
-       SILO_GPU_TUNE_SIDE_STREAM = 5 /* the escape-key pass of a scan: 0 (default) on a side stream of the lowest priority, 1 of default priority, 2 on the caller's stream */,
+       SILO_GPU_TUNE_SIDE_STREAM = 5 /* the escape-key pass of a scan: 0 (default) on a side stream of the lowest priority, 1 of default priority, 2 on the caller's stream, 3 = as 0 over the position-major keys (k_scan_escapes) */,
        SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };
 int silo_gpu_tune(int knob, int value);
 
