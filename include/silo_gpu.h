@@ -75,6 +75,8 @@ void silo_gpu_store_destroy(silo_gpu_store* store);
 uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store);
 uint32_t silo_gpu_store_row_words(const silo_gpu_store* store); /* Wp, in uint64 words */
 uint64_t silo_gpu_store_device_bytes(const silo_gpu_store* store);
+/* Free and total memory of the store's device (hipMemGetInfo), for callers that choose between the one-pass and the two-pass build. */
+int silo_gpu_store_memory_info(const silo_gpu_store* store, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* ---- index build: SequenceStorePartition::fill / interpret (sequence_store.cpp:31-66,100-220) - */
 

@@ -2194,6 +2194,18 @@ uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store) {
 uint32_t silo_gpu_store_row_words(const silo_gpu_store* store) {
    return store != nullptr ? store->row_words : 0;
 }
+int silo_gpu_store_memory_info(const silo_gpu_store* store, uint64_t* free_bytes, uint64_t* total_bytes) {
+   if (store == nullptr || free_bytes == nullptr || total_bytes == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_memory_info: null argument");
+   }
+   HIP_TRY(hipSetDevice(store->device));
+   size_t free_now = 0, total = 0;
+   HIP_TRY(hipMemGetInfo(&free_now, &total));
+   *free_bytes = free_now;
+   *total_bytes = total;
+   return SILO_GPU_OK;
+}
+
 uint64_t silo_gpu_store_device_bytes(const silo_gpu_store* store) {
    return store != nullptr ? store->device_bytes : 0;
 }

@@ -173,7 +173,23 @@ int silo_engine_generate_synthetic(silo_engine* engine, int partition, const cha
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "no such sequence store");
    }
    int status = 0;
-   if (engine->database.two_pass_build) {  // count, choose the layout of every position, then generate straight into it
+   // The one-pass build holds 3 / 5 identity planes per position, the plane of the missing symbol and then the finished store
+   // (about 2 more rows per position with its keys): where that does not fit the device, the store is built in two passes.
+   bool two_pass = engine->database.two_pass_build;
+   uint64_t free_bytes = 0, total_bytes = 0;
+   if (!two_pass && silo_gpu_store_memory_info(part->store, &free_bytes, &total_bytes) == 0) {
+      const uint64_t row_bytes = static_cast<uint64_t>(part->rowWords()) * sizeof(uint64_t);
+      uint64_t positions = 0;  // of this rank's slice of the store
+      if (is_amino_acid != 0) {
+         const auto found = part->aa_sequences.find(sequence_name);
+         positions = found != part->aa_sequences.end() ? found->second.position_end - found->second.position_begin : 0;
+      } else {
+         const auto found = part->nuc_sequences.find(sequence_name);
+         positions = found != part->nuc_sequences.end() ? found->second.position_end - found->second.position_begin : 0;
+      }
+      two_pass = (is_amino_acid != 0 ? 5u + 1u + 2u : 3u + 1u + 2u) * positions * row_bytes + (uint64_t{2} << 30) > free_bytes;
+   }
+   if (two_pass) {  // count, choose the layout of every position, then generate straight into it
       status = silo_gpu_store_build_pass(part->store, static_cast<uint32_t>(id), 1);
       status = status != 0 ? status : silo_gpu_store_generate_synthetic(part->store, static_cast<uint32_t>(id), synth);
       status = status != 0 ? status : silo_gpu_store_build_pass(part->store, static_cast<uint32_t>(id), 2);
