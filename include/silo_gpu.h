@@ -381,6 +381,15 @@ uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqst
 /* Plane rows (of Wp words each) the Mutations scan reads for positions [pos_begin, pos_end) of a sequence store: the
  * physical bytes of a scan are this x 8 Wp, plus the filter and 8 bytes per escape key. */
 uint64_t silo_gpu_store_scan_rows(const silo_gpu_store* store, uint32_t seqstore_id, uint32_t pos_begin, uint32_t pos_end);
+/* Derived symbols.  At almost every position ONE valid symbol has nearly every row; the reference leaves that symbol's bitmap
+ * out and rebuilds its count as |filter| - #missing - the other symbols' counts (position.cpp:102-127, mutations.cpp:74-95).
+ * A finalized store whose missing symbol is kept as runs does the same: such a position stores no row and no key for its most
+ * numerous symbol, and a scan derives that count from the filter's cardinality, the rows of the filter inside a run of the
+ * missing symbol or with an ambiguity code, and the other symbols' counts — the same numbers.  silo_gpu_store_scan_planes is
+ * then 0 (most positions have no row at all); a scan additionally reads the runs (12 bytes each) and the sparse keys (8 bytes
+ * each): silo_gpu_store_scan_runs / _scan_sparse_keys (0 for a store without derived symbols). */
+uint64_t silo_gpu_store_scan_runs(const silo_gpu_store* store, uint32_t seqstore_id);
+uint64_t silo_gpu_store_scan_sparse_keys(const silo_gpu_store* store, uint32_t seqstore_id);
 /* Finalizes ONE sequence store (silo_gpu_store_finalize does all that are left): its build-time planes are re-encoded into
  * the adaptive code planes and released.  A loader that fills the stores of a partition one after the other calls this
  * after each, so that their build-time planes are never resident together (10 M sequences: 112 GB for the nucleotide
@@ -416,9 +425,11 @@ int silo_gpu_memset_async(void* dev_ptr, int value, size_t bytes, void* stream);
 /* Tuning knobs of K1 (0 = default); returns the previous value.  For benchmarks only. */
 enum { SILO_GPU_TUNE_SCAN_ROWS_PER_BLOCK = 0, SILO_GPU_TUNE_SCAN_VARIANT = 1, SILO_GPU_TUNE_EVAL_LEAF_BATCH = 2 /* 8 (default) or 16 leaf loads in flight per lane in K3 */,
        SILO_GPU_TUNE_COMPACT_INDEX = 4 /* finalize: < 0 keeps the build-time identity planes, 0 (default) re-encodes every position into its cheapest
-                                          layout (one-hot rows, 2 / 3 code planes, identity planes), 2 the same without one-hot rows */,
+                                          layout (one-hot rows with the most numerous symbol derived, 2 / 3 code planes, identity planes), 2 the same
+                                          without one-hot rows, 3 with a one-hot row for the most numerous symbol too (nothing derived) */,
        SILO_GPU_TUNE_KEY_COST = 6 /* finalize: > 0 = the cost of an escape key, in plane bytes, in the choice of layouts (experiments) */,
        SILO_GPU_TUNE_MISSING_RUNS = 8 /* finalize: < 0 keeps the plane of the missing symbol (N / X) instead of turning it into runs */,
+       SILO_GPU_TUNE_LAUNCH_COST = 9 /* finalize: what a further kind of plane-scan launch costs in the choice of layouts, in KiB of plane bytes; 0 = default (192 MiB), < 0 = nothing (small test stores that are to mix layouts) */,
        SILO_GPU_TUNE_SCAN_TIMING = 7 /* 1: bracket every plane-scan launch with HIP events (silo_gpu_scan_timings) */,
        SILO_GPU_TUNE_SIDE_STREAM = 5 /* the escape-key pass of a scan: 0 (default) on a side stream of the lowest priority, 1 of default priority, 2 on the caller's stream, 3 = as 0 over the position-major keys (k_scan_escapes) */,
        SILO_GPU_TUNE_SCAN_SPARSE_DIVISOR = 3 /* a filter with a set bit in <= row_words / divisor of its 64-byte sectors takes the gather scan (K1s); 0 = default 16, < 0 = off */ };

@@ -42,6 +42,7 @@ std::atomic<int> g_tune_side_stream{0};     // the escape pass: 0 = side stream 
 std::atomic<int> g_tune_scan_timing{0};     // 1: HIP events around every plane-scan launch (silo_gpu_scan_timings)
 std::atomic<int> g_tune_missing_runs{0};    // < 0: finalize keeps the plane of the missing symbol instead of turning it into runs
 std::atomic<int> g_tune_key_cost{0};        // > 0: what an escape key costs in plane bytes in the layout choice (default KEY_COST_BYTES)
+std::atomic<int> g_tune_launch_cost{0};     // what a further kind of plane-scan launch costs in the layout choice, in KiB of plane bytes: 0 = default (LAUNCH_COST_BYTES), < 0 = nothing
 std::atomic<int> g_tune_sparse_divisor{0};  // 0 = default (row_words / 16 filter sectors with a set bit), < 0 = sparse-filter path off
 
 int fail(int code, const std::string& msg) {
@@ -117,6 +118,12 @@ using silo_gpu_layout::LAYOUT_IDENTITY;
 // valid symbol (code_map[p][1 + j]); every other valid symbol of a row is an escape key.  Rows of one-hot positions need no
 // joint decoding — each is one AND + popcount under the filter — so positions with different k form ONE run for the scan.
 using silo_gpu_layout::LAYOUT_ONE_HOT;
+// ... of which the position's most numerous symbol (code_map[p][IMPLICIT_SLOT]) may be IMPLICIT: no row, no keys — its count
+// under a filter is what is left of the filter's rows once the rows without a valid symbol (runs of the missing symbol,
+// ambiguity codes) and the other valid symbols are taken away (k_finish_scan), its plane the complement of everything else.
+using silo_gpu_layout::LAYOUT_IMPLICIT;
+using silo_gpu_layout::LAYOUT_ROWS_MASK;
+using silo_gpu_layout::IMPLICIT_SLOT;
 using silo_gpu_layout::CODE_MAP_STRIDE;  // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
 
 struct SeqStoreDev {
@@ -183,22 +190,29 @@ struct PositionLayout {
    uint32_t bits;         // plane rows: code planes, or one-hot rows
    bool identity;
    bool one_hot;
+   bool implicit;         // one-hot rows with the symbol map[IMPLICIT_SLOT] derived
    const uint8_t* map;    // code (or 1 + one-hot row) -> scan symbol index (unused when identity)
 };
 __device__ __forceinline__ PositionLayout layoutOf(const SeqStoreDev& s, uint32_t position) {
    if (s.code_map == nullptr) {
-      return {s.planes + static_cast<size_t>(position) * s.n_bits * s.row_words, s.n_bits, true, false, nullptr};
+      return {s.planes + static_cast<size_t>(position) * s.n_bits * s.row_words, s.n_bits, true, false, false, nullptr};
    }
    const uint8_t* map = s.code_map + static_cast<size_t>(position) * CODE_MAP_STRIDE;
-   return {s.planes + static_cast<size_t>(s.row_of[position]) * s.row_words, map[0] & 0x3Fu, (map[0] & LAYOUT_IDENTITY) != 0,
-           (map[0] & LAYOUT_ONE_HOT) != 0, map};
+   return {s.planes + static_cast<size_t>(s.row_of[position]) * s.row_words, static_cast<uint32_t>(map[0] & LAYOUT_ROWS_MASK), (map[0] & LAYOUT_IDENTITY) != 0,
+           (map[0] & LAYOUT_ONE_HOT) != 0, (map[0] & LAYOUT_IMPLICIT) != 0, map};
 }
 
 /// The code (0 = none) that stands for scan symbol index `scan_index` at a position — for a one-hot position 1 + the row
-/// that holds the symbol — or 0xFFFFFFFF when the symbol has neither there (its rows are escape keys).
+/// that holds the symbol — or CODE_ESCAPED when the symbol has neither there (its rows are escape keys), CODE_IMPLICIT when
+/// it is the position's derived symbol (no row, no keys).
+constexpr uint32_t CODE_ESCAPED = 0xFFFFFFFFu;
+constexpr uint32_t CODE_IMPLICIT = 0xFFFFFFFEu;
 __device__ __forceinline__ uint32_t codeOfSymbol(const PositionLayout& layout, uint32_t scan_index) {
    if (layout.identity) {
       return scan_index + 1u;
+   }
+   if (layout.implicit && layout.map[IMPLICIT_SLOT] == scan_index) {
+      return CODE_IMPLICIT;
    }
    const uint32_t n_codes = layout.one_hot ? layout.bits + 1u : (1u << layout.bits);
    for (uint32_t code = 1; code < n_codes; ++code) {
@@ -206,7 +220,7 @@ __device__ __forceinline__ uint32_t codeOfSymbol(const PositionLayout& layout, u
          return code;
       }
    }
-   return 0xFFFFFFFFu;
+   return CODE_ESCAPED;
 }
 
 /// Word `word` of the rows whose code at the position is `code`, decoded from the position's planes (one-hot: read).
@@ -243,6 +257,9 @@ struct SeqStoreHost {
    uint32_t* d_sparse_count = nullptr;  // device counter
    std::vector<uint64_t> sparse_sorted;  // host copy after finalize
    bool finalized = false;
+   // rows that received a sequence (append / generate; an import counts none: its bitmaps may leave rows without a symbol).  Only
+   // a store whose every row has a symbol at every position may derive a symbol as "the rest" (LAYOUT_IMPLICIT).
+   uint64_t rows_filled = 0;
    // counts of the unfiltered store, [positions][n_scan]: what the reference reads from stored
    // cardinalities for a full filter (mutations.cpp:98-136); computed by one scan on first use
    uint32_t* d_totals = nullptr;
@@ -283,6 +300,11 @@ struct SeqStoreHost {
       std::vector<uint32_t> escape_first_symbol;  // [P * n_scan + 1]: first key of a (position, scan symbol)
       std::vector<Run> runs;
       uint64_t device_bytes = 0;
+      // positions whose most numerous symbol is derived (LAYOUT_IMPLICIT): a scan then counts the rows of the filter without a
+      // valid symbol per position — the runs of the missing symbol by slices of 2^17 sequences (run_slice_first), the sparse keys
+      bool has_implicit = false;
+      uint32_t* d_run_slice_first = nullptr;  // [n_run_slices + 1] first run of a slice of sequences
+      uint32_t n_run_slices = 0;
    } layout;
 };
 
@@ -294,6 +316,7 @@ struct SeqStoreHost::LayoutWork {
    std::vector<Run> runs;
    uint64_t total_rows = 0, total_escapes = 0;
    size_t plane_bytes = 0, escape_bytes = 0;
+   bool has_implicit = false;
    uint8_t* d_code_map = nullptr;
    uint32_t* d_cursor = nullptr;
    uint32_t* d_first = nullptr;
@@ -344,7 +367,7 @@ namespace {
 
 int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore);  // the adaptive code planes, defined next to the scan launchers
 bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev);
-int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool* fits);
+int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits);
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -747,16 +770,31 @@ __global__ __launch_bounds__(256) void k_scan_sliced_rowwave(
 // the dense scan, hence the default capacity of row_words / 16 sectors.
 // ------------------------------------------------------------------------------------------------
 
+/// Also the scan's "prepare" step (one launch in front of everything else): the blocks zero `n_zero_words` words of scratch
+/// (the private count tables of a scan with derived symbols) between them, add the filter's cardinality to counter [2], and
+/// block (0, 0) zeroes the counter set the NEXT scan on this scratch block will use (the sets alternate: no fill launches).
 __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
-   const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index
+   const ScanBatchArgs batch, uint32_t row_words, uint32_t capacity, uint32_t* __restrict__ sparse_sectors, uint32_t* __restrict__ sector_index,
+   uint32_t* __restrict__ zero_words, uint32_t n_zero_words, uint32_t* __restrict__ counters_to_reset
 ) {
    __shared__ uint32_t s_wave_first[COMPACT_THREADS / 64];
+   __shared__ uint32_t s_wave_rows[COMPACT_THREADS / 64];
    __shared__ uint32_t s_block_first;
    const uint32_t q = blockIdx.y;
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;  // row_words is a multiple of 32: sectors never straddle the row end
    const uint32_t lane = threadIdx.x & 63u;
    const uint32_t wave = threadIdx.x >> 6;
    const uint64_t value = w < row_words ? batch.filters[q][w] : 0;
+   {  // this block's share of the scratch to zero (16-byte stores; n_zero_words is a multiple of 4)
+      const uint32_t n_chunks = n_zero_words / 4u;
+      const uint32_t n_threads = gridDim.x * gridDim.y * COMPACT_THREADS;
+      for (uint32_t chunk = (blockIdx.y * gridDim.x + blockIdx.x) * COMPACT_THREADS + threadIdx.x; chunk < n_chunks; chunk += n_threads) {
+         reinterpret_cast<uint4*>(zero_words)[chunk] = make_uint4(0, 0, 0, 0);
+      }
+      if (blockIdx.x == 0 && blockIdx.y == 0 && counters_to_reset != nullptr && threadIdx.x < SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE) {
+         counters_to_reset[threadIdx.x] = 0;
+      }
+   }
    const uint64_t ballot = __ballot(value != 0);
    // one bit per sector of this wave (at the sector's first lane): does any of its 8 words have a set bit?
    uint64_t leaders = 0;
@@ -766,20 +804,27 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_filter(
          leaders |= 1ull << (sector * SECTOR_WORDS);
       }
    }
+   const uint32_t wave_rows = waveSumToLane63(static_cast<uint32_t>(__popcll(value)));
    if (lane == 0) {
       s_wave_first[wave] = static_cast<uint32_t>(__popcll(leaders));
+   }
+   if (lane == 63u) {
+      s_wave_rows[wave] = wave_rows;
    }
    __syncthreads();
    if (threadIdx.x == 0) {  // exclusive prefix over the waves, ONE atomic per block
       uint32_t total = 0;
+      uint32_t rows = 0;
       for (uint32_t k = 0; k < COMPACT_THREADS / 64; ++k) {
          const uint32_t count = s_wave_first[k];
          s_wave_first[k] = total;
          total += count;
+         rows += s_wave_rows[k];
       }
       s_block_first = total != 0 ? atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE, total) : 0;
       if (total != 0) {
          atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE + 1, 1u);  // stretches of COMPACT_THREADS words with a set bit
+         atomicAdd(sparse_sectors + q * SPARSE_COUNTER_STRIDE + 2, rows);  // the filter's cardinality
       }
    }
    __syncthreads();
@@ -946,10 +991,19 @@ __global__ __launch_bounds__(256) void k_encode_adaptive(
       }
       return;
    }
-   const uint32_t out_bits = map[0] & 0x3Fu;  // 2 or 3 code planes, or 1..3 one-hot rows
+   const uint32_t out_bits = map[0] & LAYOUT_ROWS_MASK;  // 2 or 3 code planes, or 0..3 one-hot rows
    const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
    uint64_t out_plane[3] = {0, 0, 0};
    uint64_t coded = 0;
+   if ((map[0] & LAYOUT_IMPLICIT) != 0) {  // the rows of the derived symbol are stored nowhere
+      const uint32_t full_code = map[IMPLICIT_SLOT] + 1u;
+      uint64_t match = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < BITS; ++bit) {
+         match &= ((full_code >> bit) & 1u) != 0 ? bits[bit] : ~bits[bit];
+      }
+      coded |= match;
+   }
    for (uint32_t code = 1; code < (one_hot ? out_bits + 1u : (1u << out_bits)); ++code) {
       const uint32_t symbol = map[code];
       if (symbol == 0xFFu) {
@@ -1124,6 +1178,14 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
    }
 }
 
+/// Did the encoding pass of a two-pass build fill every (position, symbol) slice of the key list exactly?
+__global__ void k_check_cursors(const uint32_t* __restrict__ first, const uint32_t* __restrict__ cursor, uint32_t n_counters, uint32_t* __restrict__ mismatches) {
+   const uint32_t counter = blockIdx.x * blockDim.x + threadIdx.x;
+   if (counter < n_counters && cursor[counter] != first[counter + 1] - first[counter]) {
+      atomicAdd(mismatches, 1u);
+   }
+}
+
 /// first[slice][p] = index of the first slice-major key of (slice, position >= p): a binary search per entry.
 __global__ __launch_bounds__(256) void k_slice_index(
    const uint64_t* __restrict__ keys, uint32_t n_keys, uint32_t slice_shift, uint32_t n_slices, uint32_t positions, uint32_t* __restrict__ first
@@ -1146,6 +1208,227 @@ __global__ __launch_bounds__(256) void k_slice_index(
       }
    }
    first[entry] = lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Derived symbols (LAYOUT_IMPLICIT).  At almost every position of an alignment ONE symbol has nearly every row.  The reference
+// leaves that symbol's bitmap out and rebuilds its count as |filter| - #missing - the other symbols' counts
+// (position.cpp:102-127, mutations.cpp:74-95); the dense restatement of the same idea: such a position stores NO row for that
+// symbol, and a scan
+//   1. counts the other valid symbols as ever (their one-hot rows, their escape keys) — into PRIVATE tables in scratch,
+//   2. counts, per position, the rows of the filter that have no valid symbol there: those inside a run of the missing symbol
+//      (k_scan_missing_runs: +1 where a selected row's run starts, -1 where it ends, summed along the positions afterwards)
+//      and those with an ambiguity code (k_count_sparse_keys),
+//   3. k_finish_scan: derived count = |filter| - (2.) - sum of (1.) at the position; private tables -> the caller's.
+// The filter's cardinality comes from the prepare step (k_compact_filter, counter [2]).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t DERIVED_MAX_RANGES = 16;
+constexpr uint32_t DERIVED_THREADS = 1024;
+constexpr uint32_t SPARSE_KEYS_PER_THREAD = 4;
+
+/// A range of a scan with derived symbols.  Its private tables: per filter `stride` words of scratch — counts[n][n_scan], then
+/// diff[n + 1] (selected rows entering / leaving a run of the missing symbol at each position), then ambiguous[n].
+struct DerivedRange {
+   uint32_t* scratch;        // of filter 0
+   uint32_t stride;          // words per filter
+   uint32_t n_positions;
+   uint32_t n_scan;
+   uint32_t pos_begin;
+   const uint8_t* code_map;  // of the store's position 0; nullptr: no position of this store derives a symbol
+   const uint64_t* run_keys;
+   const uint32_t* run_ends;
+   const uint32_t* run_slice_first;  // [n_run_slices + 1]
+   const uint64_t* sparse_keys;      // position << 37 | symbol << 32 | sequence, ascending
+   uint32_t sparse_begin;            // the keys of the range's positions
+   uint32_t sparse_end;
+   uint32_t* caller_counts[SILO_GPU_MAX_SCAN_BATCH];  // at the range's first position
+};
+struct DerivedArgs {
+   const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
+   const uint32_t* counters;  // of the prepare step: [q * SPARSE_COUNTER_STRIDE + 2] = the cardinality of filter q
+   uint32_t row_words;
+   uint32_t n_run_slices;
+   uint32_t n_ranges;
+   uint32_t first_unit[DERIVED_MAX_RANGES + 1];  // blocks per range (k_count_sparse_keys, k_finish_scan: each their own)
+   DerivedRange ranges[DERIVED_MAX_RANGES];
+};
+
+/// grid = (1, slice of 2^17 sequences x range, filter).  The block keeps its slice of the filter in LDS (16 KiB) and, where it
+/// fits (LDS_DIFF), the diff of the whole range as well (<= ~140 KiB: 35 000 positions), so that the adds of a slice's runs —
+/// two per selected run — are LDS atomics and only the non-zero entries go to memory (256 contiguous bytes per wave instruction).
+template <bool LDS_DIFF>
+__global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const DerivedArgs args) {
+   extern __shared__ uint32_t s_runs[];  // [ESCAPE_SLICE_WORDS32] the filter slice, then [n + 1] the diff
+   uint32_t* s_diff = s_runs + ESCAPE_SLICE_WORDS32;
+   const uint32_t q = blockIdx.z;
+   const uint32_t slice = blockIdx.y % args.n_run_slices;
+   const DerivedRange& range = args.ranges[blockIdx.y / args.n_run_slices];
+   if (range.code_map == nullptr) {
+      return;  // (uniform) nothing is derived in this store
+   }
+   const uint32_t run_begin = range.run_slice_first[slice];
+   const uint32_t run_end = range.run_slice_first[slice + 1];
+   if (run_begin == run_end) {
+      return;  // (uniform)
+   }
+   uint64_t any_bit = 0;
+   {
+      const uint64_t* filter = args.filters[q];
+      const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
+#pragma unroll
+      for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / DERIVED_THREADS; ++j) {
+         const uint32_t chunk = j * DERIVED_THREADS + threadIdx.x;  // 16-byte chunk of the slice
+         const uint32_t word = first_word + chunk * 2u;
+         const ulonglong2 v = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
+         *reinterpret_cast<ulonglong2*>(s_runs + chunk * 4u) = v;
+         any_bit |= v.x | v.y;
+      }
+   }
+   const uint32_t n = range.n_positions;
+   if constexpr (LDS_DIFF) {
+      for (uint32_t j = threadIdx.x; j <= n; j += DERIVED_THREADS) {
+         s_diff[j] = 0;
+      }
+   }
+   if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
+      return;  // no row of this slice is selected
+   }
+   uint32_t* __restrict__ diff = range.scratch + static_cast<size_t>(q) * range.stride + static_cast<size_t>(n) * range.n_scan;
+   const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
+   const uint32_t pos_end = range.pos_begin + n;
+   for (uint32_t i = run_begin + threadIdx.x; i < run_end; i += DERIVED_THREADS) {
+      const uint64_t key = range.run_keys[i];
+      const uint32_t local = static_cast<uint32_t>(key >> 32) - slice_first_row;
+      if (((s_runs[local >> 5] >> (local & 31u)) & 1u) == 0) {
+         continue;
+      }
+      const uint32_t start = max(static_cast<uint32_t>(key), range.pos_begin);
+      const uint32_t end = min(range.run_ends[i], pos_end);
+      if (start < end) {
+         if constexpr (LDS_DIFF) {
+            atomicAdd(&s_diff[start - range.pos_begin], 1u);
+            atomicAdd(&s_diff[end - range.pos_begin], 0xFFFFFFFFu);
+         } else {
+            atomicAdd(&diff[start - range.pos_begin], 1u);
+            atomicAdd(&diff[end - range.pos_begin], 0xFFFFFFFFu);
+         }
+      }
+   }
+   if constexpr (LDS_DIFF) {
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j <= n; j += DERIVED_THREADS) {
+         const uint32_t value = s_diff[j];
+         if (value != 0) {
+            atomicAdd(&diff[j], value);
+         }
+      }
+   }
+}
+
+/// ambiguous[p] += the rows of filter blockIdx.y among the sparse keys (ambiguity codes) of position p: one global filter
+/// lookup per key (these are ~1e-5 of the cells), one atomic per distinct position and wave.
+__global__ __launch_bounds__(256) void k_count_sparse_keys(const DerivedArgs args) {
+   const uint32_t q = blockIdx.y;
+   const uint32_t lane = threadIdx.x & 63u;
+   uint32_t r = 0;
+   while (r + 1 < args.n_ranges && blockIdx.x >= args.first_unit[r + 1]) {
+      ++r;
+   }
+   const DerivedRange& range = args.ranges[r];
+   const uint32_t n = range.n_positions;
+   uint32_t* __restrict__ ambiguous = range.scratch + static_cast<size_t>(q) * range.stride + static_cast<size_t>(n) * range.n_scan + n + 1u;
+   const uint32_t first = range.sparse_begin + (blockIdx.x - args.first_unit[r]) * (256u * SPARSE_KEYS_PER_THREAD) + threadIdx.x;
+   uint64_t key[SPARSE_KEYS_PER_THREAD];
+#pragma unroll
+   for (uint32_t k = 0; k < SPARSE_KEYS_PER_THREAD; ++k) {
+      const uint32_t i = first + k * 256u;
+      key[k] = i < range.sparse_end ? range.sparse_keys[i] : 0;
+   }
+#pragma unroll
+   for (uint32_t k = 0; k < SPARSE_KEYS_PER_THREAD; ++k) {
+      const uint32_t sequence = static_cast<uint32_t>(key[k]);
+      bool pending = first + k * 256u < range.sparse_end && ((args.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0;
+      const uint32_t counter = static_cast<uint32_t>(key[k] >> 37) - range.pos_begin;
+      for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
+         const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
+         const uint32_t leader_counter = __shfl(counter, leader);
+         const uint64_t same = __ballot(pending && counter == leader_counter);
+         if (lane == leader) {
+            atomicAdd(&ambiguous[leader_counter], static_cast<uint32_t>(__popcll(same)));
+         }
+         if (counter == leader_counter) {
+            pending = false;
+         }
+      }
+   }
+}
+
+/// The last step of a scan with derived symbols: grid = (blocks of 1024 positions dealt to the ranges, filter).  A thread
+/// owns a position: the rows of the filter inside a run of the missing symbol there (the sum of diff up to it: the part
+/// before the block's positions summed by the block itself, then a scan over the block), plus those with an ambiguity code,
+/// are the rows without a valid symbol; what is left of the filter after them and after the other symbols' counts is the
+/// derived symbol's count.  The private table is added to the caller's.
+__global__ __launch_bounds__(DERIVED_THREADS) void k_finish_scan(const DerivedArgs args) {
+   __shared__ uint32_t s_before[DERIVED_THREADS / 64];
+   __shared__ uint32_t s_own[DERIVED_THREADS / 64];
+   const uint32_t q = blockIdx.y;
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t wave = threadIdx.x >> 6;
+   uint32_t r = 0;
+   while (r + 1 < args.n_ranges && blockIdx.x >= args.first_unit[r + 1]) {
+      ++r;
+   }
+   const DerivedRange& range = args.ranges[r];
+   const uint32_t n = range.n_positions;
+   const uint32_t n_scan = range.n_scan;
+   const uint32_t first_position = (blockIdx.x - args.first_unit[r]) * DERIVED_THREADS;
+   const uint32_t p = first_position + threadIdx.x;
+   const uint32_t* __restrict__ counts = range.scratch + static_cast<size_t>(q) * range.stride;
+   const uint32_t* __restrict__ diff = counts + static_cast<size_t>(n) * n_scan;
+   const uint32_t* __restrict__ ambiguous = diff + n + 1u;
+   uint32_t without_symbol = 0;  // rows of the filter that have no valid symbol at p
+   if (range.code_map != nullptr) {  // (uniform)
+      uint32_t before = 0;
+      for (uint32_t j = threadIdx.x; j < first_position; j += DERIVED_THREADS) {
+         before += diff[j];
+      }
+      const uint32_t scanned = waveSumToLane63(p < n ? diff[p] : 0u);  // inclusive over the wave
+      before = waveSumToLane63(before);
+      if (lane == 63u) {
+         s_before[wave] = before;
+         s_own[wave] = scanned;
+      }
+      __syncthreads();
+      without_symbol = scanned;
+      for (uint32_t k = 0; k < DERIVED_THREADS / 64; ++k) {
+         without_symbol += s_before[k] + (k < wave ? s_own[k] : 0u);
+      }
+      if (p < n) {
+         without_symbol += ambiguous[p];
+      }
+   }
+   if (p >= n) {
+      return;
+   }
+   uint32_t* __restrict__ out = range.caller_counts[q] + static_cast<size_t>(p) * n_scan;
+   const uint32_t* __restrict__ cell = counts + static_cast<size_t>(p) * n_scan;
+   uint32_t others = 0;
+   for (uint32_t symbol = 0; symbol < n_scan; ++symbol) {
+      const uint32_t count = cell[symbol];
+      others += count;
+      if (count != 0) {
+         out[symbol] += count;  // scans of one table are ordered on a stream: no atomic needed
+      }
+   }
+   if (range.code_map != nullptr) {
+      const uint8_t* map = range.code_map + static_cast<size_t>(range.pos_begin + p) * CODE_MAP_STRIDE;
+      if ((map[0] & LAYOUT_IMPLICIT) != 0) {
+         const uint32_t derived = args.counters[q * SPARSE_COUNTER_STRIDE + 2] - without_symbol - others;
+         if (derived != 0) {
+            out[map[IMPLICIT_SLOT]] += derived;
+         }
+      }
+   }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1365,6 +1648,11 @@ __device__ __forceinline__ void emitWord(
    };
    if (store.build_mode == BUILD_COUNT) {  // first pass of a two-pass build: how many rows have which valid symbol here
       const uint32_t scan_index = is_scan ? store.index[symbol] : 0xFFu;
+      // ... and how many sparsely stored symbols there are in all (none is stored: the second pass gets a buffer that holds them)
+      const uint64_t sparse_lanes = __ballot(symbol < store.n_symbols && store.kind[symbol] == PLANE_SPARSE);
+      if (sparse_lanes != 0 && lane == 0) {
+         atomicAdd(sparse_count, static_cast<uint32_t>(__popcll(sparse_lanes)));
+      }
       for (uint64_t remaining = __ballot(is_scan); remaining != 0;) {
          const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(remaining));
          const uint32_t leader_index = __shfl(scan_index, leader);
@@ -1378,12 +1666,14 @@ __device__ __forceinline__ void emitWord(
    }
    if (store.build_mode == BUILD_ENCODE) {  // second pass: straight into the position's adaptive layout
       const uint8_t* map = store.enc_code_map + static_cast<size_t>(position) * CODE_MAP_STRIDE;
-      const uint32_t rows_here = map[0] & 0x3Fu;
+      const uint32_t rows_here = map[0] & LAYOUT_ROWS_MASK;
       const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
       const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
       const uint32_t scan_index = is_scan ? store.index[symbol] : 0xFFu;
+      // the position's derived symbol is stored nowhere: no row, no key
+      const bool derived = is_scan && (map[0] & LAYOUT_IMPLICIT) != 0 && map[IMPLICIT_SLOT] == scan_index;
       uint32_t code = 0;  // the code (or 1 + one-hot row) of this lane's symbol here, 0 = not stored
-      if (is_scan) {
+      if (is_scan && !derived) {
          if (identity) {
             code = scan_index + 1u;
          } else {
@@ -1397,7 +1687,7 @@ __device__ __forceinline__ void emitWord(
       for (uint32_t row = 0; row < rows_here; ++row) {
          put(rows + static_cast<size_t>(row) * store.row_words, __ballot(one_hot ? code == row + 1u : ((code >> row) & 1u) != 0));
       }
-      if (is_scan && code == 0) {  // a valid symbol the position does not store: an escape key in the symbol's slice of the list
+      if (is_scan && code == 0 && !derived) {  // a valid symbol the position does not store: an escape key in the symbol's slice of the list
          const size_t counter = static_cast<size_t>(position) * store.n_scan + scan_index;
          const uint32_t slot = store.enc_first[counter] + atomicAdd(store.enc_cursor + counter, 1u);
          if (slot < store.enc_first[counter + 1]) {  // (more rows than the first pass counted: dropped, the cursor tells)
@@ -1911,17 +2201,58 @@ __global__ __launch_bounds__(256) void k_reconstruct_sequences(
          }
       }
    }
+   if (found == 0xFFu && layout.implicit) {  // no other symbol claims the cell: the position's derived symbol
+      for (uint32_t symbol = 0; symbol < store.n_symbols; ++symbol) {
+         if (store.kind[symbol] == PLANE_SCAN && store.index[symbol] == layout.map[IMPLICIT_SLOT]) {
+            found = symbol;
+         }
+      }
+   }
    out[static_cast<size_t>(blockIdx.y) * store.positions + position] = found == 0xFFu ? '?' : symbol_chars[found];
 }
 
 // One-hot plane of a valid mutation symbol out of the position's code planes (2, 3 or n_bits reads per word); a symbol
 // that has no code at the position yields zeros (its rows are escape keys: the caller scatters them on top).
-__global__ __launch_bounds__(256) void k_decode_plane(const SeqStoreDev store, uint32_t position, uint32_t symbol, uint64_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_decode_plane(
+   const SeqStoreDev store, uint32_t position, uint32_t symbol, const uint64_t* __restrict__ valid_words, uint64_t* __restrict__ out
+) {
    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
    if (word < store.row_words) {
       const PositionLayout layout = layoutOf(store, position);
       const uint32_t code = codeOfSymbol(layout, store.index[symbol]);
-      out[word] = code == 0xFFFFFFFFu ? 0ull : decodeCodeWord(layout, store.row_words, code, word);
+      if (code == CODE_IMPLICIT) {  // the derived symbol: every row no stored row claims (the caller clears the keys, the runs, the sparse symbols)
+         uint64_t others = 0;
+         for (uint32_t row = 0; row < layout.bits; ++row) {
+            others |= layout.rows[static_cast<size_t>(row) * store.row_words + word];
+         }
+         out[word] = ~others & valid_words[word];
+         return;
+      }
+      out[word] = code == CODE_ESCAPED ? 0ull : decodeCodeWord(layout, store.row_words, code, word);
+   }
+}
+
+/// Clears the rows of keys[begin, end) (sequence in the low 32 bits) in `out`.
+__global__ void k_clear_keys(const uint64_t* __restrict__ keys, uint32_t begin, uint32_t end, uint64_t* out) {
+   const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
+   if (k < end) {
+      const uint32_t sequence = static_cast<uint32_t>(keys[k] & 0xFFFFFFFFull);
+      atomicAnd(reinterpret_cast<unsigned long long*>(out + (sequence >> 6)), ~(1ull << (sequence & 63u)));
+   }
+}
+
+/// Clears the rows whose run of the missing symbol covers `position` in `out`.
+__global__ __launch_bounds__(256) void k_runs_clear_plane(
+   const uint64_t* __restrict__ run_keys, const uint32_t* __restrict__ run_ends, uint32_t n_runs, uint32_t position, uint64_t* __restrict__ out
+) {
+   const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+   if (run >= n_runs) {
+      return;
+   }
+   const uint64_t key = run_keys[run];
+   if (static_cast<uint32_t>(key) <= position && position < run_ends[run]) {
+      const uint32_t sequence = static_cast<uint32_t>(key >> 32);
+      atomicAnd(reinterpret_cast<unsigned long long*>(out + (sequence >> 6)), ~(1ull << (sequence & 63u)));
    }
 }
 
@@ -2041,6 +2372,9 @@ int silo_gpu_tune(int knob, int value) {
    }
    if (knob == SILO_GPU_TUNE_MISSING_RUNS) {
       return g_tune_missing_runs.exchange(value);
+   }
+   if (knob == SILO_GPU_TUNE_LAUNCH_COST) {
+      return g_tune_launch_cost.exchange(value);
    }
    return -1;
 }
@@ -2172,6 +2506,7 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.layout.d_escapes);
       (void)hipFree(seqstore.layout.d_escapes_sliced);
       (void)hipFree(seqstore.layout.d_slice_first);
+      (void)hipFree(seqstore.layout.d_run_slice_first);
       (void)hipFree(seqstore.layout.d_escape_first);
    }
    (void)hipFree(store->d_ones);
@@ -2231,6 +2566,9 @@ int silo_gpu_store_append_sequences(
    }
    seqstore.finalized = false;
    seqstore.totals_ready = seqstore.dev.build_mode == BUILD_ENCODE;  // (the counts of the first pass ARE the totals)
+   if (seqstore.dev.build_mode != BUILD_ENCODE) {
+      seqstore.rows_filled += n_sequences;
+   }
    const uint32_t positions = seqstore.dev.positions;
    const uint32_t pitch = positions;  // rows stay contiguous: ONE host-to-device copy per batch
 
@@ -2271,22 +2609,28 @@ int silo_gpu_store_append_sequences(
    const uint32_t n_words = last_word - first_word + 1u;
    const dim3 grid((n_words + 3) / 4, (positions + TRANSPOSE_POSITIONS_PER_WAVE - 1) / TRANSPOSE_POSITIONS_PER_WAVE);
 
+   // The passes of a two-pass build must not be replayed — the counting pass adds to counters, the encoding pass takes key
+   // slots and run slots with atomic cursors — so they never overflow the sparse buffer: the counting pass stores no sparse key
+   // at all (capacity 0: the counter counts them), silo_gpu_store_build_pass(2) sizes the buffer from that count.
+   const uint32_t build_mode = seqstore.dev.build_mode;
    uint32_t count_before = 0;
    err = hipMemcpy(&count_before, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
    if (err != hipSuccess) {
       release();
       return fail(SILO_GPU_ERR_HIP, std::string("reading sparse counter: ") + hipGetErrorString(err));
    }
-   if (int rc = growSparse(seqstore, count_before + (1u << 16)); rc != SILO_GPU_OK) {
-      release();
-      return rc;
+   if (build_mode == BUILD_PLANES) {
+      if (int rc = growSparse(seqstore, count_before + (1u << 16)); rc != SILO_GPU_OK) {
+         release();
+         return rc;
+      }
    }
-   // The dense writes are idempotent (atomicOr / whole-word stores); if the sparse buffer overflows
+   // The dense writes of an ordinary build are idempotent (atomicOr / whole-word stores); if the sparse buffer overflows
    // the counter is rewound, the buffer grown and the batch replayed.
    for (int attempt = 0; attempt < 8; ++attempt) {
       k_transpose_sequences<<<grid, 256>>>(
          seqstore.dev, d_chars, d_null, pitch, first_sequence, n_sequences, first_word, n_words, d_table,
-         seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity, store->d_error_flag
+         seqstore.d_sparse, seqstore.d_sparse_count, build_mode == BUILD_COUNT ? 0u : seqstore.sparse_capacity, store->d_error_flag
       );
       err = hipDeviceSynchronize();
       uint32_t count_after = 0;
@@ -2297,8 +2641,12 @@ int silo_gpu_store_append_sequences(
          release();
          return fail(SILO_GPU_ERR_HIP, std::string("k_transpose_sequences: ") + hipGetErrorString(err));
       }
-      if (count_after <= seqstore.sparse_capacity) {
+      if (build_mode == BUILD_COUNT || count_after <= seqstore.sparse_capacity) {
          break;
+      }
+      if (build_mode == BUILD_ENCODE) {
+         release();
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: the second pass brought more sparsely stored symbols than the first pass counted");
       }
       err = hipMemcpy(seqstore.d_sparse_count, &count_before, sizeof(uint32_t), hipMemcpyHostToDevice);
       if (err != hipSuccess) {
@@ -2332,6 +2680,7 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
    }
    seqstore.finalized = false;
    seqstore.totals_ready = seqstore.dev.build_mode == BUILD_ENCODE;
+   seqstore.rows_filled = store->sequence_count;
    const uint32_t n = store->sequence_count;
    const uint32_t positions = seqstore.dev.positions;
 
@@ -2416,13 +2765,16 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
       release();
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "ambiguous_threshold too large for the sparse store");
    }
-   if (int rc = growSparse(seqstore, static_cast<uint32_t>(wanted)); rc != SILO_GPU_OK) {
-      release();
-      return rc;
+   const uint32_t build_mode = seqstore.dev.build_mode;  // (the passes of a two-pass build are never replayed: see append_sequences)
+   if (build_mode == BUILD_PLANES) {
+      if (int rc = growSparse(seqstore, static_cast<uint32_t>(wanted)); rc != SILO_GPU_OK) {
+         release();
+         return rc;
+      }
    }
    for (int attempt = 0; attempt < 4; ++attempt) {
       k_generate_synthetic<<<grid, 256>>>(
-         seqstore.dev, args, n_words, seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity
+         seqstore.dev, args, n_words, seqstore.d_sparse, seqstore.d_sparse_count, build_mode == BUILD_COUNT ? 0u : seqstore.sparse_capacity
       );
       err = hipDeviceSynchronize();
       uint32_t count_after = 0;
@@ -2433,8 +2785,12 @@ int silo_gpu_store_generate_synthetic(silo_gpu_store* store, uint32_t seqstore_i
          release();
          return fail(SILO_GPU_ERR_HIP, std::string("k_generate_synthetic: ") + hipGetErrorString(err));
       }
-      if (count_after <= seqstore.sparse_capacity) {
+      if (build_mode == BUILD_COUNT || count_after <= seqstore.sparse_capacity) {
          break;
+      }
+      if (build_mode == BUILD_ENCODE) {
+         release();
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: the second pass brought more sparsely stored symbols than the first pass counted");
       }
       err = hipMemcpy(seqstore.d_sparse_count, &zero, sizeof(uint32_t), hipMemcpyHostToDevice);
       if (err != hipSuccess) {
@@ -2532,6 +2888,45 @@ int compactMissingPlane(silo_gpu_store* store, SeqStoreHost& seqstore) {
    return SILO_GPU_OK;
 }
 
+/// first[slice] = first run of the missing symbol whose sequence lies in slice `slice` of 2^ESCAPE_SLICE_SHIFT sequences or
+/// beyond (the runs are sorted by sequence): one binary search per entry.
+__global__ void k_run_slice_index(const uint64_t* __restrict__ run_keys, uint32_t n_runs, uint32_t slice_shift, uint32_t n_entries, uint32_t* __restrict__ first) {
+   const uint32_t slice = blockIdx.x * blockDim.x + threadIdx.x;
+   if (slice >= n_entries) {
+      return;
+   }
+   uint32_t lo = 0, hi = n_runs;
+   while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((static_cast<uint32_t>(run_keys[mid] >> 32) >> slice_shift) < slice) {
+         lo = mid + 1;
+      } else {
+         hi = mid;
+      }
+   }
+   first[slice] = lo;
+}
+
+/// A store with derived symbols counts, per scan, the rows of the filter inside a run of the missing symbol: where the runs
+/// of every slice of sequences begin (k_scan_missing_runs keeps that slice of the filter in LDS).
+int buildRunSliceIndex(silo_gpu_store* store, SeqStoreHost& seqstore) {
+   SeqStoreHost::Layout& layout = seqstore.layout;
+   if (!layout.has_implicit || layout.d_run_slice_first != nullptr) {
+      return SILO_GPU_OK;
+   }
+   const SeqStoreDev& dev = seqstore.dev;
+   if (dev.kind[dev.missing_symbol] != PLANE_RUNS) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "a store with derived symbols keeps the missing symbol as runs");
+   }
+   layout.n_run_slices = (store->sequence_count + (1u << ESCAPE_SLICE_SHIFT) - 1) >> ESCAPE_SLICE_SHIFT;
+   const uint32_t n_entries = layout.n_run_slices + 1;
+   HIP_TRY(hipMalloc(&layout.d_run_slice_first, n_entries * sizeof(uint32_t)));
+   k_run_slice_index<<<(n_entries + 255) / 256, 256>>>(dev.missing_run_keys, dev.n_missing_runs, ESCAPE_SLICE_SHIFT, n_entries, layout.d_run_slice_first);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipStreamSynchronize(nullptr));
+   return SILO_GPU_OK;
+}
+
 int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
    if (seqstore.layout.built) {
       return SILO_GPU_OK;
@@ -2556,10 +2951,15 @@ int finalizeSeqStore(silo_gpu_store* store, SeqStoreHost& seqstore) {
       HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice));
    }
    seqstore.finalized = true;
+   // the missing symbol first: its plane goes before the adaptive planes come (a lower peak), and only a store that keeps it as
+   // runs may derive the most numerous symbol of a position (planLayout)
+   if (const int rc = compactMissingPlane(store, seqstore); rc != SILO_GPU_OK) {
+      return rc;
+   }
    if (const int rc = buildLayout(store, seqstore); rc != SILO_GPU_OK) {
       return rc;
    }
-   return compactMissingPlane(store, seqstore);
+   return buildRunSliceIndex(store, seqstore);
 }
 }  // namespace
 
@@ -2603,6 +3003,18 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_build_pass: the encoding pass follows the counting pass");
    }
    HIP_TRY(hipDeviceSynchronize());  // every count of the first pass has landed
+   {  // the sparsely stored symbols the first pass counted (it stored none): room for all of them, the counter starts over
+      uint32_t counted = 0;
+      HIP_TRY(hipMemcpy(&counted, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      if (counted > 0xFFFF0000u) {
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: too many sparsely stored symbols");
+      }
+      if (const int rc = growSparse(seqstore, counted + 1u); rc != SILO_GPU_OK) {
+         return rc;
+      }
+      const uint32_t zero = 0;
+      HIP_TRY(hipMemcpy(seqstore.d_sparse_count, &zero, sizeof(uint32_t), hipMemcpyHostToDevice));
+   }
    dev.build_mode = BUILD_PLANES;
    dev.enc_counts = nullptr;
    seqstore.totals_ready = true;
@@ -2614,7 +3026,12 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
    }
    auto work = std::make_shared<SeqStoreHost::LayoutWork>();
    bool fits = false;
-   if (const int rc = planLayout(seqstore, *work, true, &fits); rc != SILO_GPU_OK) {
+   unsigned long long n_runs = 0;
+   if (runs_counted) {
+      HIP_TRY(hipMemcpy(&n_runs, seqstore.d_run_count, sizeof(n_runs), hipMemcpyDeviceToHost));
+   }
+   // (the most numerous symbol of a position is derived only where the missing symbol is kept as runs)
+   if (const int rc = planLayout(seqstore, *work, true, runs_counted && n_runs < (1ull << 32) && seqstore.rows_filled == store->sequence_count, &fits); rc != SILO_GPU_OK) {
       return rc;
    }
    if (!fits) {
@@ -2622,8 +3039,6 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
       return SILO_GPU_OK;
    }
    if (runs_counted) {  // the runs of the missing symbol: exactly as many slots as the first pass counted
-      unsigned long long n_runs = 0;
-      HIP_TRY(hipMemcpy(&n_runs, seqstore.d_run_count, sizeof(n_runs), hipMemcpyDeviceToHost));
       if (n_runs < (1ull << 32)) {
          const size_t slots = std::max<size_t>(n_runs, 1);
          hipError_t status = hipMalloc(&seqstore.d_missing_run_keys, slots * sizeof(uint64_t));
@@ -2747,6 +3162,9 @@ void cutIntoPieces(const std::vector<ScanRange>& ranges, uint32_t q_count, std::
             piece.code_map = reinterpret_cast<const uint8_t*>(seqstore.layout.d_row_target + first_row);
             piece.n_positions = seqstore.layout.row_of[end] - seqstore.layout.row_of[begin];
             piece.target_base = begin * dev.n_scan;
+            if (piece.n_positions == 0) {
+               return;  // positions whose only stored symbol is derived: no rows
+            }
          } else if (!identity) {
             piece.code_map = seqstore.layout.d_code_map + static_cast<size_t>(begin) * CODE_MAP_STRIDE;
          }
@@ -2889,14 +3307,18 @@ int launchGatherScan(ScanBatchArgs& batch, const uint32_t* sector_index, uint32_
    return SILO_GPU_OK;
 }
 
-/// Device scratch of the sparse-filter routing: per filter a counter and the list of sector indexes.  Blocks are
-/// pooled; a block is handed out again only once the event recorded after its last use has completed, whatever
-/// stream that use was on.
+/// Device scratch of a scan: per filter the counters of the prepare step (TWO sets: a scan uses one and zeroes the other for
+/// the next scan on this block, so no fill launch is needed), the list of sector indexes of the sparse-filter routing, and
+/// the private tables of a scan with derived symbols.  Blocks are pooled; a block is handed out again only once the event
+/// recorded after its last use has completed, whatever stream that use was on.
 struct SparseScratch {
    int device = 0;
    uint32_t capacity = 0;  // sectors per filter
-   uint32_t* sparse_sectors = nullptr;  // [SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE]
-   uint32_t* sector_index = nullptr;    // [SILO_GPU_MAX_SCAN_BATCH][capacity]
+   uint32_t* counters[2] = {nullptr, nullptr};  // [SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE] each
+   uint32_t set = 0;                            // the counter set of the current use
+   uint32_t* sector_index = nullptr;            // [SILO_GPU_MAX_SCAN_BATCH][capacity]
+   uint32_t* tables = nullptr;                  // private count tables (scans with derived symbols)
+   size_t table_words = 0;
    hipEvent_t last_use = nullptr;
    bool in_flight = false;  // handed out and not yet released
 };
@@ -2904,12 +3326,14 @@ struct SparseScratch {
 std::mutex g_sparse_scratch_mutex;
 std::vector<SparseScratch*> g_sparse_scratch;
 
-int acquireSparseScratch(int device, uint32_t capacity, SparseScratch** out) {
+int acquireSparseScratch(int device, uint32_t capacity, size_t table_words, SparseScratch** out) {
    {
       std::lock_guard<std::mutex> lock(g_sparse_scratch_mutex);
       for (SparseScratch* block : g_sparse_scratch) {
-         if (!block->in_flight && block->device == device && block->capacity >= capacity && hipEventQuery(block->last_use) == hipSuccess) {
+         if (!block->in_flight && block->device == device && block->capacity >= capacity && block->table_words >= table_words &&
+             hipEventQuery(block->last_use) == hipSuccess) {
             block->in_flight = true;
+            block->set ^= 1u;
             *out = block;
             return SILO_GPU_OK;
          }
@@ -2918,15 +3342,22 @@ int acquireSparseScratch(int device, uint32_t capacity, SparseScratch** out) {
    auto block = std::make_unique<SparseScratch>();
    block->device = device;
    block->capacity = capacity;
+   block->table_words = std::max<size_t>(table_words, size_t{1} << 20);
    void* memory = nullptr;
-   // one allocation: the index lists, then the counters
-   const size_t bytes = (static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity + SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE) * sizeof(uint32_t);
+   // one allocation: the private tables, the index lists, then the two counter sets (zeroed here, by the scans from then on)
+   const size_t counter_words = static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * SPARSE_COUNTER_STRIDE;
+   const size_t bytes = (block->table_words + static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity + 2 * counter_words) * sizeof(uint32_t);
    HIP_TRY(hipMalloc(&memory, bytes));
-   block->sector_index = static_cast<uint32_t*>(memory);
-   block->sparse_sectors = block->sector_index + static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity;
-   if (hipEventCreateWithFlags(&block->last_use, hipEventDisableTiming) != hipSuccess) {
+   block->tables = static_cast<uint32_t*>(memory);
+   block->sector_index = block->tables + block->table_words;
+   block->counters[0] = block->sector_index + static_cast<size_t>(SILO_GPU_MAX_SCAN_BATCH) * capacity;
+   block->counters[1] = block->counters[0] + counter_words;
+   hipError_t status = hipMemset(block->counters[0], 0, 2 * counter_words * sizeof(uint32_t));
+   status = status != hipSuccess ? status : hipStreamSynchronize(nullptr);  // the fill is only enqueued; the scans run on other streams
+   status = status != hipSuccess ? status : hipEventCreateWithFlags(&block->last_use, hipEventDisableTiming);
+   if (status != hipSuccess) {
       (void)hipFree(memory);
-      return fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipEventCreate failed");
+      return fail(SILO_GPU_ERR_HIP, "scan scratch: " + std::string(hipGetErrorString(status)));
    }
    block->in_flight = true;
    std::lock_guard<std::mutex> lock(g_sparse_scratch_mutex);
@@ -3142,10 +3573,125 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    return launchSliced();
 }
 
-/// scanEscapes on side stream 0: forked behind everything already queued on `hip_stream` (the filters are complete, the
-/// count tables zeroed), joined by joinSides before anything reads the tables.
-int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream) {
-   bool any = false;
+/// The private tables of a scan with derived symbols and what its extra passes read, DERIVED_MAX_RANGES ranges at a time.
+struct DerivedPlan {
+   std::vector<DerivedArgs> launches;     // ranges [16 k, 16 k + 16) of the scan
+   std::vector<ScanRange> private_ranges;  // the ranges with their count tables replaced by the private ones
+   size_t table_words = 0;
+   uint32_t most_positions = 0;  // of a range with derived symbols
+};
+
+/// Lays the private tables of `ranges` out (offsets only: `tables` may still be null) .
+void planDerived(const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, DerivedPlan& plan) {
+   plan.private_ranges = ranges;
+   plan.launches.assign((ranges.size() + DERIVED_MAX_RANGES - 1) / DERIVED_MAX_RANGES, DerivedArgs{});
+   size_t offset = 0;
+   for (size_t r = 0; r < ranges.size(); ++r) {
+      const ScanRange& range = ranges[r];
+      const SeqStoreHost& seqstore = *range.seqstore;
+      DerivedArgs& launch = plan.launches[r / DERIVED_MAX_RANGES];
+      DerivedRange& entry = launch.ranges[launch.n_ranges++];
+      const uint32_t n = range.pos_end - range.pos_begin;
+      entry.n_positions = n;
+      entry.n_scan = seqstore.dev.n_scan;
+      entry.pos_begin = range.pos_begin;
+      entry.stride = static_cast<uint32_t>((static_cast<size_t>(n) * seqstore.dev.n_scan + n + 1 + n + 3) / 4 * 4);
+      entry.scratch = reinterpret_cast<uint32_t*>(offset * sizeof(uint32_t));  // + the scratch block's tables (bindDerived)
+      offset += static_cast<size_t>(entry.stride) * q_count;
+      if (seqstore.layout.has_implicit) {
+         entry.code_map = seqstore.layout.d_code_map;
+         entry.run_keys = seqstore.dev.missing_run_keys;
+         entry.run_ends = seqstore.dev.missing_run_ends;
+         entry.run_slice_first = seqstore.layout.d_run_slice_first;
+         launch.n_run_slices = seqstore.layout.n_run_slices;
+         entry.sparse_keys = seqstore.d_sparse;
+         const auto lo = std::lower_bound(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end(), static_cast<uint64_t>(range.pos_begin) << 37);
+         const auto hi = std::lower_bound(lo, seqstore.sparse_sorted.end(), static_cast<uint64_t>(range.pos_end) << 37);
+         entry.sparse_begin = static_cast<uint32_t>(lo - seqstore.sparse_sorted.begin());
+         entry.sparse_end = static_cast<uint32_t>(hi - seqstore.sparse_sorted.begin());
+         plan.most_positions = std::max(plan.most_positions, n);
+      }
+      for (uint32_t q = 0; q < q_count; ++q) {
+         entry.caller_counts[q] = range.counts[q];
+         launch.filters[q] = filters[q];
+      }
+      launch.row_words = store->row_words;
+   }
+   plan.table_words = offset;
+}
+
+/// The tables get their place in the scratch block; the private ranges point at them.
+void bindDerived(DerivedPlan& plan, const SparseScratch& scratch, uint32_t q_count) {
+   size_t r = 0;
+   for (DerivedArgs& launch : plan.launches) {
+      launch.counters = scratch.counters[scratch.set];
+      for (uint32_t k = 0; k < launch.n_ranges; ++k, ++r) {
+         DerivedRange& entry = launch.ranges[k];
+         entry.scratch = scratch.tables + reinterpret_cast<size_t>(entry.scratch) / sizeof(uint32_t);
+         for (uint32_t q = 0; q < q_count; ++q) {
+            plan.private_ranges[r].counts[q] = entry.scratch + static_cast<size_t>(q) * entry.stride;
+         }
+      }
+   }
+}
+
+/// Rows of the filters without a valid symbol, per position: the runs of the missing symbol and the sparse keys (ambiguity codes).
+int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_stream) {
+   for (DerivedArgs& launch : plan.launches) {
+      bool any = false;
+      for (uint32_t k = 0; k < launch.n_ranges; ++k) {
+         any = any || launch.ranges[k].code_map != nullptr;
+      }
+      if (!any) {
+         continue;
+      }
+      // the diff of a range in LDS beside the filter slice, while it fits
+      const size_t lds_bytes = (ESCAPE_SLICE_WORDS32 + static_cast<size_t>(plan.most_positions) + 1) * sizeof(uint32_t);
+      const bool lds_diff = lds_bytes <= 152 * 1024;
+      static std::once_flag lds_once;
+      std::call_once(lds_once, [] {
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_missing_runs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+      });
+      const dim3 run_grid(1, launch.n_run_slices * launch.n_ranges, q_count);
+      if (lds_diff) {
+         k_scan_missing_runs<true><<<run_grid, DERIVED_THREADS, lds_bytes, hip_stream>>>(launch);
+      } else {
+         k_scan_missing_runs<false><<<run_grid, DERIVED_THREADS, ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), hip_stream>>>(launch);
+      }
+      HIP_TRY(hipGetLastError());
+      launch.first_unit[0] = 0;
+      for (uint32_t k = 0; k < launch.n_ranges; ++k) {
+         const uint32_t keys = launch.ranges[k].code_map != nullptr ? launch.ranges[k].sparse_end - launch.ranges[k].sparse_begin : 0;
+         launch.first_unit[k + 1] = launch.first_unit[k] + (keys + 256 * SPARSE_KEYS_PER_THREAD - 1) / (256 * SPARSE_KEYS_PER_THREAD);
+      }
+      if (launch.first_unit[launch.n_ranges] != 0) {
+         k_count_sparse_keys<<<dim3(launch.first_unit[launch.n_ranges], q_count), 256, 0, hip_stream>>>(launch);
+         HIP_TRY(hipGetLastError());
+      }
+   }
+   return SILO_GPU_OK;
+}
+
+/// The derived counts, and the private tables into the caller's.
+int finishDerived(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_stream) {
+   for (DerivedArgs& launch : plan.launches) {
+      launch.first_unit[0] = 0;
+      for (uint32_t k = 0; k < launch.n_ranges; ++k) {
+         launch.first_unit[k + 1] = launch.first_unit[k] + (launch.ranges[k].n_positions + DERIVED_THREADS - 1) / DERIVED_THREADS;
+      }
+      if (launch.first_unit[launch.n_ranges] != 0) {
+         k_finish_scan<<<dim3(launch.first_unit[launch.n_ranges], q_count), DERIVED_THREADS, 0, hip_stream>>>(launch);
+         HIP_TRY(hipGetLastError());
+      }
+   }
+   return SILO_GPU_OK;
+}
+
+/// The passes beside the plane scans — the escape keys and, for a scan with derived symbols, the rows without a valid symbol —
+/// on side stream 0: forked behind everything already queued on `hip_stream` (the filters are complete, the count tables
+/// zeroed), joined by joinSides before anything reads the tables.
+int forkSidePasses(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, DerivedPlan* derived, hipStream_t hip_stream) {
+   bool any = derived != nullptr;
    for (const ScanRange& range : ranges) {
       const SeqStoreHost::Layout& layout = range.seqstore->layout;
       any = any || (layout.built && layout.d_escapes != nullptr && layout.escape_first[range.pos_end] != layout.escape_first[range.pos_begin]);
@@ -3155,30 +3701,37 @@ int forkEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    }
    const int mode = g_tune_side_stream.load();  // 0: lowest-priority side stream, 1: default priority, 2: the caller's stream
    SideStreams* side = mode == 2 ? nullptr : sideStreams();
-   if (side == nullptr) {
-      return scanEscapes(ranges, filters, q_count, hip_stream);
+   hipStream_t stream = hip_stream;
+   if (side != nullptr) {
+      const int k = mode == 1 ? 1 : 0;
+      if (const int rc = forkSide(side, k, 0, hip_stream, true); rc != SILO_GPU_OK) {
+         return rc;
+      }
+      stream = side->stream[k];
    }
-   const int k = mode == 1 ? 1 : 0;
-   if (const int rc = forkSide(side, k, 0, hip_stream, true); rc != SILO_GPU_OK) {
-      return rc;
+   if (derived != nullptr) {
+      if (const int rc = scanRowsWithoutSymbol(*derived, q_count, stream); rc != SILO_GPU_OK) {
+         return rc;
+      }
    }
-   return scanEscapes(ranges, filters, q_count, side->stream[k]);
+   return scanEscapes(ranges, filters, q_count, stream);
 }
 
 /// Scan of up to SILO_GPU_MAX_SCAN_BATCH filters over position ranges of sequence stores of one alphabet, with the
 /// sparse-filter routing (K1s) around the dense kernels: every filter is compacted ONCE for all ranges, the dense
-/// kernels skip the sparse ones, the gather kernel serves them.  All decisions are taken on the device.
+/// kernels skip the sparse ones, the gather kernel serves them.  All decisions are taken on the device.  Where a store
+/// derives the most numerous symbol of its positions the kernels count into private tables and k_finish_scan completes them.
 int scanRanges(
-   const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream
+   const silo_gpu_store* store, const std::vector<ScanRange>& caller_ranges, const uint64_t* const* filters, uint32_t q_count, hipStream_t hip_stream
 ) {
-   const SeqStoreDev& any_store = ranges.front().seqstore->dev;
+   const SeqStoreDev& any_store = caller_ranges.front().seqstore->dev;
    const bool nucleotide = any_store.n_bits == 3 && any_store.n_scan == 5;
    if (!nucleotide && !(any_store.n_bits == 5 && any_store.n_scan == 22)) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "mutations scan: unsupported set of scan symbols (5 nucleotide or 22 amino-acid symbols)");
    }
    if (any_store.row_words < SCAN_THREADS * 4) {
       // short rows: one wave per position over the identity planes (such stores keep them), one filter and one range at a time
-      for (const ScanRange& range : ranges) {
+      for (const ScanRange& range : caller_ranges) {
          const SeqStoreDev& dev = range.seqstore->dev;
          const uint32_t n_positions = range.pos_end - range.pos_begin;
          const uint32_t waves = std::min<uint32_t>(n_positions, 256u * 32u);
@@ -3198,48 +3751,70 @@ int scanRanges(
    }
    g_last_scan_kernel = q_count == 1 ? "k_scan_sliced" : "k_scan_sliced_batch";
    scanTimingLog().used = 0;
-   std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
-   cutIntoPieces(ranges, q_count, pieces);
+   bool any_derived = false;
+   for (const ScanRange& range : caller_ranges) {
+      any_derived = any_derived || range.seqstore->layout.has_implicit;
+   }
+   DerivedPlan plan;
+   if (any_derived) {
+      planDerived(store, caller_ranges, filters, q_count, plan);
+   }
    const int divisor = g_tune_sparse_divisor.load();
-   if (divisor < 0) {
-      int rc = forkEscapes(ranges, filters, q_count, hip_stream);
+   const bool routing = divisor >= 0;
+   if (!routing && !any_derived) {
+      std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
+      cutIntoPieces(caller_ranges, q_count, pieces);
+      int rc = forkSidePasses(caller_ranges, filters, q_count, nullptr, hip_stream);
       if (rc == SILO_GPU_OK) {
          rc = scanPiecesDense(pieces, any_store, filters, q_count, nullptr, 0, hip_stream);
       }
       const int joined = joinSides(hip_stream);
       return rc != SILO_GPU_OK ? rc : joined;
    }
-   const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor == 0 ? 16 : divisor));
+   const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor <= 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
-   const int acquired = acquireSparseScratch(store->device, capacity, &scratch);
+   const int acquired = acquireSparseScratch(store->device, capacity, plan.table_words, &scratch);
    if (acquired != SILO_GPU_OK) {
       return acquired;
    }
+   if (any_derived) {
+      bindDerived(plan, *scratch, q_count);
+   }
+   const std::vector<ScanRange>& ranges = any_derived ? plan.private_ranges : caller_ranges;
+   std::vector<ScanPiece> pieces[N_SCAN_LAYOUTS];
+   cutIntoPieces(ranges, q_count, pieces);
    const uint32_t stride = scratch->capacity;  // the block may be larger than asked for
+   uint32_t* counters = scratch->counters[scratch->set];
    int rc = SILO_GPU_OK;
-   if (hipMemsetAsync(scratch->sparse_sectors, 0, SILO_GPU_MAX_SCAN_BATCH * SPARSE_COUNTER_STRIDE * sizeof(uint32_t), hip_stream) != hipSuccess) {
-      rc = fail(SILO_GPU_ERR_HIP, "sparse scan scratch: hipMemsetAsync failed");
-   } else {
+   {
+      // the prepare step: the sectors of every filter that hold a set bit, its cardinality, the private tables zeroed, the
+      // other counter set re-armed
       ScanBatchArgs compact{};
       for (uint32_t q = 0; q < q_count; ++q) {
          compact.filters[q] = filters[q];
       }
       k_compact_filter<<<dim3((any_store.row_words + COMPACT_THREADS - 1) / COMPACT_THREADS, q_count), COMPACT_THREADS, 0, hip_stream>>>(
-         compact, any_store.row_words, stride, scratch->sparse_sectors, scratch->sector_index
+         compact, any_store.row_words, stride, counters, scratch->sector_index, scratch->tables, static_cast<uint32_t>(plan.table_words),
+         scratch->counters[scratch->set ^ 1u]
       );
-      // the escape pass is forked behind the compaction: the plane scans wait for its counters, and beside a launch that
+      if (hipGetLastError() != hipSuccess) {
+         scratch->set ^= 1u;  // the other set was not re-armed: the next use takes this one again
+         releaseSparseScratch(scratch, hip_stream);
+         return fail(SILO_GPU_ERR_HIP, "mutations scan: the prepare step could not be launched");
+      }
+      // the side passes are forked behind the prepare step: the plane scans wait for its counters, and beside a launch that
       // fills the device it takes ten times as long (62 instead of 6 us)
-      rc = forkEscapes(ranges, filters, q_count, hip_stream);
+      rc = forkSidePasses(ranges, filters, q_count, any_derived ? &plan : nullptr, hip_stream);
       if (rc == SILO_GPU_OK) {
-         rc = scanPiecesDense(pieces, any_store, filters, q_count, scratch->sparse_sectors, capacity, hip_stream);
+         rc = scanPiecesDense(pieces, any_store, filters, q_count, routing ? counters : nullptr, capacity, hip_stream);
       }
    }
    // the gather over the sectors of the sparse filters, over the same pieces of the same planes
-   for (int layout = 0; layout < N_SCAN_LAYOUTS; ++layout) {
+   for (int layout = 0; routing && layout < N_SCAN_LAYOUTS; ++layout) {
       const std::vector<ScanPiece>& list = pieces[layout];
       for (size_t first_piece = 0; rc == SILO_GPU_OK && first_piece < list.size(); first_piece += SCAN_MAX_RANGES) {
          ScanBatchArgs batch{};
-         batch.sparse_sectors = scratch->sparse_sectors;
+         batch.sparse_sectors = counters;
          batch.sparse_capacity = capacity;
          batch.out_symbols = any_store.n_scan;
          for (uint32_t q = 0; q < q_count; ++q) {
@@ -3256,6 +3831,9 @@ int scanRanges(
       }
    }
    const int joined = joinSides(hip_stream);  // before the scratch is released: side-stream scans read its counters
+   if (rc == SILO_GPU_OK && joined == SILO_GPU_OK && any_derived) {
+      rc = finishDerived(plan, q_count, hip_stream);
+   }
    releaseSparseScratch(scratch, hip_stream);
    return rc != SILO_GPU_OK ? rc : joined;
 }
@@ -3295,7 +3873,7 @@ bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev) {
 /// From the totals of the store (seqstore.d_totals): the layout of every position, the tables that describe it and the device
 /// arrays of the finished store — the plane rows zeroed when `zero_planes` (an encoder that only sets bits).  *fits = false
 /// (nothing allocated) when no position would be re-encoded or the arrays do not fit.
-int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool* fits) {
+int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits) {
    SeqStoreDev& dev = seqstore.dev;
    const uint32_t positions = dev.positions;
    const size_t n_counters = static_cast<size_t>(positions) * dev.n_scan;
@@ -3303,10 +3881,15 @@ int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero
    std::vector<uint32_t> totals(n_counters);
    HIP_TRY(hipMemcpy(totals.data(), seqstore.d_totals, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost));
    std::vector<uint32_t> counts;  // escape keys per (position, symbol)
-   // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows (the layouts before one-hot rows, for comparisons)
+   // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows; 3: one-hot rows with a row for the most numerous symbol
+   // too (the layouts of round 2, for comparisons).  The most numerous symbol of a position is derived (LAYOUT_IMPLICIT) only where
+   // the rows without a valid symbol can be counted without a plane: the missing symbol kept as runs.
+   const int tuned = g_tune_compact_index.load();
+   const int one_hot_mode = tuned == 2 ? silo_gpu_layout::ONE_HOT_OFF : (tuned == 3 || !allow_implicit ? silo_gpu_layout::ONE_HOT_ROWS : silo_gpu_layout::ONE_HOT_IMPLICIT);
    silo_gpu_layout::chooseLayouts(
-      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), g_tune_compact_index.load() != 2,
-      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, work.code_map, counts
+      totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), one_hot_mode,
+      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, work.code_map, counts,
+      g_tune_launch_cost.load() == 0 ? silo_gpu_layout::LAUNCH_COST_BYTES : (g_tune_launch_cost.load() < 0 ? 0 : static_cast<uint64_t>(g_tune_launch_cost.load()) << 10)
    );
    work.row_of.assign(positions + 1, 0);
    work.escape_first.assign(positions + 1, 0);
@@ -3314,10 +3897,11 @@ int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero
    bool any_encoded = false;
    for (uint32_t p = 0; p < positions; ++p) {
       const uint8_t* map = work.code_map.data() + static_cast<size_t>(p) * CODE_MAP_STRIDE;
-      const uint8_t bits = map[0] & 0x3Fu;
+      const uint8_t bits = map[0] & LAYOUT_ROWS_MASK;
       const bool identity = (map[0] & LAYOUT_IDENTITY) != 0;
       const bool one_hot = (map[0] & LAYOUT_ONE_HOT) != 0;
       any_encoded = any_encoded || !identity;
+      work.has_implicit = work.has_implicit || (map[0] & LAYOUT_IMPLICIT) != 0;
       work.row_of[p] = static_cast<uint32_t>(work.total_rows);
       work.total_rows += bits;
       for (uint32_t row = 0; row < bits; ++row) {  // a row without a symbol (no valid symbol at the position at all) is empty: any counter of the position
@@ -3350,7 +3934,7 @@ int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero
    }
    SILO_LAYOUT_TRY(hipMalloc(&work.d_code_map, work.code_map.size()));
    SILO_LAYOUT_TRY(hipMalloc(&work.d_cursor, n_counters * sizeof(uint32_t)));
-   SILO_LAYOUT_TRY(hipMalloc(&work.d_planes, work.plane_bytes));
+   SILO_LAYOUT_TRY(hipMalloc(&work.d_planes, std::max<size_t>(work.plane_bytes, 256)));
    SILO_LAYOUT_TRY(hipMalloc(&work.d_escapes, work.escape_bytes));
    SILO_LAYOUT_TRY(hipMalloc(&work.d_first, work.escape_first_symbol.size() * sizeof(uint32_t)));
    SILO_LAYOUT_TRY(hipMalloc(&work.d_row_of, work.row_of.size() * sizeof(uint32_t)));
@@ -3362,8 +3946,9 @@ int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero
    SILO_LAYOUT_TRY(hipMemcpy(work.d_row_target, work.row_target.data(), work.row_target.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
    SILO_LAYOUT_TRY(hipMemcpy(work.d_escape_first, work.escape_first.data(), work.escape_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
    SILO_LAYOUT_TRY(hipMemset(work.d_cursor, 0, n_counters * sizeof(uint32_t)));
-   if (zero_planes) {
-      SILO_LAYOUT_TRY(hipMemset(work.d_planes, 0, work.plane_bytes));
+   if (zero_planes) {  // the encoding pass of a two-pass build only sets bits and fills key slots: a slot it misses must not look like a key
+      SILO_LAYOUT_TRY(hipMemset(work.d_planes, 0, std::max<size_t>(work.plane_bytes, 256)));
+      SILO_LAYOUT_TRY(hipMemset(work.d_escapes, 0xFF, work.escape_bytes));
    }
    SILO_LAYOUT_TRY(hipStreamSynchronize(nullptr));  // the fills are only enqueued (null stream)
    *fits = true;
@@ -3440,6 +4025,7 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
    layout.escape_first = std::move(work.escape_first);
    layout.escape_first_symbol = std::move(work.escape_first_symbol);
    layout.runs = std::move(work.runs);
+   layout.has_implicit = work.has_implicit;
    layout.device_bytes = work.plane_bytes + work.escape_bytes * (d_escapes_sliced != nullptr ? 2 : 1) + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
                          work.total_rows * sizeof(uint32_t);
    store->device_bytes += layout.device_bytes;
@@ -3453,6 +4039,62 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
    return SILO_GPU_OK;
 }
 
+/// +1 where a run of the missing symbol starts, -1 where it ends: summed along the positions, the rows with the missing symbol.
+__global__ void k_runs_diff_all(const uint64_t* __restrict__ run_keys, const uint32_t* __restrict__ run_ends, uint32_t n_runs, uint32_t* __restrict__ diff) {
+   const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+   if (run < n_runs) {
+      atomicAdd(&diff[static_cast<uint32_t>(run_keys[run])], 1u);
+      atomicAdd(&diff[run_ends[run]], 0xFFFFFFFFu);
+   }
+}
+
+/// Does every row of the store have a symbol at every position — a valid one (the totals), the missing one (its runs) or a
+/// sparsely stored one (the sorted keys)?  Rows that never received a sequence, or an import whose bitmaps leave rows out,
+/// do not; such a store derives nothing (the derived symbol would take them in).
+int everyRowHasASymbol(const silo_gpu_store* store, const SeqStoreHost& seqstore, bool* complete) {
+   const SeqStoreDev& dev = seqstore.dev;
+   const uint32_t positions = dev.positions;
+   *complete = false;
+   if (seqstore.d_totals == nullptr || !seqstore.totals_ready || dev.kind[dev.missing_symbol] != PLANE_RUNS) {
+      return SILO_GPU_OK;
+   }
+   std::vector<uint32_t> totals(static_cast<size_t>(positions) * dev.n_scan);
+   HIP_TRY(hipMemcpy(totals.data(), seqstore.d_totals, totals.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   std::vector<uint32_t> diff(positions + 1, 0);
+   if (dev.n_missing_runs != 0) {
+      uint32_t* d_diff = nullptr;
+      HIP_TRY(hipMalloc(&d_diff, diff.size() * sizeof(uint32_t)));
+      hipError_t status = hipMemset(d_diff, 0, diff.size() * sizeof(uint32_t));
+      if (status == hipSuccess) {
+         k_runs_diff_all<<<(dev.n_missing_runs + 255) / 256, 256>>>(dev.missing_run_keys, dev.missing_run_ends, dev.n_missing_runs, d_diff);
+         status = hipGetLastError();
+      }
+      status = status != hipSuccess ? status : hipMemcpy(diff.data(), d_diff, diff.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      (void)hipFree(d_diff);
+      HIP_TRY(status);
+   }
+   std::vector<uint32_t> sparse(positions, 0);
+   for (const uint64_t key : seqstore.sparse_sorted) {
+      const uint64_t position = key >> 37;
+      if (position < positions) {
+         sparse[position] += 1;
+      }
+   }
+   uint32_t missing = 0;
+   for (uint32_t p = 0; p < positions; ++p) {
+      missing += diff[p];
+      uint64_t covered = static_cast<uint64_t>(missing) + sparse[p];
+      for (uint32_t symbol = 0; symbol < dev.n_scan; ++symbol) {
+         covered += totals[static_cast<size_t>(p) * dev.n_scan + symbol];
+      }
+      if (covered != store->sequence_count) {
+         return SILO_GPU_OK;
+      }
+   }
+   *complete = true;
+   return SILO_GPU_OK;
+}
+
 /// finalize(): derive the adaptive planes of one sequence store from its build-time planes and release those — or keep them as
 /// they are when re-encoding would not pay (short rows), is switched off (SILO_GPU_TUNE_COMPACT_INDEX < 0) or does not fit
 /// next to them.  A store built in two passes has been encoded already: only the keys remain to be put in order.
@@ -3463,6 +4105,37 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    if (dev.build_mode == BUILD_ENCODE) {
       HIP_TRY(hipDeviceSynchronize());
       dev.build_mode = BUILD_PLANES;
+      {  // every (position, symbol) must have received exactly the keys the first pass counted for it
+         SeqStoreHost::LayoutWork& work = *seqstore.work;
+         const uint32_t n_counters = positions * dev.n_scan;
+         uint32_t* d_mismatch = nullptr;
+         uint32_t mismatch = 0;
+         HIP_TRY(hipMalloc(&d_mismatch, sizeof(uint32_t)));
+         hipError_t status = hipMemset(d_mismatch, 0, sizeof(uint32_t));
+         if (status == hipSuccess && n_counters != 0) {
+            k_check_cursors<<<(n_counters + 255) / 256, 256>>>(work.d_first, work.d_cursor, n_counters, d_mismatch);
+            status = hipGetLastError();
+         }
+         status = status != hipSuccess ? status : hipMemcpy(&mismatch, d_mismatch, sizeof(uint32_t), hipMemcpyDeviceToHost);
+         (void)hipFree(d_mismatch);
+         if (status != hipSuccess || mismatch != 0) {
+            work.discard();
+            seqstore.work.reset();
+            HIP_TRY(status);
+            return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: the second pass did not bring the rows the first pass counted (escape keys of " + std::to_string(mismatch) + " (position, symbol) cells differ)");
+         }
+      }
+      if (seqstore.work->has_implicit) {
+         bool complete = false;
+         if (const int rc = everyRowHasASymbol(store, seqstore, &complete); rc != SILO_GPU_OK) {
+            return rc;
+         }
+         if (!complete) {
+            seqstore.work->discard();
+            seqstore.work.reset();
+            return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "two-pass build: some row of the store has no symbol at some position (every row has to be filled in both passes)");
+         }
+      }
       return finishLayout(store, seqstore, *seqstore.work);
    }
    if (!reencodes(store, dev)) {
@@ -3488,7 +4161,13 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
    }
    SeqStoreHost::LayoutWork work;
    bool fits = false;
-   if (const int rc = planLayout(seqstore, work, false, &fits); rc != SILO_GPU_OK) {
+   bool complete = false;  // only a store whose every row has a symbol at every position may derive one as "the rest"
+   if (dev.kind[dev.missing_symbol] == PLANE_RUNS) {
+      if (const int rc = everyRowHasASymbol(store, seqstore, &complete); rc != SILO_GPU_OK) {
+         return rc;
+      }
+   }
+   if (const int rc = planLayout(seqstore, work, false, complete, &fits); rc != SILO_GPU_OK) {
       return rc;
    }
    if (!fits) {
@@ -3615,7 +4294,7 @@ uint32_t silo_gpu_store_scan_planes(const silo_gpu_store* store, uint32_t seqsto
    }
    uint32_t most_common = seqstore.dev.n_bits;
    uint64_t most = 0;
-   for (uint32_t bits = 1; bits < 8; ++bits) {
+   for (uint32_t bits = 0; bits < 8; ++bits) {  // (0: positions whose only frequent symbol is derived)
       if (positions_with[bits] > most) {
          most = positions_with[bits];
          most_common = bits;
@@ -3637,6 +4316,20 @@ uint64_t silo_gpu_store_scan_rows(const silo_gpu_store* store, uint32_t seqstore
       return static_cast<uint64_t>(pos_end - pos_begin) * seqstore.dev.n_bits;
    }
    return seqstore.layout.row_of[pos_end] - seqstore.layout.row_of[pos_begin];
+}
+
+uint64_t silo_gpu_store_scan_runs(const silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || !store->seqstores[seqstore_id].layout.has_implicit) {
+      return 0;
+   }
+   return store->seqstores[seqstore_id].dev.n_missing_runs;
+}
+
+uint64_t silo_gpu_store_scan_sparse_keys(const silo_gpu_store* store, uint32_t seqstore_id) {
+   if (store == nullptr || seqstore_id >= store->seqstores.size() || !store->seqstores[seqstore_id].layout.has_implicit) {
+      return 0;
+   }
+   return store->seqstores[seqstore_id].sparse_sorted.size();
 }
 
 uint64_t silo_gpu_store_scan_escapes(const silo_gpu_store* store, uint32_t seqstore_id) {
@@ -3883,8 +4576,32 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
    HIP_TRY(hipSetDevice(store->device));
    auto hip_stream = static_cast<hipStream_t>(stream);
    if (seqstore.dev.kind[symbol] == PLANE_SCAN) {  // a valid mutation symbol: decode its one-hot plane from the position's code planes
-      k_decode_plane<<<(store->row_words + 255) / 256, 256, 0, hip_stream>>>(seqstore.dev, position, symbol, dst_dev);
+      k_decode_plane<<<(store->row_words + 255) / 256, 256, 0, hip_stream>>>(seqstore.dev, position, symbol, store->d_ones, dst_dev);
       HIP_TRY(hipGetLastError());
+      const uint8_t* map = seqstore.layout.code_map.empty() ? nullptr : seqstore.layout.code_map.data() + static_cast<size_t>(position) * CODE_MAP_STRIDE;
+      if (map != nullptr && (map[0] & LAYOUT_IMPLICIT) != 0 && map[IMPLICIT_SLOT] == seqstore.dev.index[symbol]) {
+         // the position's derived symbol: "no other symbol and not missing" (the reference rebuilds its deleted bitmap the same way,
+         // nucleotide_symbol_equals.cpp:158-180) — the kernel took the stored rows away; now the keys, the runs, the ambiguity codes
+         const uint32_t key_begin = seqstore.layout.escape_first[position];
+         const uint32_t key_end = seqstore.layout.escape_first[position + 1];
+         if (key_end > key_begin) {
+            k_clear_keys<<<(key_end - key_begin + 255) / 256, 256, 0, hip_stream>>>(seqstore.layout.d_escapes, key_begin, key_end, dst_dev);
+         }
+         if (seqstore.dev.n_missing_runs > 0) {
+            k_runs_clear_plane<<<(seqstore.dev.n_missing_runs + 255) / 256, 256, 0, hip_stream>>>(
+               seqstore.dev.missing_run_keys, seqstore.dev.missing_run_ends, seqstore.dev.n_missing_runs, position, dst_dev
+            );
+         }
+         const auto lo = std::lower_bound(seqstore.sparse_sorted.begin(), seqstore.sparse_sorted.end(), static_cast<uint64_t>(position) << 37);
+         const auto hi = std::lower_bound(lo, seqstore.sparse_sorted.end(), (static_cast<uint64_t>(position) + 1) << 37);
+         if (hi > lo) {
+            const uint32_t begin = static_cast<uint32_t>(lo - seqstore.sparse_sorted.begin());
+            const uint32_t end = static_cast<uint32_t>(hi - seqstore.sparse_sorted.begin());
+            k_clear_keys<<<(end - begin + 255) / 256, 256, 0, hip_stream>>>(seqstore.d_sparse, begin, end, dst_dev);
+         }
+         HIP_TRY(hipGetLastError());
+         return SILO_GPU_OK;
+      }
       if (!seqstore.layout.escape_first_symbol.empty()) {  // rows of the symbol that are listed as escape keys (it has no code here)
          const size_t counter = static_cast<size_t>(position) * seqstore.dev.n_scan + seqstore.dev.index[symbol];
          const uint32_t begin = seqstore.layout.escape_first_symbol[counter];

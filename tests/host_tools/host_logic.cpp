@@ -23,7 +23,7 @@ int copyOut(const std::string& text, char* out, size_t capacity) {
 extern "C" {
 
 /// chooseLayouts of csrc/layout_choice.h on totals[positions][n_scan] for rows of `sequences` sequences (row bytes as the
-/// device library pads them); code_map_out[positions][8], escape_count_out[positions][n_scan].
+/// device library pads them); code_map_out[positions][8], escape_count_out[positions][n_scan].  allow_one_hot: silo_gpu_layout::OneHotMode.
 void t_choose_layouts(
    const uint32_t* totals, uint32_t n_scan, uint32_t n_bits, uint32_t positions, uint64_t sequences, int allow_one_hot, uint64_t key_cost,
    uint8_t* code_map_out, uint32_t* escape_count_out
@@ -33,7 +33,7 @@ void t_choose_layouts(
    std::vector<uint8_t> code_map;
    std::vector<uint32_t> escapes;
    silo_gpu_layout::chooseLayouts(
-      counts, n_scan, n_bits, positions, row_words * 8, allow_one_hot != 0, key_cost != 0 ? key_cost : silo_gpu_layout::KEY_COST_BYTES, code_map, escapes
+      counts, n_scan, n_bits, positions, row_words * 8, allow_one_hot, key_cost != 0 ? key_cost : silo_gpu_layout::KEY_COST_BYTES, code_map, escapes
    );
    std::memcpy(code_map_out, code_map.data(), code_map.size());
    std::memcpy(escape_count_out, escapes.data(), escapes.size() * sizeof(uint32_t));

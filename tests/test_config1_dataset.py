@@ -120,8 +120,9 @@ def test_real_alignment_is_one_symbol_at_almost_every_position():
 @pytest.mark.gpu
 def test_real_alignment_is_reencoded_into_one_hot_rows(built):
     """The same on the device: the 1 000 real sequences 70 times over (70 000 rows: long enough rows for finalize to
-    re-encode) end up in ONE plane row at almost every position — and, with the one-hot rows switched off
-    (SILO_GPU_TUNE_COMPACT_INDEX 2), in 2 code planes — and answer with 70 times the known counts."""
+    re-encode) end up with NO plane row at almost every position (the most numerous symbol is derived) — in ONE with
+    SILO_GPU_TUNE_COMPACT_INDEX 3 (a row for that symbol too), in 2 code planes with the one-hot rows switched off (2) — and
+    answer with 70 times the known counts."""
     from silo_amd import binding
     from silo_amd.engine import Engine
 
@@ -131,7 +132,7 @@ def test_real_alignment_is_reencoded_into_one_hot_rows(built):
     lib = binding.load_library()
     n, positions, escapes = layout_statistics(sequences)
     _, _, beside_first, _ = one_hot_statistics(sequences)
-    for knob in (0, 2):
+    for knob in (0, 3, 2):  # the most numerous symbol derived / a one-hot row for it too / code planes only
         with Engine(doc) as engine:
             part = engine.add_partition(copies * len(sequences))
             for k in range(copies):
@@ -146,6 +147,9 @@ def test_real_alignment_is_reencoded_into_one_hot_rows(built):
             keys = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
             print(f"knob {knob}: plane rows per position {rows / positions:.4f}, escape keys {keys} = {keys / (copies * n * positions):.2e} of the cells")
             if knob == 0:
+                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 0 and rows < 0.08 * positions
+                assert keys <= copies * int(beside_first.sum())
+            elif knob == 3:
                 assert lib.silo_gpu_store_scan_planes(store.handle, 0) == 1 and rows < 1.08 * positions
                 assert keys <= copies * int(beside_first.sum())
             else:

@@ -240,7 +240,8 @@ def test_fasta_reader_vectors(host_logic):
 
 
 # ---- the layout of the adaptive planes (csrc/layout_choice.h: host code of the device library) -----------------------------
-def choose_layouts(host_logic, totals, n_bits, sequences, one_hot=True, key_cost=0):
+def choose_layouts(host_logic, totals, n_bits, sequences, one_hot=1, key_cost=0):
+    """one_hot: 0 = code planes only, 1 = one-hot rows (a row for every stored symbol), 2 = the most numerous symbol derived."""
     import ctypes
 
     import numpy as np
@@ -253,14 +254,15 @@ def choose_layouts(host_logic, totals, n_bits, sequences, one_hot=True, key_cost
                                             ctypes.c_void_p, ctypes.c_void_p]
     host_logic.t_choose_layouts.restype = None
     host_logic.t_choose_layouts(totals.ctypes.data, n_scan, n_bits, positions, sequences, int(one_hot), key_cost, code_map.ctypes.data, escapes.ctypes.data)
-    rows = code_map[:, 0] & 0x3F
-    kind = np.where(code_map[:, 0] & 0x80, "identity", np.where(code_map[:, 0] & 0x40, "one-hot", "codes"))
+    rows = code_map[:, 0] & 0x0F
+    kind = np.where(code_map[:, 0] & 0x80, "identity", np.where(code_map[:, 0] & 0x20, "derived", np.where(code_map[:, 0] & 0x40, "one-hot", "codes")))
     return rows, kind, code_map, escapes
 
 
 def test_layout_choice_follows_the_cost_model(host_logic):
     """One row where one symbol has nearly every row, two where a second symbol is frequent, 2 code planes where three are
-    and the neighbours agree, identity planes where nothing pays; every row a position does not store is an escape key."""
+    over a stretch long enough to pay for a launch of its own, identity planes where nothing else pays; every row a position
+    does not store is an escape key."""
     import numpy as np
 
     n = 10_000_000
@@ -268,26 +270,53 @@ def test_layout_choice_follows_the_cost_model(host_logic):
     two = [n // 2, n // 2 - 3000, 1500, 1000, 500]     # two frequent symbols
     three = [n // 3, n // 3, n // 3 - 600, 400, 200]   # three
     flat = [n // 5] * 5                                # all five
-    totals = np.array([settled] * 40 + [two] + [settled] * 40 + [three] * 30 + [flat] * 3 + [settled] * 20, dtype=np.uint32)
+    totals = np.array([settled] * 40 + [two] + [settled] * 40 + [three] * 300 + [flat] * 12 + [settled] * 20, dtype=np.uint32)
     rows, kind, code_map, escapes = choose_layouts(host_logic, totals, 3, n)
     assert list(kind[:81]) == ["one-hot"] * 81 and list(rows[:40]) == [1] * 40 and rows[40] == 2 and list(rows[41:81]) == [1] * 40
-    assert list(kind[81:111]) == ["codes"] * 30 and list(rows[81:111]) == [2] * 30       # a run of its own: cheaper than 3 rows each
-    assert list(kind[111:114]) == ["identity"] * 3 and list(rows[111:114]) == [3] * 3
-    assert list(kind[114:]) == ["one-hot"] * 20
+    assert list(kind[81:381]) == ["codes"] * 300 and list(rows[81:381]) == [2] * 300     # a run of its own: cheaper than 3 rows each, launch included
+    assert list(kind[381:393]) == ["identity"] * 12 and list(rows[381:393]) == [3] * 12
+    assert list(kind[393:]) == ["one-hot"] * 20
     assert code_map[0, 1] == 0 and code_map[40, 1] == 0 and code_map[40, 2] == 1 and list(code_map[90, 1:4]) == [0, 1, 2]
     assert list(escapes[0]) == [0, 900, 600, 300, 200] and list(escapes[40]) == [0, 0, 1500, 1000, 500]
-    assert list(escapes[90]) == [0, 0, 0, 400, 200] and not escapes[111:114].any()
-    # a single position with three frequent symbols between settled ones: not worth a run of its own (2 x row bytes each way)
-    totals = np.array([settled] * 10 + [three] + [settled] * 10, dtype=np.uint32)
+    assert list(escapes[90]) == [0, 0, 0, 400, 200] and not escapes[381:393].any()
+    # a few positions with three frequent symbols between settled ones: not worth a launch of their own (192 MB of plane bytes)
+    totals = np.array([settled] * 10 + [three] * 30 + [settled] * 10, dtype=np.uint32)
     rows, kind, _, _ = choose_layouts(host_logic, totals, 3, n)
-    assert list(kind) == ["one-hot"] * 21 and rows[10] == 3
+    assert list(kind) == ["one-hot"] * 50 and list(rows[10:40]) == [3] * 30
     # without one-hot rows (SILO_GPU_TUNE_COMPACT_INDEX 2): two code planes everywhere
-    rows, kind, _, escapes = choose_layouts(host_logic, totals, 3, n, one_hot=False)
-    assert list(kind) == ["codes"] * 21 and list(rows) == [2] * 21 and list(escapes[0]) == [0, 0, 0, 300, 200]
+    rows, kind, _, escapes = choose_layouts(host_logic, totals, 3, n, one_hot=0)
+    assert list(kind) == ["codes"] * 50 and list(rows) == [2] * 50 and list(escapes[0]) == [0, 0, 0, 300, 200]
     # the key cost moves the boundary between one row and two: 40 000 rows of a second symbol are keys at 16 B, a row at 40 B
     second = [n - 41000, 40000, 500, 300, 200]
     assert choose_layouts(host_logic, np.array([second] * 8, dtype=np.uint32), 3, n)[0].tolist() == [1] * 8
     assert choose_layouts(host_logic, np.array([second] * 8, dtype=np.uint32), 3, n, key_cost=40)[0].tolist() == [2] * 8
+
+
+def test_layout_choice_derives_the_most_numerous_symbol(host_logic):
+    """Mode 2 (a store that keeps its missing symbol as runs): the most numerous symbol of a one-hot position gets no row and
+    no keys — code_map[p][7] names it — and the rows are those of the symbols behind it: none at a settled position, one
+    where a second symbol is frequent, two where three are; the escape keys are the symbols with neither."""
+    import numpy as np
+
+    n = 10_000_000
+    settled = [n - 2000, 900, 600, 300, 200]
+    two = [3000, n // 2, n // 2 - 3000 - 2500, 1500, 1000]   # the second and third symbol are the frequent ones
+    three = [n // 3, n // 3, n // 3 - 600, 400, 200]
+    empty = [0, 0, 0, 0, 0]                                  # no row has a valid symbol here (all missing)
+    totals = np.array([settled] * 5 + [two] + [three] * 2 + [empty] + [settled] * 5, dtype=np.uint32)
+    rows, kind, code_map, escapes = choose_layouts(host_logic, totals, 3, n, one_hot=2)
+    assert list(kind) == ["derived"] * 14
+    assert list(rows) == [0] * 5 + [1] + [2, 2] + [0] + [0] * 5
+    assert code_map[0, 7] == 0 and list(escapes[0]) == [0, 900, 600, 300, 200]
+    assert code_map[5, 7] == 1 and code_map[5, 1] == 2 and list(escapes[5]) == [3000, 0, 0, 1500, 1000]
+    assert code_map[6, 7] == 0 and list(code_map[6, 1:3]) == [1, 2] and list(escapes[6]) == [0, 0, 0, 400, 200]
+    assert code_map[8, 7] == 0 and not escapes[8].any()     # derived count there: |filter| - rows without a valid symbol = 0
+    # amino acids (5 identity planes): a saturated stretch long enough keeps its identity planes, the rest derives
+    aa_settled = [n - 5000] + [250] * 20 + [0]
+    aa_flat = [n // 22] * 22
+    totals = np.array([aa_settled] * 20 + [aa_flat] * 40 + [aa_settled] * 20, dtype=np.uint32)
+    rows, kind, _, _ = choose_layouts(host_logic, totals, 5, n, one_hot=2)
+    assert list(kind[:20]) == ["derived"] * 20 and list(rows[:20]) == [0] * 20 and list(kind[20:60]) == ["identity"] * 40 and list(rows[20:60]) == [5] * 40
 
 
 def test_layout_choice_on_the_real_alignment(host_logic):
@@ -301,6 +330,9 @@ def test_layout_choice_on_the_real_alignment(host_logic):
     rows_ = [s for s in sequences if s is not None]
     matrix = np.frombuffer("".join(rows_).encode(), dtype=np.uint8).reshape(len(rows_), -1)
     totals = np.stack([(matrix == ord(c)).sum(axis=0) for c in "-ACGT"], axis=1).astype(np.uint32) * 10_000
+    derived_rows, derived_kind, _, derived_escapes = choose_layouts(host_logic, totals, 3, 10_000_000, one_hot=2)
+    print(f"with the most numerous symbol derived: plane rows per position {derived_rows.sum() / len(derived_rows):.4f}, escape keys {int(derived_escapes.sum()) / 1e6:.1f} M")
+    assert derived_rows.sum() < 0.06 * len(derived_rows) and np.mean(derived_kind == "derived") > 0.999
     rows, kind, _, escapes = choose_layouts(host_logic, totals, 3, 10_000_000)
     per_position = rows.sum() / len(rows)
     keys = int(escapes.sum())

@@ -292,9 +292,10 @@ def settle_positions(rng, sym, columns, alphabet, second=0.0002):
 
 @pytest.mark.parametrize("n,alphabet", [(140000, "nuc"), (70000, "aa"), (300001, "nuc"), (1200003, "nuc")])  # the last: 10 slices of escape keys
 def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
-    """finalize() re-encodes alignment-like data per position into one-hot rows (1-3 symbols) or 2 code planes (3 symbols)
-    + escape keys, and releases the build-time planes; knob 2 leaves the one-hot rows out, with the re-encoding switched off
-    the store keeps its 3 / 5 identity planes.  All three stores answer every scan (single, batched, sub-ranges, sparse
+    """finalize() re-encodes alignment-like data per position into one-hot rows (0-3 of them: the most numerous symbol is
+    derived, knob 0; 1-3 with a row for it too, knob 3) or 2 code planes (3 symbols) + escape keys, and releases the build-time
+    planes; knob 2 leaves the one-hot rows out, with the re-encoding switched off the store keeps its 3 / 5 identity planes.
+    All four stores answer every scan (single, batched, sub-ranges, sparse
     filters, several ranges), every filter leaf and FastaAligned like the naive oracle."""
     rng = np.random.default_rng(n + 17)
     positions = 29
@@ -315,15 +316,20 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
     # a clustered filter (rows in lineage or date order): whole column tiles and key slices without a selected row are skipped
     masks[3] = (np.arange(n) >= int(n * 0.6)) & (rng.random(n) < 0.7)
     sizes = {}
-    for knob in (0, 2, -1):  # re-encoded with and without one-hot rows, then the identity planes kept
+    # re-encoded with the most numerous symbol of a position derived (0), with a one-hot row for it too (3), without one-hot rows
+    # (2), then the identity planes kept (-1); the charge per kind of launch is off (knob 9: these rows are short, with it a
+    # store would never mix layouts)
+    for knob in (0, 3, 2, -1):
         with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy()), dict(name="b", alphabet=alphabet, reference=sym2[0].copy())]) as store:
             store.tune(4, knob)
+            store.tune(9, -1)
             try:
                 store.append_sequences(0, 0, chars[sym])
                 store.append_sequences(1, 0, chars[sym2])
                 store.finalize()
             finally:
                 store.tune(4, 0)
+                store.tune(9, 0)
             sizes[knob] = store.device_bytes
             scan_symbols = list(store.scan_symbols[0])
             full_planes = 3 if alphabet == "nuc" else 5
@@ -336,7 +342,13 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
                 with pytest.raises(Exception):  # the build-time planes are gone
                     store.append_sequences(0, 0, chars[sym[:1]])
             elif knob == 0:
-                assert store.scan_rows(1, 0, 11) == 11 and store.scan_planes(1) == 1
+                assert store.scan_rows(1, 0, 11) == 0 and store.scan_planes(1) == 0 and store.scan_runs(1) > 0  # positions without a row
+                assert store.scan_rows(0, 3, 10) == 0 and store.scan_rows(0, 19, 27) == 1 and store.scan_rows(0, 22, 23) == 1
+                assert store.scan_rows(0, 13, 14) > 1 and store.scan_rows(0, 12, 13) >= 1 and 3 <= store.scan_rows(0, 0, 3) <= 6
+                assert 0 < store.scan_escapes(0) <= n * positions // 320
+                assert store.scan_escapes(1) > store.scan_escapes(0) // 29
+            elif knob == 3:
+                assert store.scan_rows(1, 0, 11) == 11 and store.scan_planes(1) == 1 and store.scan_runs(1) == 0
                 assert store.scan_rows(0, 3, 10) == 7 and store.scan_rows(0, 19, 27) == 9 and store.scan_rows(0, 22, 23) == 2
                 assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2 and store.scan_rows(0, 0, 3) == 6
                 assert 0 < store.scan_escapes(0) <= n * positions // 320
@@ -385,7 +397,7 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
             # FastaAligned reads the same planes (and the keys)
             picked = np.concatenate([rng.choice(n, size=40, replace=False), np.nonzero(~np.isin(sym[:, 13], scan_symbols))[0][:5]]).astype(np.uint32)
             assert np.array_equal(store.reconstruct_sequences(0, picked), chars[sym[picked]])
-    assert sizes[0] < sizes[2] < 0.85 * sizes[-1]  # <= 2 planes + the missing-symbol plane instead of 3 / 5 + 1
+    assert sizes[0] < sizes[3] < sizes[2] < 0.85 * sizes[-1]  # <= 2 planes + the missing-symbol plane instead of 3 / 5 + 1
 
 
 def test_scan_timings_cover_every_plane_row(built):
@@ -400,7 +412,13 @@ def test_scan_timings_cover_every_plane_row(built):
     settle_positions(rng, sym, range(3, 17), "nuc")
     with make_store(n, [dict(name="a", alphabet="nuc", reference=sym[0].copy())]) as store:
         store.append_sequences(0, 0, NUC_CHARS[sym])
-        store.finalize()
+        store.tune(4, 3)   # a one-hot row for the most numerous symbol too, and
+        store.tune(9, -1)  # no charge per kind of launch: this small store is to mix one-hot rows and code planes
+        try:
+            store.finalize()
+        finally:
+            store.tune(4, 0)
+            store.tune(9, 0)
         mask = rng.random(n) < 0.4
         ptr = store.bitset_alloc()
         store.bitset_upload(ptr, dense.pack_bits(mask))
@@ -855,6 +873,7 @@ def test_missing_symbol_becomes_runs(built, n, alphabet, positions, run_share):
     for knob in (0, -1, "two passes"):  # runs out of the plane at finalize; the plane kept; runs written while the rows stream in
         with make_store(n, [dict(name="a", alphabet=alphabet, reference=sym[0].copy())]) as store:
             store.tune(8, knob if knob == -1 else 0)
+            store.tune(9, -1)  # (no charge per kind of launch: with it these short, uniformly random rows would all become one-hot rows + keys)
             try:
                 if knob == "two passes":
                     store.build_pass(0, 1)
@@ -866,6 +885,7 @@ def test_missing_symbol_becomes_runs(built, n, alphabet, positions, run_share):
                 store.finalize()
             finally:
                 store.tune(8, 0)
+                store.tune(9, 0)
             if knob != "two passes" or n >= 65536:
                 assert (store.plane(0, 0, missing) is None) == (knob != -1)  # no resident plane once it has become runs
             for position in sorted(set(range(0, positions, 7)) | {1, positions - 2, positions - 1}):

@@ -155,7 +155,7 @@ def test_compact_scan_index_option(built):
             with bench.build_engine(200_000, 0, 1, None, 0)[0] as engine:
                 store = engine.partition_store(0)
                 sizes.append(store.device_bytes)
-                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (1 if enabled else 3)
+                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (0 if enabled else 3)
                 answers.append(engine.execute_text(query))
     finally:
         lib.silo_gpu_tune(4, 0)
@@ -185,4 +185,6 @@ def test_two_pass_build_option_gives_the_same_database(built):
             sizes.append(engine.partition_store(0).device_bytes)
             answers.append([engine.execute_text(q.encode() if isinstance(q, str) else q) for q in queries])
     assert answers[0] == answers[1] and all(status == 200 for status, _ in answers[0][:3])
-    assert abs(sizes[0] - sizes[1]) < 0.01 * sizes[0]  # (a run of the missing symbol that crosses a stretch of the build kernels is listed in pieces)
+    # (a run of the missing symbol that crosses a stretch of the build kernels is listed in pieces: a few more runs, and the runs
+    # are a visible share of a store that derives the most numerous symbol of its positions)
+    assert abs(sizes[0] - sizes[1]) < 0.03 * sizes[0]
