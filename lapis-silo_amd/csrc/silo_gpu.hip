@@ -1090,8 +1090,6 @@ constexpr uint32_t ESCAPE_SLICE_WORDS32 = (1u << ESCAPE_SLICE_SHIFT) / 32u;
 constexpr uint32_t ESCAPE_SLICE_BITS = 9;                      // sequence bits that number the slices
 constexpr uint32_t ESCAPE_MAX_SLICES = 1u << ESCAPE_SLICE_BITS;  // 67 M rows
 constexpr uint32_t ESCAPE_SLICE_THREADS = 1024;
-constexpr uint32_t ESCAPE_KEYS_IN_FLIGHT = 16;                 // per thread: the key loads of a chunk are all issued before the first is used
-constexpr uint32_t ESCAPE_CHUNK_KEYS = ESCAPE_SLICE_THREADS * ESCAPE_KEYS_IN_FLIGHT;
 constexpr uint32_t ESCAPE_MAX_RANGES = 16;
 /// One launch for up to ESCAPE_MAX_RANGES position ranges (the 12 genes of an AminoAcidMutations query): grid =
 /// (blocks per slice, slice x range, filter).  Block j of a (range, slice) takes the chunks j, j + gridDim.x, ... of that
@@ -1101,6 +1099,7 @@ struct EscapeSliceArgs {
    uint32_t row_words;
    uint32_t n_slices;
    uint32_t out_symbols;
+   uint32_t block_keys;  // keys per block (even)
    struct Range {
       const uint64_t* keys;          // slice-major keys of the store
       const uint32_t* slice_first;   // [n_slices][positions + 1]
@@ -1111,21 +1110,64 @@ struct EscapeSliceArgs {
    } ranges[ESCAPE_MAX_RANGES];
 };
 
+/// Workgroup barrier for data exchanged through LDS only: waits for the wave's LDS operations, NOT for its outstanding global
+/// loads — __syncthreads() is also a fence and drains vmcnt(0), which would stall a block on the loads it has prefetched for
+/// its next step at every barrier.
+__device__ __forceinline__ void ldsBarrier() {
+   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /// FILTERS = filters a block serves with ONE pass over its keys (1, 2, 4 or 8: a batch of 8 filters keeps 8 x 16 KiB of filter
 /// slices in LDS and reads every key once, not once per filter); blockIdx.z = first filter / FILTERS.
+///
+/// Counting.  The keys of a slice are sorted by (position, symbol), so the counters a chunk of keys adds to lie in a narrow
+/// window behind the chunk's first key: the block counts into a window of LDS counters per filter (one LDS atomic per selected
+/// key, no wave-level bookkeeping) and then adds the window to the table with CONTIGUOUS atomics — 64 consecutive counters per
+/// wave instruction, the shape the memory side takes at full rate; a lane per scattered counter, as the first version did, is
+/// an order of magnitude slower per add (MI355X guide, "Global float atomics": access shape).  A key past the window (sparse
+/// stretches of keys) goes to the table directly.
 template <int FILTERS>
-__global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
-   extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32]
+constexpr uint32_t escapeKeysInFlight() {  // per thread: fewer for a batch, whose windows are narrower
+   return FILTERS >= 8 ? 4u : (FILTERS >= 4 ? 8u : 16u);
+}
+constexpr uint32_t ESCAPE_CHUNKS_PER_BLOCK = 4;  // at most: consecutive chunks of IN_FLIGHT x 1024 keys a block counts into ONE window
+template <int FILTERS>
+constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them for 1-4 filters (two blocks per CU), 28 KiB for 8 (beside 128 KiB of filter slices)
+   return FILTERS >= 8 ? 896u : 12288u / FILTERS;
+}
+template <int FILTERS>
+constexpr uint32_t escapeLdsBytes() {
+   return FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) * static_cast<uint32_t>(sizeof(uint32_t));
+}
+
+/// grid = (blocks per slice, slice x range, filters / FILTERS).  Block j of a (range, slice) takes the keys [j, j + 1) x
+/// ESCAPE_CHUNKS_PER_BLOCK chunks of that slice's keys of the scanned positions (an even first index: 16-byte loads of two
+/// keys per lane — 8-byte loads stream at 0.54-0.70 of their rate); where the slice's keys begin and end is read from the
+/// store's slice index on the device.  No barrier between a block's chunks: its waves run on by themselves, one waits for
+/// its keys while another counts; two blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
+template <int FILTERS, bool AGGREGATE = true>
+__global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
+   constexpr uint32_t IN_FLIGHT = escapeKeysInFlight<FILTERS>();
+   constexpr uint32_t CHUNK_KEYS = ESCAPE_SLICE_THREADS * IN_FLIGHT;
+   constexpr uint32_t WINDOW = escapeWindow<FILTERS>();
+   const uint32_t BLOCK_KEYS = args.block_keys;  // even; chosen by the launcher so that a block's keys mostly fall into its window
+   extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32], then the counters [FILTERS][WINDOW]
+   uint32_t* s_count = s_filter + FILTERS * ESCAPE_SLICE_WORDS32;
    const uint32_t first_filter = blockIdx.z * FILTERS;
-   const uint32_t lane = threadIdx.x & 63u;
    const uint32_t slice = blockIdx.y % args.n_slices;
    const EscapeSliceArgs::Range& range = args.ranges[blockIdx.y / args.n_slices];
    const uint32_t* first = range.slice_first + static_cast<size_t>(slice) * (range.positions + 1u);
    const uint32_t key_begin = first[range.pos_begin];
    const uint32_t key_end = first[range.pos_end];
-   if (key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS >= key_end) {
-      return;  // (uniform) no chunk for this block
+   const uint32_t block_begin = (key_begin & ~1u) + blockIdx.x * BLOCK_KEYS;
+   if (block_begin >= key_end) {
+      return;  // (uniform) no keys for this block
    }
+   const uint32_t block_end = min(block_begin + BLOCK_KEYS, key_end);
+   // the two keys that bound the block's window of counters (slice-major keys are recoded for this kernel: counter of the store
+   // << 32 | sequence, counter = position * symbols + symbol); the loads are under way while the filter slices come in
+   const uint64_t first_key = range.keys[max(block_begin, key_begin)];
+   const uint64_t last_key = range.keys[block_end - 1u];
    uint64_t any_bit = 0;
 #pragma unroll
    for (int f = 0; f < FILTERS; ++f) {  // this slice of every filter: 16 bytes per thread, zeros past the end of the row (and for a filter past the last)
@@ -1141,40 +1183,100 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS) void k_scan_escapes_sliced(co
          any_bit |= v.x | v.y;
       }
    }
+   for (uint32_t j = threadIdx.x; j < FILTERS * WINDOW; j += ESCAPE_SLICE_THREADS) {
+      s_count[j] = 0;
+   }
    if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
       return;  // no row of this slice is selected: none of its keys counts
    }
    const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
-   for (uint32_t base = key_begin + blockIdx.x * ESCAPE_CHUNK_KEYS; base < key_end; base += gridDim.x * ESCAPE_CHUNK_KEYS) {  // uniform per block
-      uint64_t key[ESCAPE_KEYS_IN_FLIGHT];
+   const uint32_t range_first = range.pos_begin * args.out_symbols;
+   // the window: the counters from the position of the block's first key on; what it reaches of the block's last key's position
+   const uint32_t window_first = static_cast<uint32_t>(first_key >> 32) / args.out_symbols * args.out_symbols - range_first;
+   const uint32_t window_used = min(WINDOW, (static_cast<uint32_t>(last_key >> 32) / args.out_symbols + 1u) * args.out_symbols - range_first - window_first);
+   for (uint32_t base = block_begin; base < block_end; base += CHUNK_KEYS) {  // uniform per block
+      uint64_t key[IN_FLIGHT];
 #pragma unroll
-      for (uint32_t k = 0; k < ESCAPE_KEYS_IN_FLIGHT; ++k) {
-         const uint32_t i = base + k * ESCAPE_SLICE_THREADS + threadIdx.x;
-         key[k] = i < key_end ? __builtin_nontemporal_load(range.keys + i) : ~0ull;
+      for (uint32_t k = 0; k < IN_FLIGHT / 2u; ++k) {
+         const uint32_t i = base + (k * ESCAPE_SLICE_THREADS + threadIdx.x) * 2u;
+         ulonglong2 pair = make_ulonglong2(~0ull, ~0ull);
+         if (i < block_end) {
+            pair = loadPlane16<true>(range.keys + i);  // (the key before the slice's first and the key behind its last, read along, are masked out)
+         }
+         key[2 * k] = i >= key_begin && i < block_end ? pair.x : ~0ull;
+         key[2 * k + 1] = i + 1u < block_end ? pair.y : ~0ull;
       }
 #pragma unroll
-      for (uint32_t k = 0; k < ESCAPE_KEYS_IN_FLIGHT; ++k) {
-         const bool valid = key[k] != ~0ull;  // (no key is all ones: the symbol field holds at most 21)
+      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
+         const bool valid = key[k] != ~0ull;  // (no key is all ones: a store has fewer than 2^32 - 1 counters)
          const uint32_t local = valid ? static_cast<uint32_t>(key[k]) - slice_first_row : 0u;
-         // keys of one (position, symbol) sit together: one atomic per distinct counter and wave, not per key
-         const uint32_t counter = (static_cast<uint32_t>(key[k] >> 37) - range.pos_begin) * args.out_symbols + (static_cast<uint32_t>(key[k] >> 32) & 31u);
+         const uint32_t counter = valid ? static_cast<uint32_t>(key[k] >> 32) - range_first : 0xFFFFFFFFu;
+         const uint32_t in_window = counter - window_first;
+         // The lanes of a wave hold consecutive keys of the sorted list: the keys of one counter sit side by side, and 64 LDS atomics
+         // on ONE address take 64 LDS cycles (identical addresses do not combine for atomics).  So a stretch of lanes with one
+         // counter adds its selected keys with TWO atomics: with `below` = the selected lanes below a lane (v_mbcnt of the ballot:
+         // two instructions), the stretch's first lane adds -below, its last lane +below + its own key; the sum is the number of
+         // selected keys in between (uint32 wrap-around; the window is read after the barrier).
+         const uint32_t previous = __builtin_amdgcn_update_dpp(0xFFFFFFFEu, counter, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0 keeps the old value)
+         const uint32_t next = __builtin_amdgcn_update_dpp(0xFFFFFFFEu, counter, 0x130, 0xf, 0xf, false);      // wave_shl:1 (lane 63 keeps the old value)
+         const bool head = valid && counter != previous;
+         const bool tail = valid && counter != next;
 #pragma unroll
          for (int f = 0; f < FILTERS; ++f) {
-            bool pending = valid && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (local >> 5)] >> (local & 31u)) & 1u) != 0;
-            uint32_t* __restrict__ counts = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
-            for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
-               const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
-               const uint32_t leader_counter = __shfl(counter, leader);
-               const uint64_t same = __ballot(pending && counter == leader_counter);
-               if (lane == leader) {
-                  atomicAdd(&counts[leader_counter], static_cast<uint32_t>(__popcll(same)));
+            const bool is_selected = valid && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (local >> 5)] >> (local & 31u)) & 1u) != 0;
+            uint32_t* __restrict__ window = s_count + f * WINDOW;
+            uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
+            if constexpr (!AGGREGATE) {  // (measurement: one LDS atomic per selected key)
+               if (is_selected && in_window < WINDOW) {
+                  atomicAdd(&window[in_window], 1u);
+               } else if (is_selected) {
+                  atomicAdd(&table[counter], 1u);
                }
-               if (counter == leader_counter) {
-                  pending = false;
+               continue;
+            }
+            const uint64_t selected = __ballot(is_selected);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(selected >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(selected), 0u));
+            const uint32_t upto = below + (is_selected ? 1u : 0u);
+            if (in_window < WINDOW) {
+               if (head && below != 0) {
+                  atomicAdd(&window[in_window], 0u - below);
+               }
+               if (tail && upto != 0) {
+                  atomicAdd(&window[in_window], upto);
+               }
+            } else if (valid) {  // a key past the window: straight to the table
+               if (head && below != 0) {
+                  atomicAdd(&table[counter], 0u - below);
+               }
+               if (tail && upto != 0) {
+                  atomicAdd(&table[counter], upto);
                }
             }
          }
       }
+   }
+   // the window goes to the table: contiguous atomics, 64 consecutive counters per wave instruction
+   ldsBarrier();
+#pragma unroll
+   for (int f = 0; f < FILTERS; ++f) {
+      uint32_t* __restrict__ counts = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
+      for (uint32_t j = threadIdx.x; j < window_used; j += ESCAPE_SLICE_THREADS) {
+         const uint32_t value = s_count[f * WINDOW + j];
+         if (value != 0) {
+            atomicAdd(&counts[j], value);
+         }
+      }
+   }
+}
+
+/// The slice-major keys as k_scan_escapes_sliced reads them: (position * n_scan + symbol) << 32 | sequence — the counter a key
+/// adds to is a subtraction away, no shifts, no multiplication per key (the kernel is bound by its integer work per key).
+__global__ void k_recode_sliced_keys(uint64_t* __restrict__ keys, uint32_t n_keys, uint32_t n_scan) {
+   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n_keys) {
+      const uint64_t key = keys[i];
+      const uint32_t counter = static_cast<uint32_t>(key >> 37) * n_scan + (static_cast<uint32_t>(key >> 32) & 31u);
+      keys[i] = (static_cast<uint64_t>(counter) << 32) | (key & 0xFFFFFFFFull);
    }
 }
 
@@ -1225,6 +1327,7 @@ __global__ __launch_bounds__(256) void k_slice_index(
 constexpr uint32_t DERIVED_MAX_RANGES = 16;
 constexpr uint32_t DERIVED_THREADS = 1024;
 constexpr uint32_t SPARSE_KEYS_PER_THREAD = 4;
+constexpr uint32_t RUNS_IN_FLIGHT = 4;        // runs per thread whose loads are in flight together (k_scan_missing_runs)
 
 /// A range of a scan with derived symbols.  Its private tables: per filter `stride` words of scratch — counts[n][n_scan], then
 /// diff[n + 1] (selected rows entering / leaving a run of the missing symbol at each position), then ambiguous[n].
@@ -1253,7 +1356,7 @@ struct DerivedArgs {
    DerivedRange ranges[DERIVED_MAX_RANGES];
 };
 
-/// grid = (1, slice of 2^17 sequences x range, filter).  The block keeps its slice of the filter in LDS (16 KiB) and, where it
+/// grid = (blocks per slice, slice of 2^17 sequences x range, filter).  The block keeps its slice of the filter in LDS (16 KiB) and, where it
 /// fits (LDS_DIFF), the diff of the whole range as well (<= ~140 KiB: 35 000 positions), so that the adds of a slice's runs —
 /// two per selected run — are LDS atomics and only the non-zero entries go to memory (256 contiguous bytes per wave instruction).
 template <bool LDS_DIFF>
@@ -1268,8 +1371,8 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
    }
    const uint32_t run_begin = range.run_slice_first[slice];
    const uint32_t run_end = range.run_slice_first[slice + 1];
-   if (run_begin == run_end) {
-      return;  // (uniform)
+   if (run_begin + blockIdx.x * (DERIVED_THREADS * RUNS_IN_FLIGHT) >= run_end) {
+      return;  // (uniform) no chunk of runs for this block
    }
    uint64_t any_bit = 0;
    {
@@ -1296,21 +1399,30 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
    uint32_t* __restrict__ diff = range.scratch + static_cast<size_t>(q) * range.stride + static_cast<size_t>(n) * range.n_scan;
    const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
    const uint32_t pos_end = range.pos_begin + n;
-   for (uint32_t i = run_begin + threadIdx.x; i < run_end; i += DERIVED_THREADS) {
-      const uint64_t key = range.run_keys[i];
-      const uint32_t local = static_cast<uint32_t>(key >> 32) - slice_first_row;
-      if (((s_runs[local >> 5] >> (local & 31u)) & 1u) == 0) {
-         continue;
+   // the slice's runs are dealt to the gridDim.x blocks of the slice in chunks of RUNS_IN_FLIGHT x 1024 (loads of a chunk in flight together)
+   for (uint32_t base = run_begin + blockIdx.x * (DERIVED_THREADS * RUNS_IN_FLIGHT); base < run_end; base += gridDim.x * (DERIVED_THREADS * RUNS_IN_FLIGHT)) {
+      uint64_t key[RUNS_IN_FLIGHT];
+      uint32_t run_last[RUNS_IN_FLIGHT];
+#pragma unroll
+      for (uint32_t k = 0; k < RUNS_IN_FLIGHT; ++k) {
+         const uint32_t i = base + k * DERIVED_THREADS + threadIdx.x;
+         key[k] = i < run_end ? range.run_keys[i] : 0;
+         run_last[k] = i < run_end ? range.run_ends[i] : 0;  // (an empty run: start >= end below)
       }
-      const uint32_t start = max(static_cast<uint32_t>(key), range.pos_begin);
-      const uint32_t end = min(range.run_ends[i], pos_end);
-      if (start < end) {
-         if constexpr (LDS_DIFF) {
-            atomicAdd(&s_diff[start - range.pos_begin], 1u);
-            atomicAdd(&s_diff[end - range.pos_begin], 0xFFFFFFFFu);
-         } else {
-            atomicAdd(&diff[start - range.pos_begin], 1u);
-            atomicAdd(&diff[end - range.pos_begin], 0xFFFFFFFFu);
+#pragma unroll
+      for (uint32_t k = 0; k < RUNS_IN_FLIGHT; ++k) {
+         const uint32_t local = (static_cast<uint32_t>(key[k] >> 32) - slice_first_row) & ((1u << ESCAPE_SLICE_SHIFT) - 1u);
+         const bool selected = ((s_runs[local >> 5] >> (local & 31u)) & 1u) != 0;
+         const uint32_t start = max(static_cast<uint32_t>(key[k]), range.pos_begin);
+         const uint32_t end = min(run_last[k], pos_end);
+         if (selected && start < end) {
+            if constexpr (LDS_DIFF) {
+               atomicAdd(&s_diff[start - range.pos_begin], 1u);
+               atomicAdd(&s_diff[end - range.pos_begin], 0xFFFFFFFFu);
+            } else {
+               atomicAdd(&diff[start - range.pos_begin], 1u);
+               atomicAdd(&diff[end - range.pos_begin], 0xFFFFFFFFu);
+            }
          }
       }
    }
@@ -3495,31 +3607,47 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
    // the ranges whose stores have slice-major keys go ESCAPE_MAX_RANGES at a time into one launch of k_scan_escapes_sliced
    EscapeSliceArgs sliced{};
    uint32_t n_sliced = 0;
-   uint32_t most_chunks = 0;  // of one (range, slice)
+   uint32_t most_keys = 0;  // of one (range, slice)
+   uint64_t total_keys = 0, total_positions = 0;  // of the ranges of the launch
    const auto launchSliced = [&]() -> int {
       if (n_sliced == 0) {
          return SILO_GPU_OK;
       }
-      // at most two chunks per block: short blocks keep the launch balanced whatever the slices hold
       static std::once_flag lds_once;
-      std::call_once(lds_once, [] {  // eight filter slices: 128 KiB of LDS, beyond what a kernel may ask for by default
-         (void)hipFuncSetAttribute(
-            reinterpret_cast<const void*>(k_scan_escapes_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            8 * ESCAPE_SLICE_WORDS32 * static_cast<int>(sizeof(uint32_t))
-         );
+      std::call_once(lds_once, [] {  // filter slices + counter windows: beyond what a kernel may ask for by default
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<1>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<1>());
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<1>());
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<2>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<2>());
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<4>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<4>());
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<8>());
       });
-      const size_t slice_bytes = ESCAPE_SLICE_WORDS32 * sizeof(uint32_t);
       const uint32_t per_block = q_count <= 1 ? 1 : (q_count <= 2 ? 2 : (q_count <= 4 ? 4 : 8));  // filters per pass over the keys
-      const dim3 grid((most_chunks + 1) / 2, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
+      const uint32_t chunk_keys = ESCAPE_SLICE_THREADS * (per_block >= 8 ? escapeKeysInFlight<8>() : (per_block >= 4 ? escapeKeysInFlight<4>() : escapeKeysInFlight<1>()));
+      // keys per block: as many as mostly fall into the block's window of counters (3/4 of it at the average density of keys
+      // along the positions; a key beyond it still counts, with an atomic of its own), at most ESCAPE_CHUNKS_PER_BLOCK chunks
+      const uint32_t window = per_block >= 8 ? escapeWindow<8>() : (per_block >= 4 ? escapeWindow<4>() : (per_block >= 2 ? escapeWindow<2>() : escapeWindow<1>()));
+      const double keys_per_counter = static_cast<double>(total_keys) / std::max<double>(1.0, static_cast<double>(total_positions) * sliced.n_slices * sliced.out_symbols);
+      const double fitting = 0.75 * window * keys_per_counter;
+      const uint32_t block_keys = static_cast<uint32_t>(std::min<double>(chunk_keys * ESCAPE_CHUNKS_PER_BLOCK, std::max<double>(2048.0, fitting))) & ~1u;
+      sliced.block_keys = block_keys;
+      const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
       switch (per_block) {
-         case 1: k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, slice_bytes, hip_stream>>>(sliced, q_count); break;
-         case 2: k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, 2 * slice_bytes, hip_stream>>>(sliced, q_count); break;
-         case 4: k_scan_escapes_sliced<4><<<grid, ESCAPE_SLICE_THREADS, 4 * slice_bytes, hip_stream>>>(sliced, q_count); break;
-         default: k_scan_escapes_sliced<8><<<grid, ESCAPE_SLICE_THREADS, 8 * slice_bytes, hip_stream>>>(sliced, q_count); break;
+         case 1:
+            if (g_tune_scan_variant.load() == 30) {
+               k_scan_escapes_sliced<1, false><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<1>(), hip_stream>>>(sliced, q_count);
+            } else {
+               k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<1>(), hip_stream>>>(sliced, q_count);
+            }
+            break;
+         case 2: k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<2>(), hip_stream>>>(sliced, q_count); break;
+         case 4: k_scan_escapes_sliced<4><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<4>(), hip_stream>>>(sliced, q_count); break;
+         default: k_scan_escapes_sliced<8><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<8>(), hip_stream>>>(sliced, q_count); break;
       }
       HIP_TRY(hipGetLastError());
       n_sliced = 0;
-      most_chunks = 0;
+      most_keys = 0;
+      total_keys = 0;
+      total_positions = 0;
       return SILO_GPU_OK;
    };
    for (const ScanRange& range : ranges) {
@@ -3551,10 +3679,12 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
             sliced.filters[q] = filters[q];
             entry.counts[q] = range.counts[q];
          }
+         total_keys += count;
+         total_positions += range.pos_end - range.pos_begin;
          const size_t stride = static_cast<size_t>(entry.positions) + 1;
          for (uint32_t slice = 0; slice < layout.n_slices; ++slice) {
             const uint32_t keys = layout.slice_first[slice * stride + range.pos_end] - layout.slice_first[slice * stride + range.pos_begin];
-            most_chunks = std::max(most_chunks, (keys + ESCAPE_CHUNK_KEYS - 1) / ESCAPE_CHUNK_KEYS);
+            most_keys = std::max(most_keys, keys + 1u);  // (chunks start at an even key index)
          }
          continue;
       }
@@ -3652,7 +3782,9 @@ int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_s
       std::call_once(lds_once, [] {
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_missing_runs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
       });
-      const dim3 run_grid(1, launch.n_run_slices * launch.n_ranges, q_count);
+      // one block per CU fits (its LDS): about one round of the 256 CUs over all (slice, range, filter)
+      const uint32_t run_units = std::max<uint32_t>(1, launch.n_run_slices * launch.n_ranges * q_count);
+      const dim3 run_grid(std::min<uint32_t>(8, std::max<uint32_t>(1, 240 / run_units)), launch.n_run_slices * launch.n_ranges, q_count);
       if (lds_diff) {
          k_scan_missing_runs<true><<<run_grid, DERIVED_THREADS, lds_bytes, hip_stream>>>(launch);
       } else {
@@ -3687,23 +3819,27 @@ int finishDerived(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_stream) {
    return SILO_GPU_OK;
 }
 
-/// The passes beside the plane scans — the escape keys and, for a scan with derived symbols, the rows without a valid symbol —
-/// on side stream 0: forked behind everything already queued on `hip_stream` (the filters are complete, the count tables
-/// zeroed), joined by joinSides before anything reads the tables.
+/// The passes beside the plane scans.  A store with a row for every stored symbol: the escape keys on side stream 0 (lowest
+/// priority), beside plane scans that take milliseconds.  A scan with derived symbols has few plane rows left and its escape
+/// pass is as long as its plane scans — both stream at the memory's rate and gain nothing from sharing it —, so the escape
+/// pass stays on the caller's stream in front of the plane scans, and the side stream (default priority) takes the passes
+/// that are bound by latency and LDS, not by bandwidth: the runs of the missing symbol and the sparse keys.  Forked behind
+/// everything already queued on `hip_stream` (the filters are complete, the tables zeroed), joined by joinSides before
+/// anything reads the tables.  SILO_GPU_TUNE_SIDE_STREAM: 0 as described, 1 side stream of default priority, 2 everything on the caller's stream.
 int forkSidePasses(const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, DerivedPlan* derived, hipStream_t hip_stream) {
-   bool any = derived != nullptr;
+   bool any_escapes = false;
    for (const ScanRange& range : ranges) {
       const SeqStoreHost::Layout& layout = range.seqstore->layout;
-      any = any || (layout.built && layout.d_escapes != nullptr && layout.escape_first[range.pos_end] != layout.escape_first[range.pos_begin]);
+      any_escapes = any_escapes || (layout.built && layout.d_escapes != nullptr && layout.escape_first[range.pos_end] != layout.escape_first[range.pos_begin]);
    }
-   if (!any) {
+   if (!any_escapes && derived == nullptr) {
       return SILO_GPU_OK;
    }
-   const int mode = g_tune_side_stream.load();  // 0: lowest-priority side stream, 1: default priority, 2: the caller's stream
+   const int mode = g_tune_side_stream.load();
    SideStreams* side = mode == 2 ? nullptr : sideStreams();
    hipStream_t stream = hip_stream;
    if (side != nullptr) {
-      const int k = mode == 1 ? 1 : 0;
+      const int k = mode == 1 || derived != nullptr ? 1 : 0;
       if (const int rc = forkSide(side, k, 0, hip_stream, true); rc != SILO_GPU_OK) {
          return rc;
       }
@@ -3713,6 +3849,7 @@ int forkSidePasses(const std::vector<ScanRange>& ranges, const uint64_t* const* 
       if (const int rc = scanRowsWithoutSymbol(*derived, q_count, stream); rc != SILO_GPU_OK) {
          return rc;
       }
+      return any_escapes ? scanEscapes(ranges, filters, q_count, mode == 1 ? stream : hip_stream) : SILO_GPU_OK;
    }
    return scanEscapes(ranges, filters, q_count, stream);
 }
@@ -3976,7 +4113,7 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
          (void)hipFree(d_escapes_sliced);
          (void)hipFree(d_slice_first);
       };
-      hipError_t status = hipMalloc(&d_escapes_sliced, work.escape_bytes);
+      hipError_t status = hipMalloc(&d_escapes_sliced, work.escape_bytes + 16);  // (the scan loads the keys in pairs: one key of slack)
       status = status != hipSuccess ? status : hipMalloc(&d_slice_first, n_entries * sizeof(uint32_t));
       status = status != hipSuccess ? status : hipMemcpy(d_escapes_sliced, work.d_escapes, work.total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
       if (status != hipSuccess) {
@@ -3991,6 +4128,7 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
       k_slice_index<<<static_cast<uint32_t>((n_entries + 255) / 256), 256>>>(
          d_escapes_sliced, static_cast<uint32_t>(work.total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
       );
+      k_recode_sliced_keys<<<static_cast<uint32_t>((work.total_escapes + 255) / 256), 256>>>(d_escapes_sliced, static_cast<uint32_t>(work.total_escapes), dev.n_scan);
       slice_first.resize(n_entries);
       status = hipGetLastError();
       status = status != hipSuccess ? status : hipMemcpy(slice_first.data(), d_slice_first, n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost);
