@@ -350,6 +350,19 @@ int silo_gpu_mutations_select(
    const uint32_t* counts_dev, const uint8_t* reference_index_dev, uint32_t n_positions, uint32_t n_symbols, double min_proportion,
    uint32_t capacity, uint32_t* out_dev, void* stream
 );
+/* K4 with the list delivered straight into page-locked host memory: a row slot owns a host buffer the kernel writes the
+ * selected rows into and a header word its last block publishes (no device -> host copy, no event: the host spins on the
+ * word as for a count slot).  One slot serves one launch at a time.  *out_selected may exceed the slot's capacity: only the
+ * first `capacity` rows are there and the caller falls back to the whole table, as with silo_gpu_mutations_select.
+ * The rows stay valid until the slot's next launch. */
+typedef struct silo_gpu_row_slot silo_gpu_row_slot;
+int silo_gpu_row_slot_create(uint32_t row_capacity, silo_gpu_row_slot** out_slot);
+void silo_gpu_row_slot_destroy(silo_gpu_row_slot* slot);
+int silo_gpu_mutations_select_to_slot(
+   const uint32_t* counts_dev, const uint8_t* reference_index_dev, uint32_t n_positions, uint32_t n_symbols, double min_proportion,
+   silo_gpu_row_slot* slot, void* stream
+);
+int silo_gpu_row_slot_wait(silo_gpu_row_slot* slot, const silo_gpu_mutation_row** out_rows, uint32_t* out_selected, void* stream);
 /* Plain byte upload into a fresh device allocation (free with silo_gpu_free). */
 int silo_gpu_upload_bytes(const void* src_host, size_t bytes, void** out_dev);
 

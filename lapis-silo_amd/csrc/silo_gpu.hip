@@ -2134,6 +2134,57 @@ __global__ __launch_bounds__(256) void k_mutations_select(
    }
 }
 
+// K4 with the list written straight into page-locked host memory (a row slot): no copy and no event between the scan and
+// the host — the wait for a 6 KB device -> host copy and its event cost more than the row selection itself.  Rows go to the
+// slot's host buffer (system-scope stores through the mapped pointer), the cursor and the ticket of finished blocks stay in
+// device memory; every block makes its rows visible (system-scope fence) before it takes its ticket, and the block that
+// takes the last one publishes epoch << 32 | number of selected cells (may exceed the capacity: then the caller falls back
+// to the whole table) and re-arms cursor and ticket for the next launch.
+__global__ __launch_bounds__(256) void k_mutations_select_to_host(
+   const uint32_t* __restrict__ counts, const uint8_t* __restrict__ reference_index, uint32_t n_positions, uint32_t n_symbols,
+   double min_proportion, uint32_t capacity, uint32_t* __restrict__ cursor_and_ticket, silo_gpu_mutation_row* __restrict__ host_rows,
+   unsigned long long* __restrict__ host_header, uint32_t epoch
+) {
+   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+   uint32_t selected = 0;  // bit s: symbol s passes
+   uint32_t total = 0;
+   const uint32_t* at_position = counts + static_cast<size_t>(pos) * n_symbols;
+   if (pos < n_positions) {
+      for (uint32_t s = 0; s < n_symbols; ++s) {
+         total += at_position[s];
+      }
+      if (total != 0) {
+         const uint32_t threshold_count = min_proportion == 0 ? 0u : static_cast<uint32_t>(ceil(static_cast<double>(total) * min_proportion) - 1);
+         const uint32_t reference = reference_index[pos];
+         for (uint32_t s = 0; s < n_symbols; ++s) {
+            if (s != reference && at_position[s] > threshold_count) {
+               selected |= 1u << s;
+            }
+         }
+      }
+   }
+   if (selected != 0) {
+      uint32_t slot = atomicAdd(&cursor_and_ticket[0], static_cast<uint32_t>(__popc(selected)));
+      for (uint32_t s = 0; s < n_symbols; ++s) {
+         if ((selected >> s) & 1u) {
+            if (slot < capacity) {
+               host_rows[slot] = silo_gpu_mutation_row{pos, s, at_position[s], total};
+            }
+            ++slot;
+         }
+      }
+   }
+   __threadfence_system();  // this thread's rows are in host memory ...
+   __syncthreads();         // ... and so are those of the whole block, before its ticket is taken
+   if (threadIdx.x == 0) {
+      if (atomicAdd(&cursor_and_ticket[1], 1u) == gridDim.x - 1) {
+         const uint32_t n_selected = atomicExch(&cursor_and_ticket[0], 0u);
+         atomicExch(&cursor_and_ticket[1], 0u);
+         __hip_atomic_store(host_header, (static_cast<unsigned long long>(epoch) << 32) | n_selected, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+   }
+}
+
 __global__ void k_fill_ones(uint64_t* out, uint32_t row_words, uint32_t sequence_count) {
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
    if (w < row_words) {
@@ -5239,6 +5290,100 @@ int silo_gpu_mutations_select(
       );
       HIP_TRY(hipGetLastError());
    }
+   return SILO_GPU_OK;
+}
+
+struct silo_gpu_row_slot {
+   uint32_t capacity = 0;
+   uint32_t epoch = 0;                       // of the last launch
+   uint32_t* d_cursor_and_ticket = nullptr;  // device: rows appended so far, blocks done so far
+   void* host = nullptr;                     // page-locked: header word (epoch << 32 | selected cells), then the rows from byte 16
+   void* host_dev = nullptr;                 // its device address
+};
+
+int silo_gpu_row_slot_create(uint32_t row_capacity, silo_gpu_row_slot** out_slot) {
+   if (out_slot == nullptr || row_capacity == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_row_slot_create: bad arguments");
+   }
+   auto* slot = new (std::nothrow) silo_gpu_row_slot;
+   if (slot == nullptr) {
+      return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of host memory");
+   }
+   slot->capacity = row_capacity;
+   hipError_t err = hipMalloc(&slot->d_cursor_and_ticket, 2 * sizeof(uint32_t));
+   err = err != hipSuccess ? err : hipMemset(slot->d_cursor_and_ticket, 0, 2 * sizeof(uint32_t));
+   err = err != hipSuccess ? err : hipStreamSynchronize(nullptr);  // (the fill is only enqueued; the launches come on other streams)
+   err = err != hipSuccess ? err : hipHostMalloc(&slot->host, 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(row_capacity), hipHostMallocMapped | hipHostMallocCoherent);
+   if (err == hipSuccess) {
+      *static_cast<unsigned long long*>(slot->host) = 0;
+      err = hipHostGetDevicePointer(&slot->host_dev, slot->host, 0);
+   }
+   if (err != hipSuccess) {
+      silo_gpu_row_slot_destroy(slot);
+      HIP_TRY(err);
+   }
+   *out_slot = slot;
+   return SILO_GPU_OK;
+}
+
+void silo_gpu_row_slot_destroy(silo_gpu_row_slot* slot) {
+   if (slot != nullptr) {
+      (void)hipFree(slot->d_cursor_and_ticket);
+      if (slot->host != nullptr) {
+         (void)hipHostFree(slot->host);
+      }
+      delete slot;
+   }
+}
+
+int silo_gpu_mutations_select_to_slot(
+   const uint32_t* counts_dev, const uint8_t* reference_index_dev, uint32_t n_positions, uint32_t n_symbols, double min_proportion,
+   silo_gpu_row_slot* slot, void* stream
+) {
+   if (counts_dev == nullptr || reference_index_dev == nullptr || slot == nullptr || n_symbols == 0 || n_symbols > 32 || n_positions == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_mutations_select_to_slot: bad arguments");
+   }
+   slot->epoch += 1;
+   if (slot->epoch == 0) {
+      slot->epoch = 1;
+   }
+   auto* header = static_cast<unsigned long long*>(slot->host_dev);
+   k_mutations_select_to_host<<<(n_positions + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      counts_dev, reference_index_dev, n_positions, n_symbols, min_proportion, slot->capacity, slot->d_cursor_and_ticket,
+      reinterpret_cast<silo_gpu_mutation_row*>(reinterpret_cast<char*>(slot->host_dev) + 16), header, slot->epoch
+   );
+   HIP_TRY(hipGetLastError());
+   return SILO_GPU_OK;
+}
+
+int silo_gpu_row_slot_wait(silo_gpu_row_slot* slot, const silo_gpu_mutation_row** out_rows, uint32_t* out_selected, void* stream) {
+   if (slot == nullptr || out_rows == nullptr || out_selected == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_row_slot_wait: null argument");
+   }
+   const auto* header = static_cast<const unsigned long long*>(slot->host);
+   // a pure spin on the header word (as silo_gpu_count_slot_wait); a launch that does not deliver within the budget is waited
+   // for with ONE blocking hipStreamSynchronize, which also reports a broken stream
+   constexpr uint64_t SPIN_BUDGET = uint64_t{1} << 22;
+   unsigned long long value = 0;
+   bool delivered = false;
+   for (uint64_t spin = 0; spin < SPIN_BUDGET && !delivered; ++spin) {
+      value = __atomic_load_n(header, __ATOMIC_ACQUIRE);
+      delivered = static_cast<uint32_t>(value >> 32) == slot->epoch;
+#if defined(__x86_64__)
+      if (!delivered) {
+         __builtin_ia32_pause();
+      }
+#endif
+   }
+   if (!delivered) {
+      HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+      value = __atomic_load_n(header, __ATOMIC_ACQUIRE);
+      if (static_cast<uint32_t>(value >> 32) != slot->epoch) {
+         return fail(SILO_GPU_ERR_HIP, "row slot: the kernel finished without delivering its rows");
+      }
+   }
+   *out_selected = static_cast<uint32_t>(value);
+   *out_rows = reinterpret_cast<const silo_gpu_mutation_row*>(static_cast<const char*>(slot->host) + 16);
    return SILO_GPU_OK;
 }
 

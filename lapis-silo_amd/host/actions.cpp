@@ -1,9 +1,11 @@
 // actions.cpp — Action base (ordering / limit / offset), Aggregated (count) and Mutations<SymbolType>.
 // Reference: src/silo/query_engine/actions/{action,aggregated,mutations}.cpp.
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <functional>
 #include <string_view>
+#include <tuple>
 
 #include "query_engine.h"
 
@@ -91,6 +93,10 @@ std::unique_ptr<Action::Pending> Action::begin(const Database& database, std::ve
 
 QueryResult Action::finish(const Database& database, Pending& pending) const {
    return orderAndLimit(execute(database, std::move(pending.bitmap_filter)));
+}
+
+std::string Action::finishJson(const Database& database, Pending& pending) const {
+   return toJsonText(finish(database, pending));
 }
 
 // ---- ScanBatcher ---------------------------------------------------------------------------------
@@ -415,8 +421,7 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
    const bool reduced = database.all_reduce != nullptr;  // the table is all-reduced, with the query's fingerprint behind it
    pending->table_bytes = ((n_counts + (reduced ? FINGERPRINT_WORDS : 0)) * sizeof(uint32_t) + 15) / 16 * 16;
    pending->row_capacity = layout.reference_index_device != nullptr ? database.mutation_row_capacity : 0;
-   const size_t list_bytes = 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(pending->row_capacity);
-   pending->device_table = database.partitions.front().pool.acquire(pending->table_bytes + list_bytes);
+   pending->device_table = database.partitions.front().pool.acquire(pending->table_bytes);
    auto* device_counts = static_cast<uint32_t*>(pending->device_table.get());
    checkGpu(silo_gpu_memset_async(device_counts, 0, pending->table_bytes, queryStream()), "silo_gpu_memset_async");
 
@@ -455,13 +460,10 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
          scans.fetch = HostFetch(device_counts, scans.table_bytes, queryStream());
          return;
       }
-      // K4 picks the rows on the device (threshold arithmetic of mutations.cpp:197-211); only they travel
-      auto* list = reinterpret_cast<uint32_t*>(static_cast<char*>(scans.device_table.get()) + scans.table_bytes);
-      checkGpu(
-         silo_gpu_mutations_select(device_counts, reference_index, total_positions, n_symbols, proportion, scans.row_capacity, list, queryStream()),
-         "silo_gpu_mutations_select"
-      );
-      scans.fetch = HostFetch(list, 16 + sizeof(silo_gpu_mutation_row) * static_cast<size_t>(scans.row_capacity), queryStream());
+      // K4 picks the rows on the device (threshold arithmetic of mutations.cpp:197-211) and writes them straight into
+      // page-locked host memory: only they travel, and nothing waits for a copy or an event
+      scans.row_slot = RowSlot(scans.row_capacity);
+      scans.row_slot.select(device_counts, reference_index, total_positions, n_symbols, proportion, queryStream());
    };
    ScanBatcher* batcher = ScanBatcher::active();
    if (reduced) {
@@ -481,52 +483,93 @@ std::unique_ptr<Action::Pending> Mutations<SymbolType>::begin(const Database& da
 }
 
 template <typename SymbolType>
-QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScans& scans) const {
-   std::vector<QueryResultEntry> result_rows;
-   if (!scans.fetch) {
-      return QueryResult{std::move(result_rows)};
+std::vector<typename Mutations<SymbolType>::SelectedRow> Mutations<SymbolType>::collectSelected(const Database& database, PendingScans& scans) const {
+   std::vector<SelectedRow> selected;
+   if (!scans.fetch && !scans.row_slot) {
+      return selected;
    }
    const MutationTableLayout& layout = database.getMutationTableLayout<SymbolType>();
    constexpr uint32_t n_symbols = SymbolType::VALID_MUTATION_SYMBOLS.size();
-   const auto* words = static_cast<const uint32_t*>(scans.fetch.wait());
+   const uint32_t* table = nullptr;
+   const silo_gpu_mutation_row* rows = nullptr;
+   uint32_t n_selected = 0;
+   if (scans.row_slot) {
+      std::tie(rows, n_selected) = scans.row_slot.wait();
+   } else {
+      table = static_cast<const uint32_t*>(scans.fetch.wait());
+   }
    Trace::mark("counts_on_host");
    if (scans.check_fetch) {
       checkSameQuery(database, static_cast<const uint32_t*>(scans.check_fetch.wait()), scans.fingerprint);
    }
    HostFetch whole_table;
-   const uint32_t* table = nullptr;
-   if (scans.row_capacity == 0) {
-      table = words;
-   } else if (words[0] > scans.row_capacity) {  // more rows than the list holds: take the whole table after all
+   if (table == nullptr && n_selected > scans.row_capacity) {  // more rows than the list holds: take the whole table after all
       whole_table = HostFetch(scans.device_table.get(), scans.table_bytes, queryStream());
       table = static_cast<const uint32_t*>(whole_table.wait());
    }
    if (table != nullptr) {
+      // the row selection of mutations.cpp:184-232 on the host, over the count table the device filled: counts[position][valid symbol]
       for (const auto& sequence_name : scans.sequence_names) {
          const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-         addMutationsToOutput(
-            sequence_name, sequence_store, table + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols, result_rows
-         );
-      }
-   } else {
-      // the device appends in no particular order; the reference emits stores in request order, positions
-      // ascending, symbols in VALID_MUTATION_SYMBOLS order (mutations.cpp:190-229, 259-268)
-      const auto* rows = reinterpret_cast<const silo_gpu_mutation_row*>(words + 4);
-      std::vector<silo_gpu_mutation_row> sorted(rows, rows + words[0]);
-      const auto before = [](const silo_gpu_mutation_row& a, const silo_gpu_mutation_row& b) {
-         return a.position != b.position ? a.position < b.position : a.symbol_index < b.symbol_index;
-      };
-      std::sort(sorted.begin(), sorted.end(), before);
-      result_rows.reserve(sorted.size());
-      for (const auto& sequence_name : scans.sequence_names) {
-         const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
-         const uint32_t offset = layout.position_offset.at(sequence_name);
-         const auto length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
-         auto row = std::lower_bound(sorted.begin(), sorted.end(), silo_gpu_mutation_row{offset, 0, 0, 0}, before);
-         for (; row != sorted.end() && row->position < offset + length; ++row) {
-            addSelectedRowToOutput(sequence_name, sequence_store, row->position - offset, *row, result_rows);
+         const uint32_t* counts = table + static_cast<size_t>(layout.position_offset.at(sequence_name)) * n_symbols;
+         const auto& reference = sequence_store.reference_sequence;
+         for (size_t position = 0; position < reference.size(); ++position) {
+            const uint32_t* cell = counts + position * n_symbols;
+            uint32_t covered = 0;  // rows of the filter with a valid symbol here; uint32 wrap-around like the reference's sum
+            for (size_t k = 0; k < n_symbols; ++k) {
+               covered += cell[k];
+            }
+            if (covered == 0) {
+               continue;
+            }
+            // a symbol is reported when count >= ceil(covered * minProportion); written as the reference writes it (IEEE double,
+            // then "count > that - 1" in uint32), because the rounding decides rows at the boundary
+            const uint32_t must_exceed = min_proportion == 0 ? 0 : static_cast<uint32_t>(std::ceil(static_cast<double>(covered) * min_proportion) - 1);
+            for (size_t k = 0; k < n_symbols; ++k) {
+               if (SymbolType::VALID_MUTATION_SYMBOLS[k] != reference[position] && cell[k] > must_exceed) {
+                  selected.push_back({&sequence_name, &sequence_store, static_cast<uint32_t>(position), static_cast<uint32_t>(k), cell[k], covered});
+               }
+            }
          }
       }
+      return selected;
+   }
+   // the device appends in no particular order; the reference emits stores in request order, positions
+   // ascending, symbols in VALID_MUTATION_SYMBOLS order (mutations.cpp:190-229, 259-268)
+   std::vector<silo_gpu_mutation_row> sorted(rows, rows + n_selected);
+   const auto before = [](const silo_gpu_mutation_row& a, const silo_gpu_mutation_row& b) {
+      return a.position != b.position ? a.position < b.position : a.symbol_index < b.symbol_index;
+   };
+   std::sort(sorted.begin(), sorted.end(), before);
+   selected.reserve(sorted.size());
+   for (const auto& sequence_name : scans.sequence_names) {
+      const SequenceStore<SymbolType>& sequence_store = database.getSequenceStores<SymbolType>().at(sequence_name);
+      const uint32_t offset = layout.position_offset.at(sequence_name);
+      const auto length = static_cast<uint32_t>(sequence_store.reference_sequence.size());
+      auto row = std::lower_bound(sorted.begin(), sorted.end(), silo_gpu_mutation_row{offset, 0, 0, 0}, before);
+      for (; row != sorted.end() && row->position < offset + length; ++row) {
+         selected.push_back({&sequence_name, &sequence_store, row->position - offset, row->symbol_index, row->count, row->total});
+      }
+   }
+   return selected;
+}
+
+template <typename SymbolType>
+std::string Mutations<SymbolType>::mutationName(const SelectedRow& row) const {  // "<reference symbol><1-based position><symbol>", mutations.cpp:213-216
+   const char from = SymbolType::symbolToChar(row.sequence_store->reference_sequence.at(row.position));
+   const char to = SymbolType::symbolToChar(SymbolType::VALID_MUTATION_SYMBOLS.at(row.symbol_index));
+   return from + std::to_string(row.position + 1) + to;
+}
+
+template <typename SymbolType>
+QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScans& scans) const {
+   std::vector<QueryResultEntry> result_rows;
+   const std::vector<SelectedRow> selected = collectSelected(database, scans);
+   result_rows.reserve(selected.size());
+   for (const SelectedRow& row : selected) {
+      addSelectedRowToOutput(
+         *row.sequence_name, *row.sequence_store, row.position, silo_gpu_mutation_row{row.position, row.symbol_index, row.count, row.total}, result_rows
+      );
    }
    Trace::mark("rows_built");
    return QueryResult{std::move(result_rows)};
@@ -535,6 +578,83 @@ QueryResult Mutations<SymbolType>::collect(const Database& database, PendingScan
 template <typename SymbolType>
 QueryResult Mutations<SymbolType>::finish(const Database& database, Action::Pending& pending) const {
    return orderAndLimit(collect(database, dynamic_cast<PendingScans&>(pending)));
+}
+
+template <typename SymbolType>
+std::string Mutations<SymbolType>::finishJson(const Database& database, Action::Pending& pending) const {
+   // The bytes toJsonText(finish(...)) would give, written from the selected rows themselves.  Ordering: the comparator, the
+   // index array and the std:: algorithms of Action::applySort over the same values (a field of a row is a string, an
+   // int32 or a double there too), so ties fall the same way.
+   const std::vector<SelectedRow> selected = collectSelected(database, dynamic_cast<PendingScans&>(pending));
+   const size_t n_rows = selected.size();
+   std::vector<uint32_t> order(n_rows);
+   for (size_t row = 0; row < n_rows; ++row) {
+      order[row] = static_cast<uint32_t>(row);
+   }
+   std::vector<std::string> names;  // only where a row's name is needed before the rows are written: ordered by "mutation"
+   const size_t first = std::min<size_t>(offset.value_or(0), n_rows);
+   const size_t count = limit.has_value() ? std::min<size_t>(*limit, n_rows - first) : n_rows - first;
+   if (!order_by_fields.empty() && offset.value_or(0) < n_rows) {
+      enum class Key { MUTATION, PROPORTION, COUNT };
+      std::vector<std::pair<Key, bool>> keys;
+      for (const OrderByField& field : order_by_fields) {
+         keys.emplace_back(field.name == MUTATION_FIELD_NAME ? Key::MUTATION : (field.name == PROPORTION_FIELD_NAME ? Key::PROPORTION : Key::COUNT), field.ascending);
+         if (keys.back().first == Key::MUTATION && names.empty()) {
+            names.reserve(n_rows);
+            for (const SelectedRow& row : selected) {
+               names.push_back(mutationName(row));
+            }
+         }
+      }
+      const auto proportion = [&](uint32_t row) { return static_cast<double>(selected[row].count) / static_cast<double>(selected[row].total); };
+      const auto before = [&](uint32_t left, uint32_t right) {
+         for (const auto& [key, ascending] : keys) {
+            if (key == Key::MUTATION) {
+               if (!(names[left] == names[right])) {
+                  return (names[left] < names[right]) == ascending;
+               }
+            } else if (key == Key::PROPORTION) {
+               const double a = proportion(left), b = proportion(right);
+               if (!(a == b)) {
+                  return (a < b) == ascending;
+               }
+            } else {
+               const auto a = static_cast<int32_t>(selected[left].count), b = static_cast<int32_t>(selected[right].count);
+               if (!(a == b)) {
+                  return (a < b) == ascending;
+               }
+            }
+         }
+         return false;
+      };
+      const size_t window_end = limit.has_value() ? std::min<size_t>(n_rows, static_cast<size_t>(*limit) + offset.value_or(0)) : n_rows;
+      if (window_end < n_rows) {
+         std::partial_sort(order.begin(), order.begin() + static_cast<std::ptrdiff_t>(window_end), order.end(), before);
+      } else {
+         std::sort(order.begin(), order.end(), before);
+      }
+   }
+   std::string out;
+   out.reserve(32 + count * 112);
+   out += "{\"queryResult\":[";
+   char digits[16];
+   for (size_t k = 0; k < count; ++k) {
+      const uint32_t index = order[first + k];
+      const SelectedRow& row = selected[index];
+      // keys in the order of the reference's std::map: count < mutation < proportion < sequenceName
+      out += k == 0 ? "{\"count\":" : ",{\"count\":";
+      out.append(digits, std::to_chars(digits, digits + sizeof(digits), static_cast<int32_t>(row.count)).ptr);
+      out += ",\"mutation\":";
+      json::Value::appendString(out, names.empty() ? mutationName(row) : names[index]);
+      out += ",\"proportion\":";
+      json::Value::appendDouble(out, static_cast<double>(row.count) / static_cast<double>(row.total));
+      out += ",\"sequenceName\":";
+      json::Value::appendString(out, *row.sequence_name);
+      out.push_back('}');
+   }
+   out += "]}";
+   Trace::mark("rows_built");
+   return out;
 }
 
 template <typename SymbolType>

@@ -403,8 +403,7 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
    }
    // the exception -> HTTP mapping of src/silo_api/query_handler.cpp:42-73
    try {
-      const auto query_result = engine->database.executeQuery(query_json);
-      *out_json = duplicate(silo::query_engine::toJsonText(query_result));
+      *out_json = duplicate(engine->database.executeQueryJson(query_json));
       silo::Trace::mark("serialized");
       *out_http_status = 200;
    } catch (const silo::QueryParseException& ex) {

@@ -201,6 +201,70 @@ const void* HostFetch::wait() const {
    return host_;
 }
 
+// ---- RowSlot ---------------------------------------------------------------------------------------
+namespace {
+std::mutex& rowSlotMutex() {
+   static std::mutex mutex;
+   return mutex;
+}
+std::multimap<uint32_t, silo_gpu_row_slot*>& rowSlotFree() {
+   static auto* free_list = new std::multimap<uint32_t, silo_gpu_row_slot*>();  // never destroyed: threads may outlive static destruction
+   return *free_list;
+}
+}  // namespace
+
+RowSlot::RowSlot(uint32_t row_capacity) : capacity_(row_capacity) {
+   {
+      const std::lock_guard<std::mutex> lock(rowSlotMutex());
+      const auto found = rowSlotFree().find(row_capacity);
+      if (found != rowSlotFree().end()) {
+         slot_ = found->second;
+         rowSlotFree().erase(found);
+      }
+   }
+   if (slot_ == nullptr) {
+      checkGpu(silo_gpu_row_slot_create(row_capacity, &slot_), "silo_gpu_row_slot_create");
+   }
+}
+
+RowSlot& RowSlot::operator=(RowSlot&& other) noexcept {
+   if (this != &other) {
+      this->~RowSlot();
+      slot_ = other.slot_;
+      capacity_ = other.capacity_;
+      stream_ = other.stream_;
+      in_flight_ = other.in_flight_;
+      other.slot_ = nullptr;
+      other.in_flight_ = false;
+   }
+   return *this;
+}
+
+RowSlot::~RowSlot() {
+   if (slot_ != nullptr) {
+      if (in_flight_) {  // (an exception unwound the query) the kernel still writes into the slot: let it finish
+         (void)silo_gpu_stream_synchronize(stream_);
+      }
+      const std::lock_guard<std::mutex> lock(rowSlotMutex());
+      rowSlotFree().emplace(capacity_, slot_);
+      slot_ = nullptr;
+   }
+}
+
+void RowSlot::select(const uint32_t* counts, const uint8_t* reference_index, uint32_t n_positions, uint32_t n_symbols, double min_proportion, void* stream) {
+   stream_ = stream;
+   checkGpu(silo_gpu_mutations_select_to_slot(counts, reference_index, n_positions, n_symbols, min_proportion, slot_, stream), "silo_gpu_mutations_select_to_slot");
+   in_flight_ = true;
+}
+
+std::pair<const silo_gpu_mutation_row*, uint32_t> RowSlot::wait() {
+   const silo_gpu_mutation_row* rows = nullptr;
+   uint32_t selected = 0;
+   checkGpu(silo_gpu_row_slot_wait(slot_, &rows, &selected, stream_), "silo_gpu_row_slot_wait");
+   in_flight_ = false;
+   return {rows, selected};
+}
+
 // ---- pango lineage aliases (pango_lineage_alias.cpp:21-41, 88-102) -------------------------------
 PangoLineageAliasLookup PangoLineageAliasLookup::fromJson(const json::Value& json) {
    std::unordered_map<std::string, std::vector<std::string>> alias_keys;
@@ -410,6 +474,11 @@ Database::Timings& Database::lastTimings() {
 query_engine::QueryResult Database::executeQuery(const std::string& query) const {
    const query_engine::QueryEngine query_engine(*this);
    return query_engine.executeQuery(query);
+}
+
+std::string Database::executeQueryJson(const std::string& query) const {
+   const query_engine::QueryEngine query_engine(*this);
+   return query_engine.executeQueryJson(query);
 }
 
 std::pair<uint32_t, uint32_t> Database::positionWindow(size_t length) const {

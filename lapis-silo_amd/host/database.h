@@ -118,6 +118,32 @@ class HostFetch {
    size_t capacity_ = 0;
 };
 
+/// A row slot of the device library (silo_gpu_row_slot: the selected rows of a Mutations query written by the kernel straight
+/// into page-locked host memory) out of a process-wide free list; goes back when the object dies, after its launch has
+/// delivered.
+class RowSlot {
+  public:
+   RowSlot() = default;
+   explicit RowSlot(uint32_t row_capacity);
+   RowSlot(RowSlot&& other) noexcept { *this = std::move(other); }
+   RowSlot& operator=(RowSlot&& other) noexcept;
+   RowSlot(const RowSlot&) = delete;
+   RowSlot& operator=(const RowSlot&) = delete;
+   ~RowSlot();
+   /// k_mutations_select over `counts` with the rows delivered into this slot; enqueued on `stream`.
+   void select(const uint32_t* counts, const uint8_t* reference_index, uint32_t n_positions, uint32_t n_symbols, double min_proportion, void* stream);
+   /// Blocks (spins) until the launch has delivered: the rows and the number of selected cells (may exceed the capacity).
+   std::pair<const silo_gpu_mutation_row*, uint32_t> wait();
+   explicit operator bool() const { return slot_ != nullptr; }
+   [[nodiscard]] uint32_t capacity() const { return capacity_; }
+
+  private:
+   silo_gpu_row_slot* slot_ = nullptr;
+   uint32_t capacity_ = 0;
+   void* stream_ = nullptr;
+   bool in_flight_ = false;
+};
+
 class PangoLineageAliasLookup {
   public:
    PangoLineageAliasLookup() = default;
@@ -356,6 +382,8 @@ class Database {
 
    /// database.cpp:710-714
    [[nodiscard]] virtual query_engine::QueryResult executeQuery(const std::string& query) const;
+   /// The same as the response body silo_api's QueryHandler::post would write (query_handler.cpp:38-41).
+   [[nodiscard]] std::string executeQueryJson(const std::string& query) const;
 
    /// The position range [begin, end) of a genome of `length` positions that this rank holds.
    [[nodiscard]] std::pair<uint32_t, uint32_t> positionWindow(size_t length) const;

@@ -192,6 +192,27 @@ QueryResult QueryEngine::executeQuery(const std::string& query_string) const {  
    return rows;
 }
 
+std::string QueryEngine::executeQueryJson(const std::string& query_string) const {
+   Trace::reset();
+   checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");
+   Database::queryFingerprint() = database.all_reduce != nullptr ? Database::fingerprintOf(query_string) : 0;
+   const std::shared_ptr<const Query> cached = parsedQuery(query_string);
+   const Query& query = *cached;
+   Trace::mark("parsed");
+   std::vector<OperatorResult> filters;
+   const int64_t filter_time = microsecondsOf([&] { filters = compileFilter(database, *query.filter); });
+   Trace::mark("compiled");
+   std::string body;
+   const int64_t action_time = microsecondsOf([&] {
+      // the two phases of executeAndOrder back to back (begin validates the ordering and queues the device work)
+      const std::unique_ptr<actions::Action::Pending> pending = query.action->begin(database, std::move(filters));
+      body = query.action->finishJson(database, *pending);
+   });
+   Trace::mark("action_done");
+   Database::lastTimings() = {filter_time, action_time};
+   return body;
+}
+
 std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::vector<std::string>& queries, bool render_json) const {
    Trace::reset();
    checkGpu(silo_gpu_set_device(database.device), "silo_gpu_set_device");
@@ -297,9 +318,10 @@ std::vector<QueryEngine::BatchOutcome> QueryEngine::executeQueries(const std::ve
       }
       try {
          Database::queryFingerprint() = database.all_reduce != nullptr ? Database::fingerprintOf(queries[i]) : 0;
-         outcomes[i].result = parsed[i]->action->finish(database, *pending[i]);
          if (render_json) {  // here rather than after the batch: the device is still busy with the scans of the queries behind this one
-            outcomes[i].json = toJsonText(outcomes[i].result);
+            outcomes[i].json = parsed[i]->action->finishJson(database, *pending[i]);
+         } else {
+            outcomes[i].result = parsed[i]->action->finish(database, *pending[i]);
          }
       } catch (...) {
          outcomes[i].error = std::current_exception();

@@ -599,6 +599,10 @@ class Action {
    /// rows and applies ordering / offset / limit.  The default runs everything in finish().
    [[nodiscard]] virtual std::unique_ptr<Pending> begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const;
    [[nodiscard]] virtual QueryResult finish(const Database& database, Pending& pending) const;
+   /// finish() as the response body — the bytes of toJsonText(finish(...)).  An action whose rows come off the device as
+   /// plain numbers (Mutations) writes them straight into the text: the map-of-variants rows the reference's QueryResult
+   /// prescribes (query_result.h:14-20) cost more to build than the whole scan of a small query takes.
+   [[nodiscard]] virtual std::string finishJson(const Database& database, Pending& pending) const;
 
   protected:
    [[nodiscard]] QueryResult orderAndLimit(QueryResult result) const;
@@ -712,15 +716,30 @@ class Mutations : public Action {
       DeviceBuffer device_table;
       size_t table_bytes = 0;
       uint32_t row_capacity = 0;  // 0: the host selects from the whole table
-      HostFetch fetch;            // the list (or the table), enqueued right behind the scans
+      HostFetch fetch;            // the whole table, enqueued right behind the scans (row_capacity == 0)
+      RowSlot row_slot;           // the list of selected rows, written by the kernel straight into page-locked host memory
       HostFetch check_fetch;      // sharded: the two fingerprint sums behind the table (checkSameQuery)
       uint64_t fingerprint = 0;
    };
    [[nodiscard]] QueryResult collect(const Database& database, PendingScans& scans) const;
+   /// A result row as the device (or the host's pass over the whole table) selects it, before any text is made.
+   struct SelectedRow {
+      const std::string* sequence_name;
+      const SequenceStore<SymbolType>* sequence_store;
+      uint32_t position;  // within the store
+      uint32_t symbol_index;
+      uint32_t count;
+      uint32_t total;
+   };
+   /// The selected rows in the reference's output order: stores in request order, positions ascending, symbols in
+   /// VALID_MUTATION_SYMBOLS order (mutations.cpp:190-229, 259-268).
+   [[nodiscard]] std::vector<SelectedRow> collectSelected(const Database& database, PendingScans& scans) const;
+   [[nodiscard]] std::string mutationName(const SelectedRow& row) const;
 
   public:
    [[nodiscard]] std::unique_ptr<Action::Pending> begin(const Database& database, std::vector<OperatorResult> bitmap_filter) const override;
    [[nodiscard]] QueryResult finish(const Database& database, Action::Pending& pending) const override;
+   [[nodiscard]] std::string finishJson(const Database& database, Action::Pending& pending) const override;
 
    Mutations(std::vector<std::string>&& sequence_names, double min_proportion)
        : sequence_names(std::move(sequence_names)), min_proportion(min_proportion) {}
@@ -743,6 +762,9 @@ class QueryEngine {
    explicit QueryEngine(const Database& database) : database(database) {}
    virtual ~QueryEngine() = default;
    [[nodiscard]] virtual QueryResult executeQuery(const std::string& query) const;
+   /// executeQuery as the response body (the bytes of toJsonText(executeQuery(query))): what a caller that only forwards
+   /// the JSON — silo_api's QueryHandler::post, query_handler.cpp:38-41 — needs, without the QueryResult rows in between.
+   [[nodiscard]] std::string executeQueryJson(const std::string& query) const;
 
    /// Outcome of one query of a batch: a result, or the exception it raised (mapped to 400 / 500 by the caller
    /// exactly as for a single query, silo_api/query_handler.cpp:42-73).
