@@ -7,20 +7,23 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 A *step* is one complete query through the C++ QueryEngine mirror:
     {"action": {"type": "Mutations", "minProportion": 0.05},
      "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.1", "includeSublineages": true}}
-i.e. JSON parse -> filter compile -> lineage bitset (HBM resident) -> K3 bitset+count -> K1 Mutations scan
-over every position x {-,A,C,G,T} plane -> (N > 1: all-reduce of the count table over RCCL) -> counts to
-the host -> proportion rows -> result JSON.  The planes are resident in HBM before the timed region.
+i.e. JSON parse -> filter compile -> lineage bitset (HBM resident) -> Mutations scan (plane rows, escape keys, runs of the
+missing symbol, derived symbols) -> (N > 1: all-reduce of the count table over RCCL) -> row selection on the device, the
+rows written into page-locked host memory -> response JSON.  The store is resident in HBM before the timed region.
 
-Workload (default): the north-star target "10 M-sequence Mutations scan" — 10 M synthetic SARS-CoV-2
-sequences x 29 903 nt (BASELINE.json configs[3], nucleotide leg, with configs[1]'s PangoLineage
-filter); 186.9 GB of algorithmic plane bytes per step.  N > 1 shards the genome by position range
-(strong scaling, same total work).  `--sequences 1000000` runs configs[1] itself; at N = 1 that
-configuration is also measured and reported under "also".
+Workload (default): the north-star target "10 M-sequence Mutations scan" — 10 M synthetic SARS-CoV-2 sequences x 29 903 nt
+(BASELINE.json configs[3], nucleotide leg, with configs[1]'s PangoLineage filter) on ONE database that also holds the 12
+genes.  N > 1 (`--shard position`, the north star's split): the same database sharded by position range, one all-reduce
+of the count table per query (strong scaling); the line then also carries the amino-acid leg on those shards, and
+(`--shard sequence`) BASELINE.json configs[4] — a 50 M-sequence database (genome + 12 genes) sharded by sequence id,
+ONE batch of 100 filter + Mutations / AminoAcidMutations queries with an all-reduce per count table — and the filter
+queries / s on those shards.  At N = 1 configs[4] runs whole on the one GPU.
 
-metric = positions x sequences / s (whole job).  roofline: the dominant kernel k_scan_sliced, timed with
-HIP events on the stream it is launched on; algorithmic bytes = P * 5 * 8*ceil(N/64) + 8*ceil(N/64)
-(SURVEY.md §8d).  cpu_baseline: oracle/roaring_port.c (the reference's algorithm over roaring-format
-containers, OpenMP) on a bounded sample of positions of the same store, rank 0 / N = 1 only.
+metric = positions x sequences / s (whole job).  roofline: the dominant kernel of the scan (by HIP events on the stream it
+is launched on): the bytes that launch has to read / its duration, against the 8 TB/s HBM peak and against a measured
+plain stream-read ceiling; the layout-independent algorithmic figure of SURVEY.md section 8(d) beside it.  cpu_baseline:
+oracle/roaring_port.c (the reference's algorithm over roaring-format containers, OpenMP) on a bounded sample of the same
+store, rank 0 / N = 1 only.
 """
 import argparse
 import json
@@ -51,7 +54,10 @@ def load_reference_genomes(with_genes=False):
 
 
 def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False, nuc_positions=None,
-                 lineage_order=False, two_pass=False):
+                 lineage_order=False, two_pass=False, by_position=True, seed=None):
+    """An engine with one partition of `n_sequences` synthetic rows.  sharded / world > 1: this rank's shard of a sharded
+    database — by position range (every rank holds all rows for its window of positions) or by sequence id (by_position
+    False: every rank holds all positions of ITS n_sequences rows, generated from `seed`)."""
     from silo_amd import alphabet, synth
     from silo_amd.engine import Engine
 
@@ -59,30 +65,31 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
     if nuc_positions is not None:  # an amino-acid measurement: keep only a stub of the nucleotide store
         genomes["nucleotideSequences"][0]["sequence"] = genomes["nucleotideSequences"][0]["sequence"][:nuc_positions]
     reference = np.array([alphabet.NUCLEOTIDE.char_to_symbol[c] for c in genomes["nucleotideSequences"][0]["sequence"]], dtype=np.uint8)
+    seed = synth.DEFAULT_SEED if seed is None else seed
     tree = synth.make_lineage_tree(N_LINEAGES)
-    lineage = synth.assign_lineages(n_sequences, tree, synth.DEFAULT_SEED)
+    lineage = synth.assign_lineages(n_sequences, tree, seed)
     if lineage_order:
         # rows laid out lineage by lineage, sublineages behind their parent (the reference partitions by Pango lineage and
         # groups its rows by that key, preprocessor.cpp:159-227): a lineage-with-sublineages filter is then a row range
         rank_of = np.empty(len(tree.names), dtype=np.int64)
         rank_of[sorted(range(len(tree.names)), key=lambda k: [int(part) for part in tree.names[k].split(".")[1:]])] = np.arange(len(tree.names))
         lineage = lineage[np.argsort(rank_of[lineage], kind="stable")]
-    model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=synth.DEFAULT_SEED)
+    model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=seed)
     engine = Engine(genomes, device=device)
     if two_pass:  # the generator runs twice per store: counted, then written straight into the adaptive planes (no build-time planes)
         engine.set_option("two_pass_build", 1)
     if getattr(build_engine, "comm", None) is not None and (world > 1 or sharded):
-        engine.set_comm(build_engine.comm, True)  # native RCCL all-reduce / broadcast on the engine's streams
+        engine.set_comm(build_engine.comm, by_position)  # native RCCL all-reduce / broadcast on the engine's streams
     elif world > 1 or sharded:
-        engine.set_sharding(rank, world, True, all_reduce)
-        if getattr(build_engine, "broadcast", None) is not None:
+        engine.set_sharding(rank, world, by_position, all_reduce)
+        if by_position and getattr(build_engine, "broadcast", None) is not None:
             engine.set_broadcast(build_engine.broadcast)
     partition = engine.add_partition(n_sequences)
     window = engine.position_window("main", False)
     engine.generate_synthetic(partition, "main", False, model, window)
     for index, gene in enumerate(genomes["genes"]):
         gene_reference = np.array([alphabet.AMINO_ACID.char_to_symbol[c] for c in gene["sequence"]], dtype=np.uint8)
-        gene_model = synth.make_model(n_sequences, gene_reference, "aa", tree, lineage, seed=synth.DEFAULT_SEED, store_index=index + 1)
+        gene_model = synth.make_model(n_sequences, gene_reference, "aa", tree, lineage, seed=seed, store_index=index + 1)
         engine.generate_synthetic(partition, gene["name"], True, gene_model, engine.position_window(gene["name"], True))
     engine.set_lineage_column_ids(partition, "pango_lineage", tree.names, lineage)
     if with_metadata:
@@ -100,7 +107,8 @@ def make_query():
 
 def time_kernel(engine, tree, window, reps):
     """Average duration of one Mutations scan over this rank's window (HIP events on the null stream, where the scan is
-    launched), and of every k_scan_sliced launch inside it (time_kernel.per_launch)."""
+    launched), and of every kernel launch inside it (time_kernel.per_launch: plane scans, escape-key pass, runs of the
+    missing symbol, sparse keys — each with the bytes it has to read)."""
     import ctypes
 
     from silo_amd import binding
@@ -124,15 +132,16 @@ def time_kernel(engine, tree, window, reps):
     stop.record()
     ms = start.elapsed_ms(stop) / reps
     kernel = lib.silo_gpu_last_scan_kernel().decode()
-    # the dominant launch by itself: HIP events around every k_scan_sliced launch of `reps` more scans (on the stream the
-    # kernels are launched on), averaged per kernel instantiation
+    # every launch by itself: HIP events around each launch of `reps` more scans (on the stream it is launched on), averaged
+    # per kernel instantiation
     launches = {}
     previous = lib.silo_gpu_tune(7, 1)  # SILO_GPU_TUNE_SCAN_TIMING
     try:
         for _ in range(reps):
             binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, 0, n_positions, counts, None))
             for entry in binding.scan_timings():
-                slot = launches.setdefault(entry["kernel"], dict(kernel=entry["kernel"], plane_rows=entry["plane_rows"], blocks=entry["blocks"], ms=[]))
+                slot = launches.setdefault(entry["kernel"], dict(kernel=entry["kernel"], plane_rows=entry["plane_rows"], bytes=entry["bytes"],
+                                                                 blocks=entry["blocks"], ms=[]))
                 slot["ms"].append(entry["ms"])
     finally:
         lib.silo_gpu_tune(7, previous)
@@ -142,6 +151,97 @@ def time_kernel(engine, tree, window, reps):
 
 
 time_kernel.per_launch = []
+
+
+def scan_bytes(lib, handle, seqstore_id, positions, w8):
+    """Bytes one scan of a sequence store has to read, each once: plane rows + the filter row, 8 per escape key, 12 per run
+    of the missing symbol and 8 per sparse key (the last two only where the store derives a symbol)."""
+    rows = int(lib.silo_gpu_store_scan_rows(handle, seqstore_id, 0, positions))
+    keys = int(lib.silo_gpu_store_scan_escapes(handle, seqstore_id))
+    runs = int(lib.silo_gpu_store_scan_runs(handle, seqstore_id))
+    sparse = int(lib.silo_gpu_store_scan_sparse_keys(handle, seqstore_id))
+    return dict(plane_rows=rows, escape_keys=keys, missing_runs=runs, sparse_keys=sparse, bytes=rows * w8 + w8 + 8 * keys + 12 * runs + 8 * sparse)
+
+
+LAYOUT_TEXT = {
+    0: ("derived symbols: at most positions ONE valid symbol has nearly every row, and that symbol is stored nowhere — its count under a filter is the "
+        "filter's cardinality minus the rows of the filter without a valid symbol there (runs of the missing symbol, ambiguity codes) minus the other "
+        "symbols' counts, as the reference rebuilds the bitmap it deletes (position.cpp:102-127, mutations.cpp:74-95); one-hot rows only for a second / "
+        "third frequent symbol, every other row an escape key"),
+    1: ("adaptive planes, chosen per position at finalize: ONE one-hot row of the position's most frequent valid symbol (two or three rows where a "
+        "second / third symbol is frequent), or 2 code planes, the other rows as escape keys; positions where neither pays keep 3 identity planes"),
+    2: "adaptive code planes: 2 planes per position (codes 1..3 = the 3 most frequent valid symbols) with the other rows as escape keys",
+    3: "bit-sliced identity planes: 3 code planes per position instead of 5 one-hot symbol planes",
+}
+
+
+def roofline_of(lib, store, window, sequences, kernel_ms, ceiling_gbps):
+    """The roofline block of the line from time_kernel's measurements: the dominant launch (longest by HIP events) by its own
+    bytes and duration, every launch beside it, the whole scan, the algorithmic figure of SURVEY.md section 8(d)."""
+    w8 = 8 * ((sequences + 63) // 64)
+    n_local = window[1] - window[0]
+    physical = scan_bytes(lib, store.handle, 0, n_local, w8)
+    alg_bytes = n_local * 5 * w8 + w8
+    launches = [dict(kernel=v["kernel"], ms=v["ms"], bytes=v["bytes"], GBps=v["bytes"] / (v["ms"] * 1e-3) / 1e9, plane_rows=v["plane_rows"], blocks=v["blocks"])
+                for v in time_kernel.per_launch]
+    # the dominant launch = the one that moves the most bytes (a launch on the side stream may LAST longer beside the others without being the work)
+    dominant = max(time_kernel.per_launch, key=lambda v: v["bytes"]) if time_kernel.per_launch else dict(
+        kernel="?", plane_rows=0, bytes=physical["bytes"], ms=kernel_ms, blocks=0, launches=0)
+    achieved = dominant["bytes"] / (dominant["ms"] * 1e-3) / 1e9
+    scan_planes = int(lib.silo_gpu_store_scan_planes(store.handle, 0))
+    # HBM traffic per launch is a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as the
+    # microarchitecture guide prescribes); counters cannot be read from inside this process, so the value is the one on file
+    # for exactly this launch shape — labelled with its source — or null.
+    traffic, traffic_source = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for key, entry in pmc["kernels"].items():
+            name, _, grid = key.rpartition("@")
+            if name == dominant["kernel"] and grid == str(dominant["blocks"]) and entry.get("sequences") == sequences and entry.get("bytes") == dominant["bytes"]:
+                traffic = entry["hbm_bytes"]
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "stream_ceiling_GBps": ceiling_gbps,
+        "frac_of_ceiling": achieved / ceiling_gbps if ceiling_gbps else None,
+        "kernel": dominant["kernel"],
+        "kernel_ms": dominant["ms"],
+        "kernel_launches_timed": dominant.get("launches", 0),
+        "kernel_bytes_per_launch": dominant["bytes"],
+        "launches_per_scan": launches,
+        "scan_ms": kernel_ms,
+        "scan_physical": physical,
+        "scan_GBps": physical["bytes"] / (kernel_ms * 1e-3) / 1e9,
+        "scan_frac": physical["bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_scan": alg_bytes,
+        "algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+        "byte_reduction": alg_bytes / physical["bytes"],
+        "plane_rows_per_position": physical["plane_rows"] / max(1, n_local),
+        "layout": LAYOUT_TEXT.get(scan_planes, LAYOUT_TEXT[3]),
+        "note": "frac = the dominant launch's own bytes / its own duration / peak; algorithmic bytes / time exceeds the peak precisely because the "
+                "scan moves `byte_reduction` x fewer bytes than the one-hot model of SURVEY.md section 8(d); `also_identity_planes` is the same "
+                "query where nothing of that applies (the floor)",
+    }
+
+
+def stream_ceiling(lib, gigabytes=8, reps=5):
+    """Measured plain stream-read rate of this device in GB/s (silo_gpu_stream_read_probe: a uint64 sum kernel, 16-byte non-temporal loads)."""
+    import ctypes
+
+    from silo_amd import binding
+
+    ms = ctypes.c_float()
+    size = int(gigabytes * 1e9)
+    binding._check(lib.silo_gpu_stream_read_probe(size, reps, ctypes.byref(ms)))
+    return (size & ~15) / (ms.value * 1e-3) / 1e9
 
 
 def cpu_share():
@@ -235,18 +335,23 @@ def cpu_baseline(model, tree, lineage, n_sequences, store, filt, budget_position
 
 
 def filter_query(model, tree, variant=0):
-    """BASELINE.json configs[2] / SURVEY.md §8d C3: And(Or(8 eq), N-Of(3 of 8 eq), Not(Or(8 eq)), Maybe(And(8 eq)))
+    """BASELINE.json configs[2] / SURVEY.md section 8d C3: And(Or(8 eq), N-Of(3 of 8 eq), Not(Or(8 eq)), Maybe(And(8 eq)))
     over 32 distinct (position, symbol) leaves at the positions where most sequences carry a substitution.
     variant k > 0: the same tree over the NEXT 32 positions of that ranking (leaves distinct from every other variant's:
-    a batch of variants reads Q x 32 different columns, so its bytes really come from HBM, not from a cache)."""
+    a batch of variants reads Q x 32 different columns, so its bytes really come from HBM, not from a cache).  Those
+    positions are substituted in small, unrelated lineages — eight of their substitutions under And select nothing —, so
+    there the leaves under N-Of and Maybe(And) ask for the REFERENCE symbol of their position (most rows have it) and the
+    substitutions stay under Or and Not(Or): every variant selects rows, and its count is checked (tests/test_configs_gpu.py)."""
     carried = model.lineage_symbol != 0xFF                      # [P][L]
     weight = carried.astype(np.float64) @ tree.weights          # share of sequences substituted per position
     positions = np.argsort(-weight, kind="stable")[32 * variant:32 * variant + 32]
     assert len(positions) == 32 and carried[positions].any(axis=1).all(), "not enough substituted positions for this variant"
     leaves = []
-    for p in positions:
+    for k, p in enumerate(positions):
         lineages = np.nonzero(carried[p])[0]
         symbol = int(model.lineage_symbol[p][lineages[np.argmax(tree.weights[lineages])]])
+        if variant > 0 and (k < 8 or 16 <= k < 24):
+            symbol = int(model.reference[p])
         leaves.append({"type": "NucleotideEquals", "position": int(p) + 1, "symbol": "-ACGT"[symbol]})
     # leaves are sorted by how many sequences carry them: the most common 8 go under Maybe(And), the rarest 8 under Not(Or)
     return json.dumps({
@@ -453,11 +558,9 @@ def batch_workload(engine, positions, n_sequences, sync, reps=5):
     }
 
 
-def config4_workload(engine, tree, reference_text, positions, aa_positions, n_sequences, sync, reps=3):
-    """BASELINE.json configs[4] as ONE of its 8 sequence-id shards sees it (50 M sequences over 8 GPUs = 6.25 M rows per
-    GPU, genome + genes resident): one silo_engine_execute_batch of 100 distinct lineage filters (every fourth AND a
-    nucleotide predicate), each with a Mutations and an AminoAcidMutations action — 200 queries whose scans share passes
-    over the planes, 8 filters at a time (K1c).  The all-reduce of the count tables across shards is not part of it."""
+def config4_queries(tree, reference_text):
+    """BASELINE.json configs[4]: 100 distinct lineage filters (every fourth AND a nucleotide predicate), each with a Mutations
+    and an AminoAcidMutations action — 200 queries."""
     queries = []
     for k, name in enumerate(tree.names[1:101]):
         expression = {"type": "PangoLineage", "column": "pango_lineage", "value": name, "includeSublineages": True}
@@ -466,6 +569,15 @@ def config4_workload(engine, tree, reference_text, positions, aa_positions, n_se
             expression = {"type": "And", "children": [expression, {"type": "NucleotideEquals", "position": position, "symbol": reference_text[position - 1]}]}
         for action in ("Mutations", "AminoAcidMutations"):
             queries.append(json.dumps({"action": {"type": action, "minProportion": 0.05}, "filterExpression": expression}).encode())
+    return queries
+
+
+def config4_workload(engine, tree, reference_text, positions, aa_positions, total_sequences, world, sync, reps=3, reduce_max=None):
+    """BASELINE.json configs[4]: `total_sequences` sequences (genome + 12 genes) sharded by sequence id over `world` GPUs (this
+    engine holds this rank's rows), ONE silo_engine_execute_batch of the 200 queries: their scans share passes over the
+    planes, 8 filters at a time (K1c); with more than one rank every count table is all-reduced (one collective per
+    query, enqueued on the engine's stream)."""
+    queries = config4_queries(tree, reference_text)
     batched = engine.execute_batch_text(queries)
     if batched[:6] != [engine.execute_text(q) for q in queries[:6]] or any(status != 200 for status, _ in batched):
         raise AssertionError("batched results differ from one-by-one results")
@@ -475,14 +587,21 @@ def config4_workload(engine, tree, reference_text, positions, aa_positions, n_se
         engine.execute_batch_text(queries)
     sync()
     seconds = (time.perf_counter() - t0) / reps
+    if reduce_max is not None:
+        seconds = reduce_max(seconds)
+    rows = sum(len(json.loads(body.decode())["queryResult"]) for _, body in batched)
     return {
-        "workload": f"BASELINE.json configs[4], one of 8 sequence-id shards: {n_sequences} sequences (genome + 12 genes), ONE batch of 100 lineage filters "
-                    "(every fourth AND a nucleotide predicate) x (Mutations + AminoAcidMutations) = 200 queries; no collective",
+        "workload": f"BASELINE.json configs[4]: {total_sequences} sequences (genome + 12 genes) "
+                    + (f"sharded by sequence id over {world} GPUs, " if world > 1 else "on the one GPU, ")
+                    + "ONE batch of 100 lineage filters (every fourth AND a nucleotide predicate) x (Mutations + AminoAcidMutations) = 200 queries"
+                    + ("; one all-reduce per count table" if world > 1 else ""),
         "queries": len(queries),
         "ms_per_batch": seconds * 1e3,
-        "value": (len(queries) // 2) * n_sequences * (positions + aa_positions) / seconds,
+        "value": (len(queries) // 2) * total_sequences * (positions + aa_positions) / seconds,
         "unit": "positions*sequences/s",
+        "scaling": "strong",
         "queries_per_s": len(queries) / seconds,
+        "mutation_rows": rows,
     }
 
 
@@ -602,8 +721,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sequences", type=int, default=10_000_000)
+    ap.add_argument("--shard", choices=["both", "position", "sequence"], default="both",
+                    help="N > 1: the headline database sharded by position range (the north star's split; always measured, it is `value`), "
+                         "BASELINE.json configs[4] sharded by sequence id, or both (default)")
+    ap.add_argument("--config4-sequences", type=int, default=50_000_000, help="sequences of the configs[4] database (all ranks together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (1 M sequences) measurement at N=1")
+    ap.add_argument("--no-also", action="store_true", help="the headline measurement only: no further legs")
     ap.add_argument("--no-client-threads", action="store_true",
                     help="skip the config-2 filter-query legs (8 / 16 client threads; > 100 000 launches make a kernel trace large)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -687,59 +810,42 @@ def main():
         def sync():
             dist.barrier()
             torch.cuda.synchronize()
+
+        def reduce_max(seconds):
+            t = torch.tensor([seconds], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
     else:
         def sync():
             binding._check(lib.silo_gpu_stream_synchronize(None))
 
+        def reduce_max(seconds):
+            return seconds
+
+    collective = ("through gloo and host memory (one-GPU rehearsal)" if comm is None else "by silo_gpu_allreduce_counts (native ncclAllReduce on the engine stream)")
     t0 = time.time()
-    # N = 1: ONE database with the nucleotide genome AND the 12 genes resident together (BASELINE.json configs[3] on one GPU);
-    # N > 1: the nucleotide genome, position-range sharded
-    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank, use_dist, with_genes=(world == 1 and not use_dist))
+    # ONE database with the nucleotide genome AND the 12 genes resident together (BASELINE.json configs[3]); N > 1: sharded
+    # by position range — every rank holds all rows for its window of the genome and of every gene
+    engine, model, tree, lineage, window = build_engine(args.sequences, rank, world, all_reduce, local_rank, use_dist, with_genes=True)
     log(f"[rank {rank}] store ready in {time.time() - t0:.1f}s: {args.sequences} sequences, positions {window}, "
         f"{engine.partition_store(0).device_bytes / 1e9:.1f} GB in HBM")
     query = make_query()
     positions = model.positions
+    genes = load_reference_genomes(True)["genes"]
+    aa_positions = sum(len(g["sequence"]) for g in genes)
+    aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
+                           "filterExpression": json.loads(query)["filterExpression"]})
 
     elapsed, rows = run_steps(engine, query, args.steps, args.warmup, sync)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(elapsed)
     filter_us, action_us = engine.last_timings()
     ms_per_step = elapsed / args.steps * 1e3
     value = args.sequences * positions / (elapsed / args.steps)
 
     # roofline of the dominant kernel, on this rank's window
     w8 = 8 * ((args.sequences + 63) // 64)
-    n_local = window[1] - window[0]
     kernel_ms, kernel_name, store, filt, counts_dev = time_kernel(engine, tree, window, reps=max(5, args.steps))
-    # physical bytes: the plane rows, the filter and the escape keys this launch reads; algorithmic bytes: the layout-
-    # independent figure of SURVEY.md §8(d) — 5 one-hot symbol columns per position plus the filter.
-    scan_planes = int(lib.silo_gpu_store_scan_planes(store.handle, 0))
-    scan_rows = int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, n_local))  # plane rows of the adaptive layout, all positions
-    scan_escapes = int(lib.silo_gpu_store_scan_escapes(store.handle, 0))
-    alg_bytes = n_local * 5 * w8 + w8
-    physical_bytes = scan_rows * w8 + w8 + 8 * scan_escapes          # of the whole scan: every plane-scan launch + the escape pass
-    scan_gbps = physical_bytes / (kernel_ms * 1e-3) / 1e9
-    # the dominant launch by itself (HIP events around that launch): its plane rows, each read once, and the filter row
-    dominant = time_kernel.per_launch[0] if time_kernel.per_launch else dict(kernel=kernel_name, plane_rows=scan_rows, ms=kernel_ms, blocks=0, launches=0)
-    dominant_bytes = dominant["plane_rows"] * w8 + w8
-    physical_gbps = dominant_bytes / (dominant["ms"] * 1e-3) / 1e9
-    # HBM traffic per launch is a PMC figure (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
-    # the microarchitecture guide prescribes); counters cannot be read from inside this process, so the value is the one
-    # on file for exactly this launch shape — labelled with its source — or null.
-    traffic = None
-    traffic_source = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        for key, entry in pmc["kernels"].items():  # same kernel family, same launch shape (grid) as measured here
-            name, _, grid = key.rpartition("@")
-            if name == dominant["kernel"] and grid == str(dominant["blocks"] * 256) and entry.get("sequences") == args.sequences and entry.get("rows") == scan_rows:
-                traffic = entry["hbm_bytes"]
-                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this launch shape in an earlier run; not measured by this run)"
-    except (OSError, ValueError, KeyError):
-        pass
-
+    ceiling = stream_ceiling(lib) if rank == 0 else None
     result = {
         "metric": "Mutations-scan positions*sequences/s",
         "value": value,
@@ -759,92 +865,53 @@ def main():
             "sequences": args.sequences,
             "positions": positions,
             "mutation_rows": len(rows),
-            "sharding": "none" if not use_dist else f"position-range x{world}, all-reduce of counts[{positions}][5] "
-                        + ("through gloo and host memory (one-GPU rehearsal)" if comm is None else "by silo_gpu_allreduce_counts (native ncclAllReduce on the engine stream)"),
+            "sharding": "none" if not use_dist else f"position-range x{world}, all-reduce of counts[{positions}][5] " + collective,
             "reference_phases_us": {"filter": filter_us, "action": action_us},
         },
-        "roofline": {
-            # The dominant kernel of the step — the k_scan_sliced launch over the runs of one-hot rows — by itself:
-            # achieved = the bytes that launch has to read (its plane rows once + the filter row) / its own duration (HIP
-            # events around the launch, on its stream), frac = achieved / peak.  The whole scan of the query (every
-            # plane-scan launch + the escape-key pass) and the layout-independent algorithmic figure of SURVEY.md §8(d)
-            # (5 one-hot symbol columns per position + the filter, 0.625 B per position x sequence) are kept beside it;
-            # algorithmic bytes / time exceeds the peak precisely because the scan moves `byte_reduction` x fewer bytes.
-            "bound": "hbm",
-            "achieved": physical_gbps,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": physical_gbps / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_source,
-            "kernel": dominant["kernel"],
-            "kernel_ms": dominant["ms"],
-            "kernel_launches_timed": dominant["launches"],
-            "kernel_plane_rows": dominant["plane_rows"],
-            "physical_bytes_per_launch": dominant_bytes,
-            "launches_per_scan": [{"kernel": v["kernel"], "ms": v["ms"], "plane_rows": v["plane_rows"], "blocks": v["blocks"]} for v in time_kernel.per_launch],
-            "scan_ms": kernel_ms,
-            "scan_physical_bytes": physical_bytes,
-            "scan_GBps": scan_gbps,
-            "scan_frac": scan_gbps / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_scan": alg_bytes,
-            "algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
-            "byte_reduction": alg_bytes / physical_bytes,
-            "scan_planes_per_position": scan_planes,
-            "plane_rows": scan_rows,
-            "plane_rows_per_position": scan_rows / max(1, n_local),
-            "escape_keys": scan_escapes,
-            "layout": ("adaptive planes, chosen per position at finalize: ONE one-hot row of the position's most frequent valid symbol (two or three "
-                       "rows where a second / third symbol is frequent), or 2 code planes (codes 1..3 = the 3 most frequent), the other rows as "
-                       "escape keys; positions where neither pays keep 3 identity planes" if scan_planes == 1 else
-                       "adaptive code planes: 2 planes per position (codes 1..3 = the 3 most frequent valid symbols of the position) with the other "
-                       "rows as escape keys; positions where that does not pay keep 3 identity planes"
-                       if scan_planes == 2 else "bit-sliced: 3 code planes per position instead of 5 one-hot symbol planes"),
-        },
+        "roofline": roofline_of(lib, store, window, args.sequences, kernel_ms, ceiling),
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ~10-30 s of CPU work in all (build + 6 passes): one partition, one 300-position grain per thread
-        budget = args.cpu_positions
         try:
-            result["cpu_baseline"] = cpu_baseline(model, tree, lineage, args.sequences, store, filt, budget)
+            result["cpu_baseline"] = cpu_baseline(model, tree, lineage, args.sequences, store, filt, args.cpu_positions)
         except AssertionError:
             raise
         except Exception as error:  # the baseline is informational; a failure to build it must not hide the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "positions*sequences/s", "cores": 0, "kind": "port", "sample": f"failed: {error}"}
-    aa_query = json.dumps({"action": {"type": "AminoAcidMutations", "minProportion": 0.05},
-                           "filterExpression": json.loads(query)["filterExpression"]})
-    genes = load_reference_genomes(True)["genes"]
-    aa_positions = sum(len(g["sequence"]) for g in genes)
 
-    def aa_rows(engine):
-        """Plane rows the scan reads per gene (adaptive layout: 2, 3 or 5 per position)."""
+    def aa_physical(engine, window_of=None):
         handle = engine.partition_store(0).handle
-        return {g["name"]: int(lib.silo_gpu_store_scan_rows(handle, engine.seqstore_id(0, g["name"], True), 0, len(g["sequence"]))) for g in genes}
+        total = dict(plane_rows=0, escape_keys=0, missing_runs=0, sparse_keys=0, bytes=0)
+        per_gene = {}
+        for g in genes:
+            begin, end = engine.position_window(g["name"], True)
+            part = scan_bytes(lib, handle, engine.seqstore_id(0, g["name"], True), end - begin, w8)
+            per_gene[g["name"]] = part["plane_rows"]
+            for key in total:
+                total[key] += part[key]
+        return total, per_gene
 
-    def aa_escapes(engine):
-        handle = engine.partition_store(0).handle
-        return sum(int(lib.silo_gpu_store_scan_escapes(handle, engine.seqstore_id(0, g["name"], True))) for g in genes)
-
-    if rank == 0 and world == 1 and not use_dist and not args.no_also:
-        # BASELINE.json configs[3] on ONE GPU: the amino-acid leg on the SAME database (nucleotide genome + 12 genes resident)
-        elapsed_aa_full, rows_aa_full = run_steps(engine, aa_query, args.steps, args.warmup, sync)
-        rows_per_gene = aa_rows(engine)
-        aa_physical = sum(rows_per_gene.values()) * w8 + 12 * w8 + 8 * aa_escapes(engine)
+    if not args.no_also:
+        # BASELINE.json configs[3], amino-acid leg, on the SAME database (N > 1: on its position shards, one all-reduce per query)
+        elapsed_aa, rows_aa = run_steps(engine, aa_query, args.steps, args.warmup, sync)
+        elapsed_aa = reduce_max(elapsed_aa)
+        physical_aa, rows_per_gene = aa_physical(engine)
         result["also_amino_acid_full"] = {
-            "workload": f"AminoAcidMutations over all 12 genes (BASELINE.json configs[3], amino-acid leg) on the same {args.sequences}-sequence database, same filter",
-            "value": args.sequences * aa_positions / (elapsed_aa_full / args.steps),
+            "workload": f"AminoAcidMutations over all 12 genes (BASELINE.json configs[3], amino-acid leg) on the same {args.sequences}-sequence database, same filter"
+                        + (f"; position-range x{world}" if use_dist else ""),
+            "value": args.sequences * aa_positions / (elapsed_aa / args.steps),
             "unit": "positions*sequences/s",
-            "ms_per_step": elapsed_aa_full / args.steps * 1e3,
-            "algorithmic_GBps_whole_query": aa_positions * 22 * w8 / (elapsed_aa_full / args.steps) / 1e9,
+            "ms_per_step": elapsed_aa / args.steps * 1e3,
+            "algorithmic_GBps_whole_query": aa_positions * 22 * w8 / (elapsed_aa / args.steps) / 1e9,
             "plane_rows_per_gene": rows_per_gene,
-            "plane_rows_per_position": sum(rows_per_gene.values()) / aa_positions,
-            "escape_keys": aa_escapes(engine),
-            "physical_GBps_whole_query": aa_physical / (elapsed_aa_full / args.steps) / 1e9,
-            "mutation_rows": len(rows_aa_full),
+            "physical_this_rank": physical_aa,
+            "physical_GBps_whole_query_this_rank": physical_aa["bytes"] / (elapsed_aa / args.steps) / 1e9,
+            "mutation_rows": len(rows_aa),
         }
-        result["config"]["database"] = (f"one database on one GPU: nucleotide genome ({scan_rows} plane rows) + 12 genes ({sum(rows_per_gene.values())} plane rows) "
-                                        f"+ the runs of the missing symbol, {engine.partition_store(0).device_bytes / 1e9:.1f} GB of HBM")
+        result["config"]["database"] = (f"one database: nucleotide genome + 12 genes + the runs of the missing symbol, "
+                                        f"{engine.partition_store(0).device_bytes / 1e9:.1f} GB of HBM" + (" on this rank" if use_dist else " on one GPU"))
+    if rank == 0 and world == 1 and not use_dist and not args.no_also:
         if not args.no_client_threads:
             result["filter_queries"] = filter_workload(engine, model, tree, args.sequences, sync)
         result["batched_queries"] = batch_workload(engine, positions, args.sequences, sync)
@@ -853,32 +920,64 @@ def main():
     lib.silo_gpu_free(counts_dev)
     engine.close()
 
-    if rank == 0 and world == 1 and not args.no_also and args.sequences != 1_000_000:
+    reference_text = load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
+    if not args.no_also and (world == 1 or args.shard in ("both", "sequence")):
+        # BASELINE.json configs[4]: the big database, sharded by sequence id (each rank generates ITS rows), built in two passes
+        per_rank = args.config4_sequences // world
+        t_build = time.perf_counter()
+        engine4, model4, tree4, _, _ = build_engine(per_rank, rank, world, all_reduce, local_rank, use_dist, with_genes=True, two_pass=per_rank > 12_000_000,
+                                                    by_position=False, seed=0x5110C0DE + 7919 * rank)
+        build_seconds = time.perf_counter() - t_build
+        leg = config4_workload(engine4, tree4, reference_text, positions, aa_positions, per_rank * world, world, sync, reps=3, reduce_max=reduce_max)
+        leg["device_GB_this_rank"] = engine4.partition_store(0).device_bytes / 1e9
+        leg["build_seconds"] = build_seconds
+        if use_dist:
+            leg["sharding"] = f"sequence-id x{world} ({per_rank} rows per rank), all-reduce per count table " + collective
+        result["also_config4"] = leg
+        if use_dist and not args.no_client_threads:
+            # filter -> Aggregated on the sequence-id shards: every rank counts its rows, one all-reduce of the count per query
+            wire = filter_query(model4, tree4).encode()
+            count = json.loads(engine4.execute_text(wire)[1].decode())["queryResult"][0]["count"]
+            for _ in range(5):
+                engine4.execute_text(wire)
+            sync()
+            n_queries = 300
+            t0 = time.perf_counter()
+            for _ in range(n_queries):
+                engine4.execute_text(wire)
+            sync()
+            seconds = reduce_max(time.perf_counter() - t0)
+            result["filter_queries"] = {
+                "workload": f"BASELINE.json configs[2] tree -> Aggregated on the {per_rank * world}-sequence database sharded by sequence id x{world}: "
+                            "every rank evaluates the filter on its rows, the counts are all-reduced",
+                "count": count,
+                "latency_us": seconds / n_queries * 1e6,
+                "queries_per_s_1_client": n_queries / seconds,
+            }
+        engine4.close()
+
+    if rank == 0 and world == 1 and not use_dist and not args.no_also and args.sequences != 1_000_000:
         # BASELINE.json configs[1]: 1 M sequences, same query
         engine1, model1, tree1, lineage1, window1 = build_engine(1_000_000, 0, 1, None, local_rank, with_genes=True, with_metadata=True)  # no collective
         elapsed1, rows1 = run_steps(engine1, query, args.steps, args.warmup, sync)
-        # the amino-acid leg at 1 M sequences
-        elapsed_aa, rows_aa = run_steps(engine1, aa_query, args.steps, args.warmup, sync)
-        aa_bytes = aa_positions * 22 * 8 * ((1_000_000 + 63) // 64)
+        elapsed_aa1, rows_aa1 = run_steps(engine1, aa_query, args.steps, args.warmup, sync)
         result["also_amino_acid"] = {
             "workload": "AminoAcidMutations over all 12 genes (BASELINE.json configs[3], amino-acid leg), 1000000 sequences, same filter",
-            "value": 1_000_000 * aa_positions / (elapsed_aa / args.steps),
+            "value": 1_000_000 * aa_positions / (elapsed_aa1 / args.steps),
             "unit": "positions*sequences/s",
-            "ms_per_step": elapsed_aa / args.steps * 1e3,
-            "algorithmic_GBps_whole_query": aa_bytes / (elapsed_aa / args.steps) / 1e9,
-            "physical_GBps_whole_query": sum(aa_rows(engine1).values()) * 8 * ((1_000_000 + 63) // 64) / (elapsed_aa / args.steps) / 1e9,
-            "mutation_rows": len(rows_aa),
+            "ms_per_step": elapsed_aa1 / args.steps * 1e3,
+            "mutation_rows": len(rows_aa1),
         }
-        kernel_ms1, _, _, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
-        w81 = 8 * ((1_000_000 + 63) // 64)
-        alg1 = positions * 5 * w81 + w81
+        kernel_ms1, _, store1, filt1, counts1 = time_kernel(engine1, tree1, window1, reps=max(5, args.steps))
+        roofline1 = roofline_of(lib, store1, window1, 1_000_000, kernel_ms1, ceiling)
         result["also"] = {
             "workload": "BASELINE.json configs[1]: 1000000 sequences, same query",
             "value": 1_000_000 * positions / (elapsed1 / args.steps),
             "ms_per_step": elapsed1 / args.steps * 1e3,
-            "kernel_ms": kernel_ms1,
-            "roofline_frac": (int(lib.silo_gpu_store_scan_rows(engine1.partition_store(0).handle, 0, 0, positions)) * w81 + w81) / (kernel_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "algorithmic_GBps": alg1 / (kernel_ms1 * 1e-3) / 1e9,
+            "scan_ms": kernel_ms1,
+            "scan_frac": roofline1["scan_frac"],
+            "dominant_kernel": roofline1["kernel"],
+            "dominant_kernel_frac": roofline1["frac"],
             "mutation_rows": len(rows1),
         }
         result["also_metadata"] = metadata_workload(engine1, 1_000_000, sync)
@@ -886,7 +985,41 @@ def main():
         lib.silo_gpu_free(counts1)
         engine1.close()
         if args.sequences == 10_000_000:
-            # the same query where the rows lie in lineage order: column tiles without a selected row are not read
+            # What the headline degrades to when the data is not alignment-like: the same store kept on its 3 identity planes per
+            # position (nothing derived, no one-hot rows: the floor), and the layout of round 2 (a one-hot row for the most
+            # numerous symbol too) — the same query, the same rows.
+            for label, knob, text in (("also_identity_planes", -1, "3 identity code planes per position, every cell read (the floor: what the query costs when no "
+                                                                    "position has a dominant symbol)"),
+                                      ("also_one_hot_rows", 3, "a one-hot row for the most numerous symbol of every position too (nothing derived: the layout of round 2)")):
+                previous = lib.silo_gpu_tune(4, knob)
+                try:
+                    engine_k, _, tree_k, _, window_k = build_engine(args.sequences, 0, 1, None, local_rank)
+                finally:
+                    lib.silo_gpu_tune(4, previous)
+                elapsed_k, rows_k = run_steps(engine_k, query, max(5, args.steps // 2), args.warmup, sync)
+                if rows_k != rows:
+                    raise AssertionError(f"{label}: the rows differ from the headline's")
+                kernel_ms_k, _, store_k, filt_k, counts_k = time_kernel(engine_k, tree_k, window_k, reps=5)
+                roofline_k = roofline_of(lib, store_k, window_k, args.sequences, kernel_ms_k, ceiling)
+                result[label] = {
+                    "workload": f"the headline query on the {args.sequences}-sequence genome stored as: {text}",
+                    "value": args.sequences * positions / (elapsed_k / max(5, args.steps // 2)),
+                    "unit": "positions*sequences/s",
+                    "ms_per_step": elapsed_k / max(5, args.steps // 2) * 1e3,
+                    "device_GB": store_k.device_bytes / 1e9,
+                    "scan_ms": kernel_ms_k,
+                    "scan_physical_bytes": roofline_k["scan_physical"]["bytes"],
+                    "scan_frac": roofline_k["scan_frac"],
+                    "dominant_kernel": roofline_k["kernel"],
+                    "dominant_kernel_ms": roofline_k["kernel_ms"],
+                    "dominant_kernel_frac": roofline_k["frac"],
+                    "dominant_kernel_frac_of_ceiling": roofline_k["frac_of_ceiling"],
+                    "mutation_rows": len(rows_k),
+                }
+                lib.silo_gpu_free(filt_k)
+                lib.silo_gpu_free(counts_k)
+                engine_k.close()
+            # the same query where the rows lie in lineage order: column tiles and key slices without a selected row are not read
             engine_sorted, _, _, _, _ = build_engine(args.sequences, 0, 1, None, local_rank, lineage_order=True)
             elapsed_sorted, rows_sorted = run_steps(engine_sorted, query, args.steps, args.warmup, sync)
             result["also_rows_in_lineage_order"] = {
@@ -898,28 +1031,6 @@ def main():
                 "mutation_rows": len(rows_sorted),
             }
             engine_sorted.close()
-            # how far one GPU goes: 25 M sequences, the genome built in two passes (counted, then written straight into the
-            # adaptive planes: the 3 build-time planes per position would not fit beside the finished store)
-            big_n = 25_000_000
-            t_build = time.perf_counter()
-            engine_big, _, _, _, _ = build_engine(big_n, 0, 1, None, local_rank, two_pass=True)
-            build_seconds = time.perf_counter() - t_build
-            elapsed_big, rows_big = run_steps(engine_big, query, max(5, args.steps // 2), args.warmup, sync)
-            result["also_25m_sequences"] = {
-                "workload": f"the headline query on {big_n} sequences x {positions} nt on the same single GPU, the store built in two passes of the generator "
-                            "(silo_gpu_store_build_pass: no build-time planes)",
-                "value": big_n * positions / (elapsed_big / max(5, args.steps // 2)),
-                "unit": "positions*sequences/s",
-                "ms_per_step": elapsed_big / max(5, args.steps // 2) * 1e3,
-                "device_GB": engine_big.partition_store(0).device_bytes / 1e9,
-                "build_seconds": build_seconds,
-                "mutation_rows": len(rows_big),
-            }
-            engine_big.close()
-            engine4, _, tree4, _, _ = build_engine(6_250_000, 0, 1, None, local_rank, with_genes=True)
-            reference_text = load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
-            result["also_config4_shard"] = config4_workload(engine4, tree4, reference_text, positions, aa_positions, 6_250_000, sync)
-            engine4.close()
 
     if use_dist:
         dist.barrier()

@@ -481,18 +481,26 @@ int silo_gpu_broadcast_bytes(silo_gpu_comm* comm, void* bytes_dev, size_t n_byte
 /* Name of the last kernel variant silo_gpu_mutations_scan launched (for roofline attribution). */
 const char* silo_gpu_last_scan_kernel(void);
 
-/* Per-launch timing of the plane scans (measurement only).  With SILO_GPU_TUNE_SCAN_TIMING set to 1, every k_scan_sliced
- * launch of the calling thread's scans is bracketed by HIP events on the stream it is launched on; this call waits for the
+/* Per-launch timing of a scan (measurement only).  With SILO_GPU_TUNE_SCAN_TIMING set to 1, every k_scan_sliced,
+ * k_scan_escapes_sliced, k_scan_missing_runs and k_count_sparse_keys launch of the calling thread's scans is bracketed by HIP
+ * events on the stream it is launched on; this call waits for the
  * events of that thread's LAST scan and returns one entry per launch (at most `capacity`; *n_out = launches).  plane_rows =
  * plane rows the launch streams (each once, row_words * 8 bytes), filters = filter rows it holds in registers. */
 typedef struct silo_gpu_scan_timing {
    char kernel[64];       /* e.g. "k_scan_sliced<2, 2, 8, 1, 2>", as rocprofv3 names it */
-   uint64_t plane_rows;
+   uint64_t plane_rows;   /* plane rows a k_scan_sliced launch streams (0 for the other kernels) */
+   uint64_t bytes;        /* what the launch has to read, each byte once: plane rows + filter rows; 8 bytes per escape key (+ a filter
+                             slice per block); 12 bytes per run of the missing symbol; 8 per sparse key */
    uint32_t filters;
    uint32_t blocks;
    float ms;
 } silo_gpu_scan_timing;
 int silo_gpu_scan_timings(silo_gpu_scan_timing* out, uint32_t capacity, uint32_t* n_out);
+
+/* The achievable HBM read rate of this device (measurement only; SURVEY.md section 8(d): "also measure an achievable-stream-read
+ * ceiling with a plain uint64 sum kernel"): allocates `bytes` of device memory, sums it `reps` times with 16-byte non-temporal
+ * loads (8 in flight per lane) and returns the average duration of one pass in *out_ms_per_pass (HIP events, null stream). */
+int silo_gpu_stream_read_probe(uint64_t bytes, uint32_t reps, float* out_ms_per_pass);
 
 /* Thread-local description of the last error. */
 const char* silo_gpu_last_error(void);

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -3361,6 +3362,41 @@ ScanTimingLog& scanTimingLog() {
    return log;
 }
 
+/// With SILO_GPU_TUNE_SCAN_TIMING set: an entry of the thread's timing log with its start event recorded on `stream` (the
+/// stream the launch that follows goes to); nullptr otherwise.  `bytes` = what the launch has to read, each byte once.
+ScanLaunchTiming* startLaunchTiming(const char* kernel, uint64_t plane_rows, uint64_t bytes, uint32_t filters, uint32_t blocks, hipStream_t stream) {
+   if (g_tune_scan_timing.load() != 1) {
+      return nullptr;
+   }
+   ScanTimingLog& log = scanTimingLog();
+   if (log.used == log.launches.size()) {
+      ScanLaunchTiming fresh;
+      if (hipEventCreate(&fresh.start) != hipSuccess || hipEventCreate(&fresh.stop) != hipSuccess) {
+         (void)hipGetLastError();
+         return nullptr;
+      }
+      log.launches.push_back(fresh);
+   }
+   ScanLaunchTiming* timing = &log.launches[log.used++];
+   std::snprintf(timing->entry.kernel, sizeof(timing->entry.kernel), "%s", kernel);
+   timing->entry.plane_rows = plane_rows;
+   timing->entry.bytes = bytes;
+   timing->entry.filters = filters;
+   timing->entry.blocks = blocks;
+   if (hipEventRecord(timing->start, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      --log.used;
+      return nullptr;
+   }
+   return timing;
+}
+
+void finishLaunchTiming(ScanLaunchTiming* timing, hipStream_t stream) {
+   if (timing != nullptr) {
+      (void)hipEventRecord(timing->stop, stream);
+   }
+}
+
 /// Launches k_scan_sliced for the `q_count` filters and the pieces already entered in `batch` (planes, n_positions, counts).
 template <int BITS, int NSYM, int KIND>
 int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count, hipStream_t hip_stream) {
@@ -3404,25 +3440,13 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    const dim3 grid(batch.first_unit[batch.n_ranges]);
    ScanLaunchTiming* timing = nullptr;
    if (g_tune_scan_timing.load() == 1) {
-      ScanTimingLog& log = scanTimingLog();
-      if (log.used == log.launches.size()) {
-         ScanLaunchTiming fresh;
-         if (hipEventCreate(&fresh.start) == hipSuccess && hipEventCreate(&fresh.stop) == hipSuccess) {
-            log.launches.push_back(fresh);
-         }
+      uint64_t plane_rows = 0;
+      for (uint32_t r = 0; r < batch.n_ranges; ++r) {
+         plane_rows += KIND == KIND_ROWS ? batch.n_positions[r] : static_cast<uint64_t>(batch.n_positions[r]) * BITS;
       }
-      if (log.used < log.launches.size()) {
-         timing = &log.launches[log.used++];
-         uint64_t plane_rows = 0;
-         for (uint32_t r = 0; r < batch.n_ranges; ++r) {
-            plane_rows += KIND == KIND_ROWS ? batch.n_positions[r] : static_cast<uint64_t>(batch.n_positions[r]) * BITS;
-         }
-         std::snprintf(timing->entry.kernel, sizeof(timing->entry.kernel), "k_scan_sliced<%d, %d, %d, %u, %d>", BITS, NSYM, wide ? 8 : 4, wide ? 1u : std::min(q_count, 8u), KIND);
-         timing->entry.plane_rows = plane_rows;
-         timing->entry.filters = q_count;
-         timing->entry.blocks = grid.x;
-         HIP_TRY(hipEventRecord(timing->start, hip_stream));
-      }
+      char name[64];
+      std::snprintf(name, sizeof(name), "k_scan_sliced<%d, %d, %d, %u, %d>", BITS, NSYM, wide ? 8 : 4, wide ? 1u : std::min(q_count, 8u), KIND);
+      timing = startLaunchTiming(name, plane_rows, (plane_rows + q_count) * row_words * sizeof(uint64_t), q_count, grid.x, hip_stream);
    }
 #define SILO_LAUNCH_SLICED(WPT, Q) \
    k_scan_sliced<BITS, NSYM, WPT, Q, KIND><<<grid, SCAN_THREADS, 0, hip_stream>>>(batch, row_words, positions_per_block, n_tiles)
@@ -3451,9 +3475,7 @@ int launchSlicedScan(ScanBatchArgs& batch, uint32_t row_words, uint32_t q_count,
    }
 #undef SILO_LAUNCH_SLICED
    HIP_TRY(hipGetLastError());
-   if (timing != nullptr) {
-      HIP_TRY(hipEventRecord(timing->stop, hip_stream));
-   }
+   finishLaunchTiming(timing, hip_stream);
    return SILO_GPU_OK;
 }
 
@@ -3682,6 +3704,13 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       const uint32_t block_keys = static_cast<uint32_t>(std::min<double>(chunk_keys * ESCAPE_CHUNKS_PER_BLOCK, std::max<double>(2048.0, fitting))) & ~1u;
       sliced.block_keys = block_keys;
       const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
+      char name[64];
+      std::snprintf(name, sizeof(name), "k_scan_escapes_sliced<%u, true>", per_block);
+      // bytes: the keys once per pass of `per_block` filters, plus a 16 KiB filter slice per block and filter
+      ScanLaunchTiming* timing = startLaunchTiming(
+         name, 0, total_keys * sizeof(uint64_t) * grid.z + static_cast<uint64_t>(grid.x) * grid.y * q_count * ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), q_count,
+         grid.x * grid.y * grid.z, hip_stream
+      );
       switch (per_block) {
          case 1:
             if (g_tune_scan_variant.load() == 30) {
@@ -3695,6 +3724,7 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          default: k_scan_escapes_sliced<8><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<8>(), hip_stream>>>(sliced, q_count); break;
       }
       HIP_TRY(hipGetLastError());
+      finishLaunchTiming(timing, hip_stream);
       n_sliced = 0;
       most_keys = 0;
       total_keys = 0;
@@ -3758,6 +3788,7 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
 struct DerivedPlan {
    std::vector<DerivedArgs> launches;     // ranges [16 k, 16 k + 16) of the scan
    std::vector<ScanRange> private_ranges;  // the ranges with their count tables replaced by the private ones
+   std::vector<std::array<uint64_t, DERIVED_MAX_RANGES>> run_counts;  // [launch][range] runs of the missing symbol of the range's store (for the timing log)
    size_t table_words = 0;
    uint32_t most_positions = 0;  // of a range with derived symbols
 };
@@ -3766,6 +3797,7 @@ struct DerivedPlan {
 void planDerived(const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, DerivedPlan& plan) {
    plan.private_ranges = ranges;
    plan.launches.assign((ranges.size() + DERIVED_MAX_RANGES - 1) / DERIVED_MAX_RANGES, DerivedArgs{});
+   plan.run_counts.assign(plan.launches.size(), {});
    size_t offset = 0;
    for (size_t r = 0; r < ranges.size(); ++r) {
       const ScanRange& range = ranges[r];
@@ -3780,6 +3812,7 @@ void planDerived(const silo_gpu_store* store, const std::vector<ScanRange>& rang
       entry.scratch = reinterpret_cast<uint32_t*>(offset * sizeof(uint32_t));  // + the scratch block's tables (bindDerived)
       offset += static_cast<size_t>(entry.stride) * q_count;
       if (seqstore.layout.has_implicit) {
+         plan.run_counts[r / DERIVED_MAX_RANGES][launch.n_ranges - 1] = seqstore.dev.n_missing_runs;
          entry.code_map = seqstore.layout.d_code_map;
          entry.run_keys = seqstore.dev.missing_run_keys;
          entry.run_ends = seqstore.dev.missing_run_ends;
@@ -3836,20 +3869,31 @@ int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_s
       // one block per CU fits (its LDS): about one round of the 256 CUs over all (slice, range, filter)
       const uint32_t run_units = std::max<uint32_t>(1, launch.n_run_slices * launch.n_ranges * q_count);
       const dim3 run_grid(std::min<uint32_t>(8, std::max<uint32_t>(1, 240 / run_units)), launch.n_run_slices * launch.n_ranges, q_count);
+      uint64_t run_bytes = 0, sparse_bytes = 0;
+      for (uint32_t k = 0; k < launch.n_ranges; ++k) {
+         if (launch.ranges[k].code_map != nullptr) {
+            run_bytes += plan.run_counts[&launch - plan.launches.data()][k] * (sizeof(uint64_t) + sizeof(uint32_t));
+            sparse_bytes += static_cast<uint64_t>(launch.ranges[k].sparse_end - launch.ranges[k].sparse_begin) * sizeof(uint64_t);
+         }
+      }
+      ScanLaunchTiming* run_timing = startLaunchTiming(lds_diff ? "k_scan_missing_runs<true>" : "k_scan_missing_runs<false>", 0, run_bytes * q_count, q_count, run_grid.x * run_grid.y * run_grid.z, hip_stream);
       if (lds_diff) {
          k_scan_missing_runs<true><<<run_grid, DERIVED_THREADS, lds_bytes, hip_stream>>>(launch);
       } else {
          k_scan_missing_runs<false><<<run_grid, DERIVED_THREADS, ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), hip_stream>>>(launch);
       }
       HIP_TRY(hipGetLastError());
+      finishLaunchTiming(run_timing, hip_stream);
       launch.first_unit[0] = 0;
       for (uint32_t k = 0; k < launch.n_ranges; ++k) {
          const uint32_t keys = launch.ranges[k].code_map != nullptr ? launch.ranges[k].sparse_end - launch.ranges[k].sparse_begin : 0;
          launch.first_unit[k + 1] = launch.first_unit[k] + (keys + 256 * SPARSE_KEYS_PER_THREAD - 1) / (256 * SPARSE_KEYS_PER_THREAD);
       }
       if (launch.first_unit[launch.n_ranges] != 0) {
+         ScanLaunchTiming* sparse_timing = startLaunchTiming("k_count_sparse_keys", 0, sparse_bytes * q_count, q_count, launch.first_unit[launch.n_ranges] * q_count, hip_stream);
          k_count_sparse_keys<<<dim3(launch.first_unit[launch.n_ranges], q_count), 256, 0, hip_stream>>>(launch);
          HIP_TRY(hipGetLastError());
+         finishLaunchTiming(sparse_timing, hip_stream);
       }
    }
    return SILO_GPU_OK;
@@ -5384,6 +5428,73 @@ int silo_gpu_row_slot_wait(silo_gpu_row_slot* slot, const silo_gpu_mutation_row*
    }
    *out_selected = static_cast<uint32_t>(value);
    *out_rows = reinterpret_cast<const silo_gpu_mutation_row*>(static_cast<const char*>(slot->host) + 16);
+   return SILO_GPU_OK;
+}
+
+namespace {
+/// Plain stream read: the sum of `n_chunks` 16-byte chunks, 16 non-temporal loads in flight per lane, every block a contiguous
+/// stretch of the buffer — the achievable HBM read rate that SURVEY.md section 8(d) asks the scan to be compared with.
+__global__ __launch_bounds__(256) void k_stream_sum(const uint64_t* __restrict__ data, uint64_t n_chunks, unsigned long long* __restrict__ sink) {
+   constexpr uint32_t IN_FLIGHT = 16;
+   const uint64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
+   const uint64_t begin = static_cast<uint64_t>(blockIdx.x) * per_block;
+   const uint64_t end = min(n_chunks, begin + per_block);
+   uint64_t sum = 0;
+   for (uint64_t base = begin; base < end; base += 256u * IN_FLIGHT) {
+      ulonglong2 value[IN_FLIGHT];
+#pragma unroll
+      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
+         const uint64_t chunk = base + k * 256u + threadIdx.x;
+         value[k] = chunk < end ? loadPlane16<true>(data + chunk * 2u) : make_ulonglong2(0, 0);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
+         sum += value[k].x + value[k].y;
+      }
+   }
+   if (sum == 0x123456789ABCDEFull) {  // (never: keeps the loads alive without a store per thread)
+      atomicAdd(sink, 1ull);
+   }
+}
+}  // namespace
+
+int silo_gpu_stream_read_probe(uint64_t bytes, uint32_t reps, float* out_ms_per_pass) {
+   if (out_ms_per_pass == nullptr || bytes < (1u << 20) || reps == 0) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_stream_read_probe: bad arguments");
+   }
+   uint64_t* data = nullptr;
+   unsigned long long* sink = nullptr;
+   hipEvent_t start = nullptr, stop = nullptr;
+   bytes &= ~uint64_t{15};
+   hipError_t status = hipMalloc(&data, bytes);
+   status = status != hipSuccess ? status : hipMalloc(&sink, sizeof(unsigned long long));
+   status = status != hipSuccess ? status : hipMemset(data, 0x5A, bytes);
+   status = status != hipSuccess ? status : hipMemset(sink, 0, sizeof(unsigned long long));
+   status = status != hipSuccess ? status : hipEventCreate(&start);
+   status = status != hipSuccess ? status : hipEventCreate(&stop);
+   float ms = 0;
+   if (status == hipSuccess) {
+      const uint32_t blocks = 256u * 32u;  // many short blocks: a few rounds of 4-8 blocks of 256 threads per CU
+      k_stream_sum<<<blocks, 256>>>(data, bytes / 16, sink);  // warm-up
+      status = hipEventRecord(start, nullptr);
+      for (uint32_t rep = 0; rep < reps && status == hipSuccess; ++rep) {
+         k_stream_sum<<<blocks, 256>>>(data, bytes / 16, sink);
+         status = hipGetLastError();
+      }
+      status = status != hipSuccess ? status : hipEventRecord(stop, nullptr);
+      status = status != hipSuccess ? status : hipEventSynchronize(stop);
+      status = status != hipSuccess ? status : hipEventElapsedTime(&ms, start, stop);
+   }
+   (void)hipFree(data);
+   (void)hipFree(sink);
+   if (start != nullptr) {
+      (void)hipEventDestroy(start);
+   }
+   if (stop != nullptr) {
+      (void)hipEventDestroy(stop);
+   }
+   HIP_TRY(status);
+   *out_ms_per_pass = ms / static_cast<float>(reps);
    return SILO_GPU_OK;
 }
 

@@ -70,8 +70,8 @@ class RoaringPayload(ctypes.Structure):
 
 class ScanTiming(ctypes.Structure):
     """silo_gpu_scan_timing: one plane-scan launch of the thread's last Mutations scan."""
-    _fields_ = [("kernel", ctypes.c_char * 64), ("plane_rows", ctypes.c_uint64), ("filters", ctypes.c_uint32), ("blocks", ctypes.c_uint32),
-                ("ms", ctypes.c_float)]
+    _fields_ = [("kernel", ctypes.c_char * 64), ("plane_rows", ctypes.c_uint64), ("bytes", ctypes.c_uint64), ("filters", ctypes.c_uint32),
+                ("blocks", ctypes.c_uint32), ("ms", ctypes.c_float)]
 
 
 def scan_timings(capacity=64):
@@ -80,7 +80,8 @@ def scan_timings(capacity=64):
     out = (ScanTiming * capacity)()
     n = ctypes.c_uint32()
     _check(lib.silo_gpu_scan_timings(out, capacity, ctypes.byref(n)))
-    return [dict(kernel=out[k].kernel.decode(), plane_rows=int(out[k].plane_rows), filters=int(out[k].filters), blocks=int(out[k].blocks), ms=float(out[k].ms))
+    return [dict(kernel=out[k].kernel.decode(), plane_rows=int(out[k].plane_rows), bytes=int(out[k].bytes), filters=int(out[k].filters), blocks=int(out[k].blocks),
+                 ms=float(out[k].ms))
             for k in range(min(capacity, n.value))]
 
 
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "silo_gpu_malloc", "silo_gpu_memcpy_d2h", "silo_gpu_memcpy_h2d", "silo_gpu_stream_synchronize", "silo_gpu_stream_create", "silo_gpu_set_device", "silo_gpu_stream_destroy", "silo_gpu_store_plane",
     "silo_gpu_store_sparse_plane", "silo_gpu_filter_eval", "silo_gpu_filter_eval_batch", "silo_gpu_popcount", "silo_gpu_mutations_scan", "silo_gpu_mutations_scan_batch", "silo_gpu_mutations_scan_ranges", "silo_gpu_store_scan_planes", "silo_gpu_store_scan_escapes", "silo_gpu_store_scan_rows", "silo_gpu_store_scan_runs", "silo_gpu_row_slot_create", "silo_gpu_row_slot_destroy", "silo_gpu_mutations_select_to_slot", "silo_gpu_row_slot_wait", "silo_gpu_store_scan_sparse_keys", "silo_gpu_store_finalize_seqstore", "silo_gpu_store_build_pass", "silo_gpu_store_build_mode", "silo_gpu_store_memory_info", "silo_gpu_store_import_position", "silo_gpu_store_import_missing_rows",
     "silo_gpu_memset_async", "silo_gpu_event_create", "silo_gpu_event_record", "silo_gpu_event_elapsed_ms",
-    "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_scan_timings", "silo_gpu_last_error",
+    "silo_gpu_event_destroy", "silo_gpu_event_synchronize", "silo_gpu_host_alloc", "silo_gpu_host_free", "silo_gpu_memcpy_d2h_async", "silo_gpu_mutations_select", "silo_gpu_upload_bytes", "silo_gpu_upload_column", "silo_gpu_bitset_from_compare", "silo_gpu_group_count", "silo_gpu_group_count_hashed", "silo_gpu_reconstruct_sequences", "silo_gpu_bitset_from_pairs", "silo_gpu_count_pairs", "silo_gpu_count_slot_create", "silo_gpu_count_slot_destroy", "silo_gpu_filter_eval_count", "silo_gpu_count_slot_wait", "silo_gpu_tune", "silo_gpu_last_scan_kernel", "silo_gpu_scan_timings", "silo_gpu_stream_read_probe", "silo_gpu_last_error",
     "silo_gpu_comm_unique_id", "silo_gpu_comm_create", "silo_gpu_comm_destroy", "silo_gpu_comm_rank", "silo_gpu_comm_world",
     "silo_gpu_allreduce_counts", "silo_gpu_broadcast_bytes",
 ]
@@ -186,9 +187,11 @@ def load_library():
     lib.silo_gpu_scan_timings.argtypes = [ctypes.POINTER(ScanTiming), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     lib.silo_gpu_scan_timings.restype = ctypes.c_int
     lib.silo_gpu_last_error.restype = ctypes.c_char_p
+    lib.silo_gpu_stream_read_probe.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float)]
+    lib.silo_gpu_stream_read_probe.restype = ctypes.c_int
     lib.silo_gpu_store_scan_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     lib.silo_gpu_store_scan_rows.restype = ctypes.c_uint64
-    for name in ("silo_gpu_store_scan_runs", "silo_gpu_row_slot_create", "silo_gpu_row_slot_destroy", "silo_gpu_mutations_select_to_slot", "silo_gpu_row_slot_wait", "silo_gpu_store_scan_sparse_keys"):
+    for name in ("silo_gpu_store_scan_runs", "silo_gpu_store_scan_sparse_keys"):
         getattr(lib, name).argtypes = [vp, ctypes.c_uint32]
         getattr(lib, name).restype = ctypes.c_uint64
     lib.silo_gpu_store_finalize_seqstore.argtypes = [vp, ctypes.c_uint32]

@@ -120,19 +120,12 @@ def leaf_plane(engine, expression):
     return words
 
 
-def test_config2_tree_at_10m_equals_numpy_over_its_leaf_planes(full_store):
-    engine, model, tree, lineage = full_store
-    expression = json.loads(bench.filter_query(model, tree))["filterExpression"]
-    or8, nof, not_or8, maybe_and8 = expression["children"]
-    plain = [leaf_plane(engine, leaf) for leaf in or8["children"] + nof["children"] + not_or8["child"]["children"]]
-    upper = [leaf_plane(engine, {"type": "Maybe", "child": leaf}) for leaf in maybe_and8["child"]["children"]]
-
-    # the leaf planes against the CPU twin of the generator, on a sample of rows
+def check_leaf_planes_against_the_generator(model, all_leaves, plain, upper):
+    """24 plain leaf planes + 8 planes under Maybe against the CPU twin of the generator (oracle/synth.py) on 60 000 sampled rows."""
     rng = np.random.default_rng(5)
     rows = np.unique(rng.integers(0, FULL_N, size=60_000))
     ambiguity = {s: set(codes) for s, codes in enumerate([[0], [1, 5, 10, 8, 12, 13, 14, 15], [2, 6, 10, 7, 11, 13, 14, 15], [3, 5, 9, 7, 11, 12, 14, 15],
                                                          [4, 6, 9, 8, 11, 12, 13, 15]])}  # nucleotide_symbol_equals.cpp:28-73
-    all_leaves = or8["children"] + nof["children"] + not_or8["child"]["children"] + maybe_and8["child"]["children"]
     positions = np.array([leaf["position"] - 1 for leaf in all_leaves])
     symbols = oracle_synth.symbol_matrix(model, rows, positions)  # [rows][32]
     for k, leaf in enumerate(all_leaves):
@@ -142,6 +135,18 @@ def test_config2_tree_at_10m_equals_numpy_over_its_leaf_planes(full_store):
         accepted = {symbol} if k < 24 else ambiguity[symbol]
         want = np.isin(symbols[:, k], list(accepted))
         assert np.array_equal(got.astype(bool), want), leaf
+
+
+def test_config2_tree_at_10m_equals_numpy_over_its_leaf_planes(full_store):
+    engine, model, tree, lineage = full_store
+    expression = json.loads(bench.filter_query(model, tree))["filterExpression"]
+    or8, nof, not_or8, maybe_and8 = expression["children"]
+    plain = [leaf_plane(engine, leaf) for leaf in or8["children"] + nof["children"] + not_or8["child"]["children"]]
+    upper = [leaf_plane(engine, {"type": "Maybe", "child": leaf}) for leaf in maybe_and8["child"]["children"]]
+
+    # the leaf planes against the CPU twin of the generator, on a sample of rows
+    all_leaves = or8["children"] + nof["children"] + not_or8["child"]["children"] + maybe_and8["child"]["children"]
+    check_leaf_planes_against_the_generator(model, all_leaves, plain, upper)
 
     # the tree over the planes, in numpy
     valid = np.zeros(len(plain[0]), dtype=np.uint64)
@@ -165,6 +170,50 @@ def test_config2_tree_at_10m_equals_numpy_over_its_leaf_planes(full_store):
     assert 0 < want_count < FULL_N
     # many of them in one batch (one multi-query launch): every answer the same count
     assert engine.execute_batch([query] * 70) == [(200, {"queryResult": [{"count": want_count}]})] * 70
+
+
+def test_config2_batch_of_64_different_trees_at_10m_equals_numpy(full_store):
+    """The batch that carries BASELINE's second metric (bench.py filter_workload): 64 trees of the config-2 shape over 64 x 32
+    DIFFERENT leaves, as one silo_engine_execute_batch (one k_filter_eval_batch launch).  Every count is checked against the
+    tree evaluated in numpy over the downloaded leaf planes (variants > 0 ask for the reference symbol under N-Of and
+    Maybe(And): planes of DERIVED symbols, rebuilt as "no other symbol and not missing"), and most of them select rows."""
+    engine, model, tree, lineage = full_store
+    valid = None
+    want_counts = []
+    queries = []
+    for variant in range(64):
+        text = bench.filter_query(model, tree, variant)
+        queries.append(json.loads(text))
+        or8, nof, not_or8, maybe_and8 = queries[-1]["filterExpression"]["children"]
+        plain = [leaf_plane(engine, leaf) for leaf in or8["children"] + nof["children"] + not_or8["child"]["children"]]
+        upper = [leaf_plane(engine, {"type": "Maybe", "child": leaf}) for leaf in maybe_and8["child"]["children"]]
+        if variant in (1, 40):  # planes of derived symbols (the reference symbol of a position) against the generator's twin
+            check_leaf_planes_against_the_generator(model, or8["children"] + nof["children"] + not_or8["child"]["children"] + maybe_and8["child"]["children"], plain, upper)
+        if valid is None:
+            valid = np.zeros(len(plain[0]), dtype=np.uint64)
+            valid[: FULL_N // 64] = ~np.uint64(0)
+            if FULL_N % 64:
+                valid[FULL_N // 64] = np.uint64((1 << (FULL_N % 64)) - 1)
+        any_of = np.bitwise_or.reduce(plain[0:8])
+        # at least 3 of 8, with a bit-sliced counter over the words (no per-row array)
+        ones = np.zeros_like(valid)
+        twos = np.zeros_like(valid)
+        fours = np.zeros_like(valid)
+        for plane in plain[8:16]:
+            carry = ones & plane
+            ones ^= plane
+            carry2 = twos & carry
+            twos ^= carry
+            fours |= carry2  # saturates at "4 or more"
+        at_least_3 = fours | (twos & ones)
+        none_of = ~np.bitwise_or.reduce(plain[16:24]) & valid
+        all_maybe = np.bitwise_and.reduce(upper)
+        want = any_of & at_least_3 & none_of & all_maybe
+        want_counts.append(int(np.unpackbits(want.view(np.uint8)).sum()))
+    got = engine.execute_batch(queries)
+    assert got == [(200, {"queryResult": [{"count": count}]}) for count in want_counts]
+    assert sum(1 for count in want_counts if count > 0) >= 32, want_counts
+    assert [engine.execute_query(queries[k]) for k in (1, 17, 63)] == [[{"count": want_counts[k]}] for k in (1, 17, 63)]
 
 
 def scan_table(lib, store, filt, begin, end, seqstore_id=0, n_symbols=5):

@@ -94,7 +94,8 @@ def test_bench_rccl_path_on_one_gpu(built):
     b = json.loads(forced.stdout.strip().splitlines()[-1])
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
     assert b["config"]["sharding"].startswith("position-range x1") and "silo_gpu_allreduce_counts" in b["config"]["sharding"]
-    assert 0.05 < b["roofline"]["frac"] <= 1.0  # physical bytes / time / peak: a fraction
+    assert 0 < b["roofline"]["frac"] <= 1.0  # the dominant launch's bytes / its time / peak: a fraction (small at 200 000 rows)
+    assert b["roofline"]["kernel"] in {entry["kernel"] for entry in b["roofline"]["launches_per_scan"]} and b["roofline"]["stream_ceiling_GBps"] > 1000
 
 
 @pytest.mark.gpu
@@ -167,6 +168,30 @@ def test_bench_two_rank_path_rehearsed_on_one_gpu(built, launcher):
     a, b = json.loads(single.stdout.strip()), json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["sharding"].startswith("position-range x2")
     assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_line_carries_every_leg_of_the_metric(built):
+    """`bench.py --gpus 2` without --no-also (rehearsed on one GPU): beside the position-sharded headline the line carries the
+    amino-acid leg on the position shards, BASELINE.json configs[4] on sequence-id shards (ONE batch of 200 queries, an
+    all-reduce per count table) and the filter queries / s on those shards — the same answers as one rank gives."""
+    root = os.path.dirname(HERE)
+    options = ["--sequences", "200000", "--config4-sequences", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(name, None)
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-client-threads"] + options, capture_output=True, text=True, env=env,
+                            timeout=1200)
+    assert single.returncode == 0, single.stderr[-2000:]
+    double = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + options, capture_output=True, text=True,
+                            env=env, timeout=1200)
+    assert double.returncode == 0, double.stderr[-2000:]
+    a, b = json.loads(single.stdout.strip().splitlines()[-1]), json.loads(double.stdout.strip().splitlines()[-1])
+    assert a["config"]["mutation_rows"] == b["config"]["mutation_rows"] > 0
+    assert a["also_amino_acid_full"]["mutation_rows"] == b["also_amino_acid_full"]["mutation_rows"] > 0 and "position-range x2" in b["also_amino_acid_full"]["workload"]
+    assert b["also_config4"]["sharding"].startswith("sequence-id x2 (150000 rows per rank)") and b["also_config4"]["queries"] == 200
+    assert b["also_config4"]["mutation_rows"] > 1000 and b["also_config4"]["value"] > 0
+    assert b["filter_queries"]["count"] >= 0 and b["filter_queries"]["queries_per_s_1_client"] > 0
 
 
 @pytest.mark.gpu
