@@ -74,7 +74,8 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
         rank_of = np.empty(len(tree.names), dtype=np.int64)
         rank_of[sorted(range(len(tree.names)), key=lambda k: [int(part) for part in tree.names[k].split(".")[1:]])] = np.arange(len(tree.names))
         lineage = lineage[np.argsort(rank_of[lineage], kind="stable")]
-    model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=seed)
+    # the table of lineage substitutions is the database's (every shard has it); the rows are the shard's (`seed`)
+    model = synth.make_model(n_sequences, reference, "nuc", tree, lineage, seed=seed, table_seed=synth.DEFAULT_SEED)
     engine = Engine(genomes, device=device)
     if two_pass:  # the generator runs twice per store: counted, then written straight into the adaptive planes (no build-time planes)
         engine.set_option("two_pass_build", 1)
@@ -89,7 +90,7 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
     engine.generate_synthetic(partition, "main", False, model, window)
     for index, gene in enumerate(genomes["genes"]):
         gene_reference = np.array([alphabet.AMINO_ACID.char_to_symbol[c] for c in gene["sequence"]], dtype=np.uint8)
-        gene_model = synth.make_model(n_sequences, gene_reference, "aa", tree, lineage, seed=seed, store_index=index + 1)
+        gene_model = synth.make_model(n_sequences, gene_reference, "aa", tree, lineage, seed=seed, store_index=index + 1, table_seed=synth.DEFAULT_SEED)
         engine.generate_synthetic(partition, gene["name"], True, gene_model, engine.position_window(gene["name"], True))
     engine.set_lineage_column_ids(partition, "pango_lineage", tree.names, lineage)
     if with_metadata:
@@ -937,7 +938,10 @@ def main():
         if use_dist and not args.no_client_threads:
             # filter -> Aggregated on the sequence-id shards: every rank counts its rows, one all-reduce of the count per query
             wire = filter_query(model4, tree4).encode()
-            count = json.loads(engine4.execute_text(wire)[1].decode())["queryResult"][0]["count"]
+            status, body = engine4.execute_text(wire)
+            if status != 200:
+                raise RuntimeError(body.decode())
+            count = json.loads(body.decode())["queryResult"][0]["count"]
             for _ in range(5):
                 engine4.execute_text(wire)
             sync()

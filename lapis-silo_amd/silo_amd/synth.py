@@ -7,7 +7,7 @@ the CPU by oracle/synth.py — so any slice of a 10 M-sequence store can be repr
 holding it on the host.
 """
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -111,8 +111,11 @@ def make_model(
     lineage_of_sequence: np.ndarray,
     seed: int = DEFAULT_SEED,
     store_index: int = 0,
+    table_seed: Optional[int] = None,
 ) -> SynthModel:
-    """Per-store model; `lineage_of_sequence` is shared by all sequence stores of a database."""
+    """Per-store model; `lineage_of_sequence` is shared by all sequence stores of a database.  table_seed: the seed of the
+    table of lineage substitutions where it is not `seed` — the sequence-id shards of one database share the lineages (and
+    so the table) and differ in their rows (`seed`)."""
     reference = np.ascontiguousarray(reference, dtype=np.uint8)
     positions = len(reference)
     store_seed = (seed + 0x9E3779B9 * (store_index + 1)) & 0xFFFFFFFFFFFFFFFF
@@ -143,7 +146,9 @@ def make_model(
         trail_gap=trail,
         missing_start=missing_start,
         missing_len=missing_len,
-        lineage_symbol=make_lineage_table(reference, alphabet, tree, store_seed),
+        lineage_symbol=make_lineage_table(
+            reference, alphabet, tree, store_seed if table_seed is None else (table_seed + 0x9E3779B9 * (store_index + 1)) & 0xFFFFFFFFFFFFFFFF
+        ),
         private_threshold=private_threshold,
         ambiguous_threshold=ambiguous_threshold,
     )
