@@ -23,16 +23,19 @@ const MetadataColumnPartition& columnOf(const DatabasePartition& partition, cons
 }
 
 /// Under position-range sharding every rank holds every row (and every metadata column), so row-wise actions simply
-/// run on each rank; a sequence-id shard sees only its own rows and would need a gather that is not built.
-void requireAllRowsLocal(const Database& database, const char* what) {
+/// run on each rank.  A sequence-id shard is one DatabasePartition of the reference (query_engine.cpp:40-49): an action
+/// whose rows are rows of the database (Details, Fasta, FastaAligned) answers for ITS rows and the front end concatenates
+/// the shards' responses — no collective; ordering, offset and limit then hold per shard.  An action
+/// that merges rows across partitions (Aggregated with groupByFields, Insertions) would need a gather that is not built.
+void requireRowsMergedLocally(const Database& database, const char* what) {
    if (database.shard_world > 1 && !database.shard_by_position) {
       throw std::runtime_error(std::string(what) + " is not supported on a database sharded by sequence id");
    }
 }
-/// Needs every position of a sequence on this device.
-void requireUnsharded(const Database& database, const char* what) {
-   if (database.shard_world > 1) {
-      throw std::runtime_error(std::string(what) + " is not supported on a sharded (multi-GPU) database");
+/// Needs every position of a sequence on this device: not on a position-range shard.
+void requireAllPositionsLocal(const Database& database, const char* what) {
+   if (database.shard_world > 1 && database.shard_by_position) {
+      throw std::runtime_error(std::string(what) + " is not supported on a database sharded by position range");
    }
 }
 
@@ -60,7 +63,7 @@ std::vector<uint32_t> selectedRows(const DatabasePartition& partition, const Ope
 
 // ---- Aggregated with groupByFields ---------------------------------------------------------------------
 QueryResult Aggregated::aggregateWithGrouping(const Database& database, std::vector<OperatorResult>& bitmap_filter) const {
-   requireAllRowsLocal(database, "Aggregated with groupByFields");
+   requireRowsMergedLocally(database, "Aggregated with groupByFields");
    struct Group {
       uint32_t count = 0;
       std::vector<JsonValue> values;
@@ -250,7 +253,6 @@ QueryResult Details::finish(const Database& database, Pending& pending) const {
 
 QueryResult Details::executeAndOrder(const Database& database, std::vector<OperatorResult> bitmap_filter) const {  // details.cpp:186-219
    validateOrderByFields(database);
-   requireAllRowsLocal(database, "Details");
    const std::vector<storage::ColumnMetadata> field_metadata = parseFields(database, fields);
 
    struct Row {
@@ -356,7 +358,6 @@ QueryResult Fasta::execute(const Database& database, std::vector<OperatorResult>
       total_count += filter.cardinality();
    }
    CHECK_SILO_QUERY(total_count <= SEQUENCE_LIMIT, "Fasta action currently limited to " + std::to_string(SEQUENCE_LIMIT) + " sequences")
-   requireAllRowsLocal(database, "Fasta");
    QueryResult results;
    results.query_result.reserve(total_count);
    for (size_t partition_id = 0; partition_id < database.partitions.size(); ++partition_id) {
@@ -414,7 +415,7 @@ QueryResult InsertionAggregation<SymbolType>::execute(const Database& database, 
          "The database does not contain the " + std::string(SymbolType::SYMBOL_NAME) + " sequence '" + sequence_name + "'"
       )
    }
-   requireAllRowsLocal(database, "Insertions");
+   requireRowsMergedLocally(database, "Insertions");
 
    // One k_count_pairs launch per (partition, column, sequence): the and_cardinality of the filter with the rows of
    // every distinct insertion at once (:196-206).  Launch all, then fetch.
@@ -526,7 +527,7 @@ QueryResult FastaAligned::execute(const Database& database, std::vector<Operator
       total_count += filter.cardinality();
    }
    CHECK_SILO_QUERY(total_count < 10001, "FastaAligned action currently limited to 10000 sequences")
-   requireUnsharded(database, "FastaAligned");
+   requireAllPositionsLocal(database, "FastaAligned");
 
    const std::string& primary_key_column = database.database_config.primary_key;
    QueryResult results;

@@ -8,6 +8,9 @@ mode "gpu":  the real engine on cuda:0 in every rank (a 1-GPU box), sharded by p
 mode "batch100": BASELINE.json configs[4] in shape — ONE batch of 100 queries (a lineage filter, every other one ANDed
              with a nucleotide predicate, each followed by Mutations or AminoAcidMutations) on sequence-id shards,
              against the oracle.
+mode "gpu_big": 140 000 rows (>= 65 536 on every shard: finalize re-encodes the stores and the tiled kernels, the escape pass
+             and the derived-symbol passes run), filled by the device generator; rank 0 checks every answer against the naive
+             counter (oracle/dense.py) over the generator's CPU twin — silo_oracle.py needs minutes per query at this size.
 Prints one JSON line from rank 0.
 """
 import ctypes
@@ -29,7 +32,11 @@ from oracle import synth as oracle_synth  # noqa: E402
 from silo_amd import synth  # noqa: E402
 from silo_amd.engine import Engine  # noqa: E402
 
-N, P, L = 5000, 997, 60
+# rows of the whole database: 5 000 by default (short rows: identity planes, the row-wave kernel); SILO_TEST_ROWS >= 140 000 puts
+# >= 65 536 rows on every shard, where finalize re-encodes the stores (derived symbols, one-hot rows, slice-major escape keys,
+# runs of the missing symbol) and the tiled kernels run — sharding + collective + adaptive layout together against the oracle
+N = int(os.environ.get("SILO_TEST_ROWS", "5000"))
+P, L = 997, 60
 
 
 def genomes():
@@ -42,10 +49,171 @@ def genomes():
     return doc, ref, gene
 
 
+NUC_CHARS = "-ACGTRYSWKMBDHVN"
+AA_CHARS = "-ACDEFGHIKLMNPQRSTVWYBZ*X"
+# what a symbol may be under Maybe: itself or an ambiguity code that may stand for it (nucleotide_symbol_equals.cpp:28-73)
+NUC_UPPER = {0: [0], 1: [1, 5, 10, 8, 12, 13, 14, 15], 2: [2, 6, 10, 7, 11, 13, 14, 15], 3: [3, 5, 9, 7, 11, 12, 14, 15], 4: [4, 6, 9, 8, 11, 12, 13, 15]}
+
+
+def dense_mutation_rows(symbols, mask, reference, valid_symbols, chars, min_proportion, sequence_name):
+    """The rows Mutations / AminoAcidMutations must give, by direct counting: mutations.cpp:184-232 over oracle/dense.py's table."""
+    table = dense.mutation_counts(symbols, mask, valid_symbols).astype(np.int64)
+    rows = []
+    for position in range(table.shape[0]):
+        total = int(table[position].sum())
+        if total == 0:
+            continue
+        must_exceed = 0 if min_proportion == 0 else int(np.uint32(np.ceil(np.float64(total) * min_proportion) - 1))
+        for k, symbol in enumerate(valid_symbols):
+            count = int(table[position][k])
+            if symbol != reference[position] and count > must_exceed:
+                rows.append({"count": count, "mutation": f"{chars[reference[position]]}{position + 1}{chars[symbol]}", "proportion": count / total,
+                             "sequenceName": sequence_name})
+    return rows
+
+
+def big_case(rank, world, by_position):
+    """140 000 rows on two shards, filled by the device generator; rank 0 checks against the naive counter."""
+    from silo_amd import alphabet, binding
+
+    n, p_nuc, p_aa, n_lineages = 140_000, 301, 97, 60
+    ref = synth.random_reference(p_nuc, "nuc", 3)
+    gene = synth.random_reference(p_aa, "aa", 4)
+    doc = {"nucleotideSequences": [{"name": "main", "sequence": "".join(NUC_CHARS[s] for s in ref)}],
+           "genes": [{"name": "S", "sequence": "".join(AA_CHARS[s] for s in gene)}]}
+    tree = synth.make_lineage_tree(n_lineages)
+    lineage = synth.assign_lineages(n, tree, 11)
+    lib = binding.load_library()
+
+    def all_reduce(device_ptr, count, stream):
+        host = np.empty(count, dtype=np.int32)
+        binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, host.nbytes, stream))
+        tensor = torch.from_numpy(host)
+        dist.all_reduce(tensor)
+        binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), host.nbytes, stream))
+
+    def broadcast(device_ptr, nbytes, root, stream):
+        host = np.empty(nbytes, dtype=np.uint8)
+        if rank == root:
+            binding._check(lib.silo_gpu_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), device_ptr, nbytes, stream))
+        tensor = torch.from_numpy(host)
+        dist.broadcast(tensor, src=root)
+        if rank != root:
+            binding._check(lib.silo_gpu_memcpy_h2d(device_ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, stream))
+
+    # the rows of a shard: all of them under position sharding; a slice, generated from the shard's own seed, by sequence id
+    shards = [slice(0, n)] if by_position else [slice(n * r // world, n * (r + 1) // world) for r in range(world)]
+
+    def models_of(shard_index):
+        rows = shards[shard_index]
+        seed = 5 + 1000 * shard_index
+        made = {"main": synth.make_model(rows.stop - rows.start, ref, "nuc", tree, lineage[rows], seed=seed, store_index=0, table_seed=5),
+                "S": synth.make_model(rows.stop - rows.start, gene, "aa", tree, lineage[rows], seed=seed, store_index=1, table_seed=5)}
+        for model in made.values():
+            model.ambiguous_threshold = 1 << 11  # ~1e-4 of the cells: ambiguity codes at every position
+            # the model gives every other sequence a run of the missing symbol of up to half the store: on these short stores that is
+            # no alignment (the runs would not even be smaller than a quarter of the symbol's plane, and the plane would stay): one in ten
+            model.missing_len[np.random.default_rng(seed).random(len(model.missing_len)) < 0.8] = 0
+        return made
+
+    mine = models_of(0 if by_position else rank)
+    engine = Engine(doc)
+    engine.set_sharding(rank, world, by_position, all_reduce)
+    if by_position:
+        engine.set_broadcast(broadcast)
+    n_local = shards[0 if by_position else rank].stop - shards[0 if by_position else rank].start
+    part = engine.add_partition(n_local)
+    for name, is_aa in (("main", False), ("S", True)):
+        engine.generate_synthetic(part, name, is_aa, mine[name], engine.position_window(name, is_aa))
+    engine.set_lineage_column_ids(part, "pango_lineage", tree.names, lineage[shards[0 if by_position else rank]])
+    engine.finalize()
+    store = engine.partition_store(0)
+    window = engine.position_window("main", False)
+    layout = {"most_common_rows_per_position": int(lib.silo_gpu_store_scan_planes(store.handle, 0)), "runs": int(lib.silo_gpu_store_scan_runs(store.handle, 0)),
+              "plane_rows": int(lib.silo_gpu_store_scan_rows(store.handle, 0, 0, window[1] - window[0])), "positions": window[1] - window[0],
+              "escape_keys": int(lib.silo_gpu_store_scan_escapes(store.handle, 0))}
+    # re-encoded with derived symbols: the runs of the missing symbol are part of the scan, fewer plane rows than 3 identity planes per position
+    re_encoded = layout["runs"] > 0 and layout["plane_rows"] < 3 * layout["positions"] and layout["escape_keys"] > 0
+
+    def lineage_filter(name, sublineages=True):
+        return {"type": "PangoLineage", "column": "pango_lineage", "value": name, "includeSublineages": sublineages}
+
+    reference_33 = NUC_CHARS[ref[32]]
+    sizes = np.bincount(lineage, minlength=n_lineages)
+    frequent = [tree.names[i] for i in np.argsort(-sizes, kind="stable")[:16]]
+    queries = [
+        {"action": {"type": "Mutations", "minProportion": 0.02}, "filterExpression": lineage_filter("B.1")},
+        {"action": {"type": "AminoAcidMutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
+        {"action": {"type": "Mutations", "minProportion": 0.0}, "filterExpression": {"type": "True"}},
+        {"action": {"type": "Mutations", "minProportion": 0.5}, "filterExpression": lineage_filter("B.2.3", False)},
+        {"action": {"type": "AminoAcidMutations", "minProportion": 0.05}, "filterExpression": lineage_filter("B.2")},
+        {"action": {"type": "Mutations", "minProportion": 0.3}, "filterExpression": {"type": "And", "children": [
+            {"type": "Not", "child": {"type": "NucleotideEquals", "position": 10, "symbol": "-"}},
+            {"type": "Maybe", "child": {"type": "NucleotideEquals", "position": 33, "symbol": reference_33}}]}},
+        {"action": {"type": "Aggregated"}, "filterExpression": lineage_filter("B.1")},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "NucleotideEquals", "position": 150, "symbol": NUC_CHARS[ref[149]]}},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "NucleotideEquals", "position": 200, "symbol": "N"}},
+        {"action": {"type": "Aggregated"}, "filterExpression": {"type": "Or", "children": [
+            {"type": "NucleotideEquals", "position": 301, "symbol": "R"}, {"type": "NucleotideEquals", "position": 1, "symbol": "-"}]}},
+    ]
+    queries += [{"action": {"type": "Mutations", "minProportion": 0.05}, "filterExpression": lineage_filter(name)} for name in frequent[:6]]
+    queries += [{"action": {"type": "AminoAcidMutations", "minProportion": 0.05}, "filterExpression": lineage_filter(name, False)} for name in frequent[:6]]
+    results = [engine.execute_raw(q) for q in queries]
+    batch = [{"action": {"type": "Mutations" if k % 2 == 0 else "AminoAcidMutations", "minProportion": 0.04}, "filterExpression": lineage_filter(frequent[k], k % 3 != 0)}
+             for k in range(16)]
+    batched = engine.execute_batch(batch)
+    dist.barrier()
+    if rank == 0:
+        # the whole database as characters' symbols, from the generator's CPU twin: shard by shard (sequence ids) or whole
+        symbols = {}
+        for name, positions in (("main", p_nuc), ("S", p_aa)):
+            symbols[name] = np.vstack([
+                oracle_synth.symbol_matrix(models_of(k)[name] if k > 0 or not by_position else mine[name], np.arange(shards[k].stop - shards[k].start), np.arange(positions))
+                for k in range(len(shards))])
+        valid_nuc, valid_aa = list(alphabet.NUCLEOTIDE.valid_mutation_symbols), list(alphabet.AMINO_ACID.valid_mutation_symbols)
+
+        def mask_of(expression):
+            kind = expression["type"]
+            if kind == "True":
+                return np.ones(n, dtype=bool)
+            if kind == "PangoLineage":
+                index = tree.names.index(expression["value"])
+                return tree.subtree(index)[lineage].astype(bool) if expression["includeSublineages"] else lineage == index
+            if kind == "NucleotideEquals":
+                return symbols["main"][:, expression["position"] - 1] == NUC_CHARS.index(expression["symbol"])
+            if kind == "Maybe":  # of a NucleotideEquals
+                child = expression["child"]
+                return np.isin(symbols["main"][:, child["position"] - 1], NUC_UPPER[NUC_CHARS.index(child["symbol"])])
+            if kind == "Not":
+                return ~mask_of(expression["child"])
+            if kind in ("And", "Or"):
+                parts = [mask_of(child) for child in expression["children"]]
+                return np.logical_and.reduce(parts) if kind == "And" else np.logical_or.reduce(parts)
+            raise ValueError(kind)
+
+        def expected(query):
+            mask = mask_of(query["filterExpression"])
+            action = query["action"]
+            if action["type"] == "Aggregated":
+                return [{"count": int(mask.sum())}]
+            if action["type"] == "Mutations":
+                return dense_mutation_rows(symbols["main"], mask, ref, valid_nuc, NUC_CHARS, action["minProportion"], "main")
+            return dense_mutation_rows(symbols["S"], mask, gene, valid_aa, AA_CHARS, action["minProportion"], "S")
+
+        equal = [status == 200 and document["queryResult"] == expected(query) for (status, document), query in zip(results, queries)]
+        batch_equal = [status == 200 and document["queryResult"] == expected(query) for (status, document), query in zip(batched, batch)]
+        print(json.dumps({"rows_per_rank": n_local, "re_encoded": bool(re_encoded), "layout": layout, "equal": equal, "batch_equal": batch_equal,
+                          "nonempty": sum(1 for _, document in results if len(document.get("queryResult", [])) > 0)}), flush=True)
+    engine.close()
+
+
 def main():
     mode, shard = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "gpu_big":
+        big_case(rank, world, shard == "position")
+        return
     doc, ref, gene = genomes()
     tree = synth.make_lineage_tree(L)
     lineage = synth.assign_lineages(N, tree, 11)
@@ -128,6 +296,7 @@ def main():
     age = metadata_rng.integers(0, 90, size=N)
     engine.append_metadata(part, "country", "indexed_string", [f"C{c}" for c in country[rows]])
     engine.append_metadata(part, "age", "int", [str(a) if a % 11 else "" for a in age[rows]])
+    engine.set_schema("country")  # (the oracle's primary key below: FastaAligned labels its rows with it)
     engine.finalize()
 
     oracle_db = None
@@ -199,6 +368,29 @@ def main():
                         "filterExpression": {"type": "NucleotideEquals", "position": 950, "symbol": "A"}})
         queries.append({"action": {"type": "Details", "fields": ["age", "country"], "orderByFields": ["age", "country"], "limit": 7},
                         "filterExpression": {"type": "NucleotideEquals", "position": 20, "symbol": "T"}})
+    concatenated = None
+    if not by_position:
+        # row-wise actions on sequence-id shards: every rank answers for ITS rows, the front end concatenates (no collective)
+        row_queries = [
+            {"action": {"type": "Details", "fields": ["age", "country"]}, "filterExpression": {"type": "NucleotideEquals", "position": 20, "symbol": "T"}},
+            {"action": {"type": "FastaAligned", "sequenceName": "main"}, "filterExpression": {"type": "And", "children": [
+                {"type": "PangoLineage", "column": "pango_lineage", "value": "B.2.3", "includeSublineages": False},
+                {"type": "NucleotideEquals", "position": 30, "symbol": "-"}]}},
+        ]
+        local = [engine.execute_raw(q) for q in row_queries]
+        everyones = [None] * world
+        dist.all_gather_object(everyones, local)
+        if rank == 0:
+            concatenated = []
+            for k, query in enumerate(row_queries):
+                assert all(answers[k][0] == 200 for answers in everyones), [answers[k] for answers in everyones]
+                rows = [row for answers in everyones for row in answers[k][1]["queryResult"]]
+                want = so.execute_query(oracle_db, query)
+                key = lambda row: json.dumps(row, sort_keys=True)
+                concatenated.append(sorted(map(key, rows)) == sorted(map(key, json.loads(json.dumps(want)))) and len(rows) > 0)
+        # what does merge rows across shards is refused
+        status, document = engine.execute_raw({"action": {"type": "Aggregated", "groupByFields": ["country"]}, "filterExpression": {"type": "True"}})
+        assert world == 1 or (status == 500 and "sharded by sequence id" in document["message"]), (status, document)
     results = [engine.execute_raw(q) for q in queries]
     # the same queries as one batch: scans share plane passes, the count tables are reduced after the launches
     batched = engine.execute_batch(queries)
@@ -221,7 +413,9 @@ def main():
     if rank == 0:
         want = oracle_answers(queries)
         got = json.loads(json.dumps(results))
-        print(json.dumps({"results": results, "matches_oracle": [g == w for g, w in zip(got, want)], "mismatch_refused": gathered}), flush=True)
+        print(json.dumps({"results": results if N <= 20000 else [[status, len(json.dumps(document))] for status, document in results],
+                          "matches_oracle": [g == w for g, w in zip(got, want)], "mismatch_refused": gathered, "row_actions_concatenate": concatenated,
+                          "rows_per_rank": n_local}), flush=True)
     engine.close()
 
 

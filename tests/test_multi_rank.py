@@ -17,12 +17,14 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, mode, shard, timeout=600):
+def launch(world, mode, shard, timeout=600, rows=None):
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if rows is not None:
+            env["SILO_TEST_ROWS"] = str(rows)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "multi_rank_worker.py"), mode, shard],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outputs = []
@@ -61,6 +63,24 @@ def test_two_ranks_match_one_rank_gpu(built, shard):
     n_cases = 2 if shard == "position" else 3
     assert double["mismatch_refused"] == [[True] * n_cases + [True]] * 2, double["mismatch_refused"]
     assert single["mismatch_refused"] == [[False] * n_cases + [True]], single["mismatch_refused"]
+    if shard == "sequence":  # Details / FastaAligned: the shards' rows, concatenated, are the unsharded rows
+        assert single["row_actions_concatenate"] == [True, True] and double["row_actions_concatenate"] == [True, True]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["position", "sequence"])
+def test_two_ranks_with_re_encoded_stores_match_the_dense_oracle_gpu(built, shard):
+    """The same at 140 000 rows (>= 65 536 on every shard): finalize re-encodes the stores — derived symbols, one-hot rows,
+    slice-major escape keys, runs of the missing symbol — and the tiled kernels, the escape pass and the derived-symbol passes
+    run on every rank: sharding + collective + adaptive layout together.  The restatement of the reference (silo_oracle.py)
+    takes ten minutes per query at this size (its row-wise probes of the missing symbol, mutations.cpp:75-82, in Python), so
+    the checker is the naive counter (oracle/dense.py over the generator's twin): count tables, thresholds, rows, proportions —
+    one by one and as ONE batch of 16 queries (8 filters per pass over rows and keys)."""
+    out = launch(2, "gpu_big", shard, timeout=900)
+    assert out["rows_per_rank"] == (140_000 if shard == "position" else 70_000) and out["re_encoded"], out["layout"]
+    assert all(out["equal"]) and len(out["equal"]) >= 20, out["equal"]
+    assert all(out["batch_equal"]) and len(out["batch_equal"]) == 16
+    assert out["nonempty"] >= 15
 
 
 @pytest.mark.gpu
