@@ -352,3 +352,90 @@ def test_config3_amino_acid_scan_at_10m_layouts_and_c_port_agree(built):
     finally:
         engine.close()
         plain_engine.close()
+
+
+def test_config4_batch_at_6m_rows_matches_the_c_port_on_windows(built):
+    """BASELINE.json configs[4] as one of its 8 sequence-id shards holds it — 6.25 M sequences, genome + 12 genes — and as
+    bench.py runs it: ONE silo_engine_execute_batch of 100 lineage filters (every fourth AND a nucleotide predicate) x
+    (Mutations + AminoAcidMutations), 8 filters per pass over the plane rows and over the escape keys
+    (k_scan_sliced<2,2,4,8,rows>, k_scan_escapes_sliced<8>).  Responses of seven of the queries — plain lineage filters of
+    different sizes, two with the nucleotide predicate, two amino-acid ones — against the C port of the reference's algorithm
+    (oracle/roaring_port.c over roaring-format containers) on windows of positions: counts, thresholds, rows, proportions."""
+    from silo_amd import alphabet
+
+    n = 6_250_000
+    engine, model, tree, lineage, _ = bench.build_engine(n, 0, 1, None, 0, with_genes=True)
+    try:
+        reference_text = bench.load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
+        queries = bench.config4_queries(tree, reference_text)
+        assert len(queries) == 200
+        batched = engine.execute_batch_text(queries)
+        assert all(status == 200 for status, _ in batched)
+        assert sum(1 for _, body in batched if len(json.loads(body.decode())["queryResult"]) > 0) >= 190
+        genes = bench.load_reference_genomes(True)["genes"]
+        gene_index = {gene["name"]: k for k, gene in enumerate(genes)}
+
+        def mask_of(expression):
+            if expression["type"] == "And":
+                return np.logical_and.reduce([mask_of(child) for child in expression["children"]])
+            if expression["type"] == "PangoLineage":
+                return tree.subtree(tree.names.index(expression["value"]))[lineage].astype(bool)
+            column = oracle_synth.symbol_matrix(model, np.arange(n), np.array([expression["position"] - 1]))[:, 0]
+            return column == NUC_CHARS.index(expression["symbol"])
+
+        def rows_in_window(document, name, begin, count):
+            import re
+            picked = []
+            for row in document["queryResult"]:
+                position = int(re.match(r"^[^0-9]*([0-9]+)", row["mutation"]).group(1)) - 1
+                if row["sequenceName"] == name and begin <= position < begin + count:
+                    picked.append(row)
+            return picked
+
+        def expected_rows(table, reference, valid_symbols, chars, begin, name):
+            rows = []
+            for offset in range(table.shape[0]):
+                total = int(table[offset].sum())
+                if total == 0:
+                    continue
+                must_exceed = int(np.ceil(total * 0.05) - 1)
+                for k, symbol in enumerate(valid_symbols):
+                    count = int(table[offset][k])
+                    if symbol != reference[begin + offset] and count > must_exceed:
+                        rows.append({"count": count, "mutation": f"{chars[reference[begin + offset]]}{begin + offset + 1}{chars[symbol]}",
+                                     "proportion": count / total, "sequenceName": name})
+            return rows
+
+        checked = 0
+        for index in (0, 6, 14, 38, 198):  # Mutations queries: lineages of different sizes; 6 and 14 ... 198 carry the nucleotide predicate (k % 4 == 3)
+            query = json.loads(queries[index].decode())
+            assert query["action"]["type"] == "Mutations"
+            mask = mask_of(query["filterExpression"])
+            port_filter = cpu_port.Filter(dense.pack_bits(mask), n)
+            document = json.loads(batched[index][1].decode())
+            for begin, count in ((0, 32), (model.positions // 2 // 64 * 64, 32), (model.positions - 32, 32)):
+                port = cpu_port.PortStore(n, begin, count, "nuc", model=model)
+                table, _ = port.mutations_scan(port_filter, n_threads=0, grain=max(1, count // 8))
+                port.close()
+                want = expected_rows(table[:, :5].astype(np.int64), model.reference, [0, 1, 2, 3, 4], NUC_CHARS, begin, "main")
+                assert rows_in_window(document, "main", begin, count) == want, (index, begin)
+                checked += len(want)
+        aa_chars = "-ACDEFGHIKLMNPQRSTVWYBZ*X"
+        valid_aa = list(alphabet.AMINO_ACID.valid_mutation_symbols)
+        for index, gene_name, begin, count in ((1, "S", 600, 24), (39, "ORF1a", 2000, 24)):
+            query = json.loads(queries[index].decode())
+            assert query["action"]["type"] == "AminoAcidMutations"
+            mask = mask_of(query["filterExpression"])
+            gene = genes[gene_index[gene_name]]
+            reference = np.array([alphabet.AMINO_ACID.char_to_symbol[c] for c in gene["sequence"]], dtype=np.uint8)
+            gene_model = synth.make_model(n, reference, "aa", tree, lineage, seed=synth.DEFAULT_SEED, store_index=gene_index[gene_name] + 1)
+            port = cpu_port.PortStore(n, begin, count, "aa", model=gene_model)
+            table, _ = port.mutations_scan(cpu_port.Filter(dense.pack_bits(mask), n), n_threads=0, grain=max(1, count // 8))
+            port.close()
+            want = expected_rows(table[:, valid_aa].astype(np.int64), reference, valid_aa, aa_chars, begin, gene_name)
+            document = json.loads(batched[index][1].decode())
+            assert rows_in_window(document, gene_name, begin, count) == want, (index, gene_name)
+            checked += len(want)
+        assert checked > 20  # rows were compared, not empty windows
+    finally:
+        engine.close()
