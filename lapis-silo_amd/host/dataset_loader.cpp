@@ -614,6 +614,30 @@ std::string describeDatabaseConfig(const std::string& path, bool validate) {
    return json::Value(std::move(out)).dump();
 }
 
+/// The order the reference lays rows out in: it partitions by the partitionBy column — the keys in ascending order, consecutive
+/// keys merged into <= 32 partitions (preprocessor.cpp:159-227) — and orders the rows of a partition by dateToSortBy, then by
+/// the primary key (database_config.cpp:190-198).  One partition here, so the rows go by (partition key, date, primary key):
+/// every lineage is a row range, and inside it the dates ascend — lineage and date filters then select runs of rows, whose
+/// column tiles and key slices are the only ones a scan reads.  Rows without a date come last (DuckDB's NULLS LAST).
+std::vector<uint32_t> referenceRowOrder(
+   const std::vector<std::string>& partition_keys, const std::vector<std::string>& dates, const std::vector<std::string>& primary_keys
+) {
+   std::vector<uint32_t> order(primary_keys.size());
+   for (size_t row = 0; row < order.size(); ++row) {
+      order[row] = static_cast<uint32_t>(row);
+   }
+   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+      if (!partition_keys.empty() && partition_keys[a] != partition_keys[b]) {
+         return partition_keys[a] < partition_keys[b];
+      }
+      if (!dates.empty() && dates[a] != dates[b]) {
+         return dates[b].empty() || (!dates[a].empty() && dates[a] < dates[b]);
+      }
+      return primary_keys[a] < primary_keys[b];
+   });
+   return order;
+}
+
 DatasetSummary loadDataset(Database& database, const std::string& directory) {
    if (!database.partitions.empty()) {
       throw PreprocessingException("loadDataset needs an empty database");
@@ -658,6 +682,9 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
    const bool from_ndjson = config.count("ndjsonInputFilename") != 0;
    const std::string input_path = (root / (from_ndjson ? config["ndjsonInputFilename"] : setting("metadataFilename", "metadata.tsv"))).string();
 
+   // "sortRows: false" in preprocessing_config.yaml keeps the rows in file order (no reference analogue; the default lays them out
+   // as the reference does, see referenceRowOrder)
+   const bool sort_rows = setting("sortRows", "true") != "false";
    // pass 1: the row count (a device store is allocated for a known number of rows)
    size_t rows = 0;
    {
@@ -766,7 +793,57 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          }
          begin_pass(2);
       }
-      while (next_record(reader, line)) {
+      // The records in the reference's row order: the file is held in memory (its texts, while they fit `sortRowsMaxBytes`,
+      // 8 GiB by default), the sort keys read from every record's metadata, and the records then fed in that order — the
+      // reference leaves the same to DuckDB.  A larger file keeps its own order.
+      std::vector<std::string> held;
+      std::vector<uint32_t> order;
+      if (sort_rows) {
+         const uint64_t budget = std::strtoull(setting("sortRowsMaxBytes", "8589934592").c_str(), nullptr, 10);
+         uint64_t bytes = 0;
+         LineReader holding_reader(input_path);
+         std::string text;
+         bool fits = true;
+         while (fits && next_record(holding_reader, text)) {
+            bytes += text.size();
+            fits = bytes <= budget;
+            held.push_back(std::move(text));
+            text.clear();
+         }
+         if (!fits) {
+            held.clear();
+         } else {
+            std::vector<std::string> partition_keys, dates, primary_keys;
+            for (const std::string& text_of_record : held) {
+               const json::Value record = json::parse(text_of_record);
+               static const json::Value no_metadata = json::Value::object();
+               const json::Value& metadata = record.contains("metadata") && record["metadata"].is_object() ? record["metadata"] : no_metadata;
+               const auto text_of = [&](const std::string& column) {
+                  return metadata.contains(column) && metadata[column].is_string() ? metadata[column].as_string() : std::string();
+               };
+               if (schema.partition_by.has_value()) {
+                  partition_keys.push_back(text_of(*schema.partition_by));
+               }
+               if (schema.date_to_sort_by.has_value()) {
+                  dates.push_back(text_of(*schema.date_to_sort_by));
+               }
+               primary_keys.push_back(text_of(schema.primary_key));
+            }
+            order = referenceRowOrder(partition_keys, dates, primary_keys);
+         }
+      }
+      size_t next_held = 0;
+      const auto next_in_order = [&](std::string& record_text) {
+         if (held.empty()) {
+            return next_record(reader, record_text);
+         }
+         if (next_held == order.size()) {
+            return false;
+         }
+         record_text = held[order[next_held++]];
+         return true;
+      };
+      while (next_in_order(line)) {
          const json::Value record = json::parse(line);
          if (first_record) {
             // sequence_info.cpp:91-157 (SequenceInfo::validate): the sequence names of the FIRST record and of the
@@ -869,11 +946,34 @@ DatasetSummary loadDataset(Database& database, const std::string& directory) {
          for (size_t k = 0; k < metadata_writer.size(); ++k) {
             metadata_column_index.push_back(column_of(metadata_writer.name(k)));
          }
+         std::vector<std::vector<std::string>> table;  // the metadata file is small next to the sequences: held whole
          while (reader.next(line)) {
             if (line.find_first_not_of(" \t") == std::string::npos) {
                continue;
             }
-            const std::vector<std::string> fields = splitTabs(line);
+            table.push_back(splitTabs(line));
+         }
+         std::vector<uint32_t> order(table.size());
+         for (size_t row = 0; row < order.size(); ++row) {
+            order[row] = static_cast<uint32_t>(row);
+         }
+         if (sort_rows) {
+            const auto column_values = [&](const std::string& name) {
+               const size_t index = column_of(name);
+               std::vector<std::string> values;
+               values.reserve(table.size());
+               for (const auto& fields : table) {
+                  values.push_back(index < fields.size() ? fields[index] : "");
+               }
+               return values;
+            };
+            order = referenceRowOrder(
+               schema.partition_by.has_value() ? column_values(*schema.partition_by) : std::vector<std::string>{},
+               schema.date_to_sort_by.has_value() ? column_values(*schema.date_to_sort_by) : std::vector<std::string>{}, column_values(schema.primary_key)
+            );
+         }
+         for (const uint32_t row : order) {
+            const std::vector<std::string>& fields = table[row];
             keys.push_back(key_column < fields.size() ? fields[key_column] : "");
             for (size_t k = 0; k < metadata_writer.size(); ++k) {
                const size_t index = metadata_column_index[k];

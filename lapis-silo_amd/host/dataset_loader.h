@@ -19,6 +19,7 @@
 #pragma once
 
 #include <string>
+#include <vector>
 
 #include "database.h"
 
@@ -46,6 +47,13 @@ std::string describeDatabaseConfig(const std::string& path, bool validate);
 /// The records of a FASTA file (plain / .zst / .xz) as the loader reads them, a JSON array of [key, genome] sorted by key;
 /// throws PreprocessingException with the reference's FastaFormatException messages (fasta_reader.cpp:11-47).
 std::string describeFasta(const std::string& path);
+
+/// The row order of the loader = the reference's: rows by (partitionBy key, dateToSortBy, primary key), rows without a date last
+/// (preprocessor.cpp:159-227, database_config.cpp:190-198); an empty vector = the schema names no such column.  order[k] = the
+/// input row that becomes row k.
+std::vector<uint32_t> referenceRowOrder(
+   const std::vector<std::string>& partition_keys, const std::vector<std::string>& dates, const std::vector<std::string>& primary_keys
+);
 
 /// Fills `database` (must be empty) from the files in `directory` and finalises it.
 DatasetSummary loadDataset(Database& database, const std::string& directory);

@@ -39,6 +39,19 @@ void t_choose_layouts(
    std::memcpy(escape_count_out, escapes.data(), escapes.size() * sizeof(uint32_t));
 }
 
+/// referenceRowOrder of host/dataset_loader.cpp over n rows given as three arrays of C strings (partition_keys / dates may be null).
+void t_reference_row_order(const char* const* partition_keys, const char* const* dates, const char* const* primary_keys, uint32_t n, uint32_t* order_out) {
+   const auto strings = [n](const char* const* values) {
+      std::vector<std::string> out;
+      for (uint32_t k = 0; values != nullptr && k < n; ++k) {
+         out.emplace_back(values[k]);
+      }
+      return out;
+   };
+   const std::vector<uint32_t> order = silo::preprocessing::referenceRowOrder(strings(partition_keys), strings(dates), strings(primary_keys));
+   std::memcpy(order_out, order.data(), order.size() * sizeof(uint32_t));
+}
+
 uint32_t t_string_to_date(const char* text) {
    return silo::common::stringToDate(text);
 }

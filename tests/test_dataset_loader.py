@@ -100,6 +100,46 @@ def test_tsv_and_fasta_directory(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("source", ["tsv", "ndjson"])
+def test_rows_lie_in_the_reference_order(built, tmp_path, source):
+    """The loader lays the rows out as the reference's preprocessing does (preprocessor.cpp:159-227, database_config.cpp:190-198):
+    by partitionBy key (pango_lineage), then dateToSortBy (date), then primaryKey — so a lineage is a row range and the dates
+    ascend inside it.  Seen through the engine: the bitset of a lineage filter is ONE run of rows, Details (which walks the
+    rows in storage order) returns them in that order; `sortRows: false` keeps the file's order (and the same answers)."""
+    import numpy as np
+
+    from silo_amd.engine import Engine
+
+    directory = EXAMPLE
+    if source == "ndjson":
+        write_ndjson_dataset(str(tmp_path), "none")
+        directory = str(tmp_path)
+    details = {"action": {"type": "Details", "fields": ["pango_lineage", "date", "gisaid_epi_isl"]}, "filterExpression": {"type": "True"}}
+    with Engine.from_directory(directory) as engine:
+        rows = engine.execute_query(details)
+        assert len(rows) == 100
+        key = lambda row: (row["pango_lineage"] or "", row["date"] is None, row["date"] or "", row["gisaid_epi_isl"])
+        assert [key(row) for row in rows] == sorted(key(row) for row in rows)
+        assert len({row["pango_lineage"] for row in rows}) > 5
+        words, count = engine.evaluate_filter({"type": "PangoLineage", "column": "pango_lineage", "value": "B.1.1.7", "includeSublineages": False})
+        selected = np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0]
+        assert count == len(selected) == 48 and selected[-1] - selected[0] == 47  # one run of rows
+        sorted_counts = engine.execute_query({"action": {"type": "Mutations", "minProportion": 0.3}, "filterExpression": {"type": "True"}})
+    if source == "tsv":
+        for name in os.listdir(EXAMPLE):
+            origin = os.path.join(EXAMPLE, name)
+            if name == "preprocessing_config.yaml":
+                with open(origin) as handle, open(os.path.join(str(tmp_path), name), "w") as out:
+                    out.write(handle.read().rstrip("\n") + "\nsortRows: false\n")
+            else:
+                os.symlink(origin, os.path.join(str(tmp_path), name))
+        with Engine.from_directory(str(tmp_path)) as engine:
+            unsorted = engine.execute_query(details)
+            assert [key(row) for row in unsorted] != sorted(key(row) for row in unsorted) and sorted(map(key, unsorted)) == [key(row) for row in rows]
+            assert engine.execute_query({"action": {"type": "Mutations", "minProportion": 0.3}, "filterExpression": {"type": "True"}}) == sorted_counts
+
+
+@pytest.mark.gpu
 def test_tsv_and_fasta_directory_in_two_passes(built, tmp_path):
     """twoPassBuild: true in preprocessing_config.yaml: every sequence store of the directory is fed twice (counted, then
     written by silo_gpu_store_build_pass's second pass) — the same summary, the same goldens."""

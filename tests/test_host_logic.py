@@ -340,3 +340,26 @@ def test_layout_choice_on_the_real_alignment(host_logic):
           f"identity {np.mean(kind == 'identity'):.4f}; escape keys {keys / 1e6:.1f} M = {keys / totals.sum():.2e} of the cells")
     assert 1.0 <= per_position < 1.06 and np.mean(rows == 1) > 0.95 and np.mean(kind == "identity") < 0.001
     assert keys < 0.002 * totals.sum()
+
+
+# ---- the row order of the loader (host/dataset_loader.cpp) ------------------------------------------------------------------
+def test_loader_orders_rows_as_the_reference_does(host_logic):
+    """preprocessor.cpp:159-227 + database_config.cpp:190-198: rows by partitionBy key, then dateToSortBy, then primary key; rows
+    without a date last; without a partitionBy column by date and key alone; stable."""
+    import ctypes
+
+    def order(partition_keys, dates, primary_keys):
+        n = len(primary_keys)
+        as_array = lambda values: None if values is None else (ctypes.c_char_p * n)(*[v.encode() for v in values])
+        out = (ctypes.c_uint32 * n)()
+        host_logic.t_reference_row_order.restype = None
+        host_logic.t_reference_row_order(as_array(partition_keys), as_array(dates), as_array(primary_keys), n, out)
+        return list(out)
+
+    lineages = ["B.1.1.7", "B.1", "B.1.1.7", "AY.4", "B.1", "B.1.1.7", "AY.4"]
+    dates = ["2021-03-01", "2020-11-05", "2021-01-10", "", "2020-11-05", "2021-01-10", "2021-08-20"]
+    keys = ["k6", "k5", "k4", "k3", "k2", "k1", "k0"]
+    assert order(lineages, dates, keys) == [6, 3, 4, 1, 5, 2, 0]   # AY.4 (dated, then undated), B.1 (same date: by key), B.1.1.7 by date then key
+    assert order(None, dates, keys) == [4, 1, 5, 2, 0, 6, 3]       # one partition: date, key; the undated row last
+    assert order(None, None, keys) == [6, 5, 4, 3, 2, 1, 0]
+    assert order(lineages, None, ["same"] * 7) == [3, 6, 1, 4, 0, 2, 5]  # ties keep the input order
