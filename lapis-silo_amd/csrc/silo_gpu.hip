@@ -1596,37 +1596,12 @@ struct FilterEvalArgs {
 
 // Tried and dropped (profiles/r01_k3_variants.md): 16 instead of 8 leaf loads in flight per n-ary instruction, and
 // fetching the first 24 leaves up front into LDS (register-staged: spilled to scratch; LDS-DMA global_load_lds_dwordx4:
-// no spill) — neither moved the kernel time of the 32-column program (19-21 us at 10 M sequences either way).
-template <uint32_t BATCH>
-__global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
-   extern __shared__ ulonglong2 s_slots[];  // [n_slots][EVAL_THREADS]
-   using silo_gpu::Word2;
-   const uint32_t lane = threadIdx.x;
-   const uint32_t w = (blockIdx.x * EVAL_THREADS + lane) * 2;  // row_words is even (multiple of 32)
-   const bool active = w < args.row_words;
-   const uint32_t w_safe = active ? w : 0;
-   Word2 valid{0, 0};
-   if (active) {
-      valid = {silo_gpu::valid_mask(w, args.sequence_count), silo_gpu::valid_mask(w + 1, args.sequence_count)};
-   }
-   const auto leaf = [&](uint32_t index) -> Word2 {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(args.leaves[index] + w_safe);
-      return {v.x, v.y};
-   };
-   const auto get = [&](uint32_t index) -> Word2 {
-      if (index >= SILO_GPU_LEAF_OPERAND) {
-         return leaf(index - SILO_GPU_LEAF_OPERAND);
-      }
-      const ulonglong2 v = s_slots[index * EVAL_THREADS + lane];
-      return {v.x, v.y};
-   };
-   const auto set = [&](uint32_t index, Word2 value) { s_slots[index * EVAL_THREADS + lane] = make_ulonglong2(value.x, value.y); };
-
-   Word2 result = silo_gpu::bitprog_run<Word2, BATCH>(args.code, args.n_instructions, valid, get, set, leaf);
-   result = result & valid;
-   if (active && args.out != nullptr) {
-      *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
-   }
+// no spill) — neither moved the kernel time of the 32-column program (19-21 us at 10 M sequences either way).  Round 3:
+// blocks of 4 waves that fetch ALL leaves of a 128-word tile into LDS at once (32 loads in flight per tile) before wave 0
+// evaluates: 30 us instead of 20 (profiles/r03_notes.md) — the kernel is not waiting for its loads.
+/// The end of a filter kernel's wave (64 lanes, one per pair of result words): the popcount of the result goes to the count
+/// shards, and with a count slot the last block hands the total to the host.
+__device__ __forceinline__ void deliverFilterCount(const FilterEvalArgs& args, silo_gpu::Word2 result, uint32_t lane) {
    if (args.out_count != nullptr && args.ticket == nullptr) {
       const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
       addToCountShard(args.out_count, waveSumToLane63(bits));
@@ -1669,6 +1644,39 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalAr
          }
       }
    }
+}
+
+template <uint32_t BATCH>
+__global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalArgs args) {
+   extern __shared__ ulonglong2 s_slots[];  // [n_slots][EVAL_THREADS]
+   using silo_gpu::Word2;
+   const uint32_t lane = threadIdx.x;
+   const uint32_t w = (blockIdx.x * EVAL_THREADS + lane) * 2;  // row_words is even (multiple of 32)
+   const bool active = w < args.row_words;
+   const uint32_t w_safe = active ? w : 0;
+   Word2 valid{0, 0};
+   if (active) {
+      valid = {silo_gpu::valid_mask(w, args.sequence_count), silo_gpu::valid_mask(w + 1, args.sequence_count)};
+   }
+   const auto leaf = [&](uint32_t index) -> Word2 {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(args.leaves[index] + w_safe);
+      return {v.x, v.y};
+   };
+   const auto get = [&](uint32_t index) -> Word2 {
+      if (index >= SILO_GPU_LEAF_OPERAND) {
+         return leaf(index - SILO_GPU_LEAF_OPERAND);
+      }
+      const ulonglong2 v = s_slots[index * EVAL_THREADS + lane];
+      return {v.x, v.y};
+   };
+   const auto set = [&](uint32_t index, Word2 value) { s_slots[index * EVAL_THREADS + lane] = make_ulonglong2(value.x, value.y); };
+
+   Word2 result = silo_gpu::bitprog_run<Word2, BATCH>(args.code, args.n_instructions, valid, get, set, leaf);
+   result = result & valid;
+   if (active && args.out != nullptr) {
+      *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
+   }
+   deliverFilterCount(args, result, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

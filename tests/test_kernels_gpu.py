@@ -429,10 +429,16 @@ def test_scan_timings_cover_every_plane_row(built):
             entries = binding.scan_timings()
         finally:
             store.tune(7, 0)
-        assert len(entries) >= 2  # one-hot rows and 2 code planes at least
-        assert all(e["kernel"].startswith("k_scan_sliced<") and e["ms"] > 0 and e["blocks"] > 0 and e["filters"] == 1 for e in entries)
-        assert any(e["kernel"] == "k_scan_sliced<2, 2, 8, 1, 2>" for e in entries)
-        assert sum(e["plane_rows"] for e in entries) == store.scan_rows(0, 0, positions)
+        planes = [e for e in entries if e["kernel"].startswith("k_scan_sliced<")]
+        assert len(planes) >= 2  # one-hot rows and 2 code planes at least
+        assert all(e["ms"] > 0 and e["blocks"] > 0 and e["filters"] == 1 and e["bytes"] > 0 for e in entries)
+        assert any(e["kernel"] == "k_scan_sliced<2, 2, 8, 1, 2>" for e in planes)
+        assert sum(e["plane_rows"] for e in planes) == store.scan_rows(0, 0, positions)
+        row_bytes = 8 * ((n + 63) // 64 + 31) // 32 * 32
+        assert all(e["bytes"] == (e["plane_rows"] + 1) * row_bytes for e in planes)  # the launch's plane rows + the filter row
+        # the escape-key pass is a launch of the scan as well: 8 bytes per key (+ the filter slices of its blocks)
+        escapes = [e for e in entries if e["kernel"].startswith("k_scan_escapes_sliced<")]
+        assert len(escapes) == 1 and escapes[0]["bytes"] >= 8 * store.scan_escapes(0) > 0
         assert np.array_equal(store.mutations_scan(0, ptr), want)
         assert binding.scan_timings() == []
 
