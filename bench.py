@@ -54,7 +54,7 @@ def load_reference_genomes(with_genes=False):
 
 
 def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, with_genes=False, with_metadata=False, nuc_positions=None,
-                 lineage_order=False, two_pass=False, by_position=True, seed=None):
+                 lineage_order=False, two_pass=False, by_position=True, seed=None, options=None):
     """An engine with one partition of `n_sequences` synthetic rows.  sharded / world > 1: this rank's shard of a sharded
     database — by position range (every rank holds all rows for its window of positions) or by sequence id (by_position
     False: every rank holds all positions of ITS n_sequences rows, generated from `seed`)."""
@@ -79,6 +79,8 @@ def build_engine(n_sequences, rank, world, all_reduce, device, sharded=False, wi
     engine = Engine(genomes, device=device)
     if two_pass:  # the generator runs twice per store: counted, then written straight into the adaptive planes (no build-time planes)
         engine.set_option("two_pass_build", 1)
+    for name, value in (options or {}).items():  # silo_engine_set_option: how THIS engine's stores are laid out
+        engine.set_option(name, value)
     if getattr(build_engine, "comm", None) is not None and (world > 1 or sharded):
         engine.set_comm(build_engine.comm, by_position)  # native RCCL all-reduce / broadcast on the engine's streams
     elif world > 1 or sharded:
@@ -995,11 +997,7 @@ def main():
             for label, knob, text in (("also_identity_planes", -1, "3 identity code planes per position, every cell read (the floor: what the query costs when no "
                                                                     "position has a dominant symbol)"),
                                       ("also_one_hot_rows", 3, "a one-hot row for the most numerous symbol of every position too (nothing derived: the layout of round 2)")):
-                previous = lib.silo_gpu_tune(4, knob)
-                try:
-                    engine_k, _, tree_k, _, window_k = build_engine(args.sequences, 0, 1, None, local_rank)
-                finally:
-                    lib.silo_gpu_tune(4, previous)
+                engine_k, _, tree_k, _, window_k = build_engine(args.sequences, 0, 1, None, local_rank, options={"store_layout": knob})
                 elapsed_k, rows_k = run_steps(engine_k, query, max(5, args.steps // 2), args.warmup, sync)
                 if rows_k != rows:
                     raise AssertionError(f"{label}: the rows differ from the headline's")

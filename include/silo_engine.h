@@ -116,9 +116,16 @@ int silo_engine_set_broadcast(silo_engine* engine, silo_engine_broadcast_bytes b
 /* Tunables.  "mutation_row_capacity": Mutations / AminoAcidMutations select their result rows on the device into a
  * list of this many cells per query (default 4096); a query selecting more fetches the whole count table
  * and selects on the host; 0 = always the host selection.  Results are identical either way.
- * "compact_scan_index" (1 default / 0): whether silo_engine_finalize derives — and the Mutations scans read — the compact
- * scan index of the sequence stores (include/silo_gpu.h, K1i: +50 % HBM for the stores, the scan 1.5x faster for
- * nucleotides and up to 2.5x for amino acids); a process-wide setting of the device library.
+ * How silo_engine_finalize lays THIS engine's sequence stores out (per engine: silo_gpu_store_options of its device stores; set
+ * before finalize, finalized stores keep their layout):
+ *   "compact_scan_index" (1 default / 0): every position re-encoded into its cheapest layout — at almost every position of an
+ *     alignment the most numerous symbol is stored nowhere and derived by the scan, the rest are one-hot rows and keys — or (0) the
+ *     3 / 5 identity code planes kept as built (every cell read by a scan: what a query costs when no position has a dominant symbol);
+ *   "store_layout" (-1 / 0 default / 2 / 3): the same choice in full, as SILO_GPU_TUNE_COMPACT_INDEX of include/silo_gpu.h;
+ *   "missing_symbol_runs" (1 default / 0): the missing symbol (N / X) kept as runs along the rows, or as a plane per position
+ *     (then no symbol is derived).
+ * "two_pass_build" (0 default / 1): silo_engine_generate_synthetic runs the generator twice per sequence store (counted, then written
+ * straight into the finished layout: no build-time planes); chosen by itself where the one-pass build would not fit the device.
  * "compat_remove_quirk" (1 default / 0): SILO_COMPAT_REMOVE_QUIRK — HasNucleotideMutation / HasAminoAcidMutation build their
  * symbol lists as the reference does, with std::remove and no erase (has_mutation.cpp:58-65, has_aa_mutation.cpp:48-52):
  * at a reference-T (amino acids: reference-STOP) position the reference symbol itself stays in the list.  0 = the list

@@ -65,12 +65,27 @@ typedef struct {
    const silo_gpu_seqstore_desc* seqstores;
 } silo_gpu_store_desc;
 
+/* How finalize lays a store out — per STORE (two engines of one process may differ); a field left at SILO_GPU_OPTION_DEFAULT
+ * follows the process-wide silo_gpu_tune knob of the same meaning (those are for probes and tests).  Set before finalize. */
+#define SILO_GPU_OPTION_DEFAULT INT32_MIN
+typedef struct silo_gpu_store_options {
+   int32_t layout;           /* as SILO_GPU_TUNE_COMPACT_INDEX: < 0 keep the build-time identity planes, 0 re-encode every position into its
+                                cheapest layout (the most numerous symbol derived where the missing symbol is kept as runs), 2 without one-hot
+                                rows, 3 with a one-hot row for the most numerous symbol too */
+   int32_t missing_runs;     /* as SILO_GPU_TUNE_MISSING_RUNS: < 0 keeps the plane of the missing symbol */
+   int32_t key_cost;         /* as SILO_GPU_TUNE_KEY_COST: > 0 = plane bytes an escape key costs in the choice of layouts */
+   int32_t launch_cost_kib;  /* as SILO_GPU_TUNE_LAUNCH_COST */
+} silo_gpu_store_options;
+
 /* ---- lifetime ------------------------------------------------------------------------------- */
 
 /* Allocates zeroed planes in HBM.  Replaces SequenceStorePartition's constructor
  * (sequence_store.cpp:21-29).  Fails with SILO_GPU_ERR_NO_DEVICE when no GPU is present. */
 int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out);
 void silo_gpu_store_destroy(silo_gpu_store* store);
+
+/* NULL resets every field to SILO_GPU_OPTION_DEFAULT.  Stores that are finalized already keep their layout. */
+int silo_gpu_store_set_options(silo_gpu_store* store, const silo_gpu_store_options* options);
 
 uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store);
 uint32_t silo_gpu_store_row_words(const silo_gpu_store* store); /* Wp, in uint64 words */

@@ -359,6 +359,8 @@ struct silo_gpu_store {
    // scratch of silo_gpu_store_import_position: the one-hot row being expanded and the union of the rows seen so far
    uint64_t* d_import_row = nullptr;
    uint64_t* d_import_union = nullptr;
+   // how finalize lays the store out: this store's choice, or (SILO_GPU_OPTION_DEFAULT) the process-wide silo_gpu_tune knob
+   silo_gpu_store_options options{SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT};
    uint8_t* d_char_table[2] = {nullptr, nullptr};  // per alphabet, uploaded on first use
    char* d_symbol_chars[2] = {nullptr, nullptr};   // symbol -> character, for FastaAligned
    std::mutex mutex;
@@ -366,9 +368,23 @@ struct silo_gpu_store {
 
 namespace {
 
+/// The layout options of a store: its own, or the process-wide knob where it has none.
+int layoutOption(const silo_gpu_store* store) {
+   return store->options.layout != SILO_GPU_OPTION_DEFAULT ? store->options.layout : g_tune_compact_index.load();
+}
+int missingRunsOption(const silo_gpu_store* store) {
+   return store->options.missing_runs != SILO_GPU_OPTION_DEFAULT ? store->options.missing_runs : g_tune_missing_runs.load();
+}
+int keyCostOption(const silo_gpu_store* store) {
+   return store->options.key_cost != SILO_GPU_OPTION_DEFAULT ? store->options.key_cost : g_tune_key_cost.load();
+}
+int launchCostOption(const silo_gpu_store* store) {
+   return store->options.launch_cost_kib != SILO_GPU_OPTION_DEFAULT ? store->options.launch_cost_kib : g_tune_launch_cost.load();
+}
+
 int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore);  // the adaptive code planes, defined next to the scan launchers
 bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev);
-int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits);
+int planLayout(const silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits);
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -2695,6 +2711,16 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
    delete store;
 }
 
+int silo_gpu_store_set_options(silo_gpu_store* store, const silo_gpu_store_options* options) {
+   if (store == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_set_options: null store");
+   }
+   std::lock_guard<std::mutex> lock(store->mutex);
+   store->options = options != nullptr ? *options
+                                       : silo_gpu_store_options{SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT};
+   return SILO_GPU_OK;
+}
+
 uint32_t silo_gpu_store_sequence_count(const silo_gpu_store* store) {
    return store != nullptr ? store->sequence_count : 0;
 }
@@ -3001,7 +3027,7 @@ int compactMissingPlane(silo_gpu_store* store, SeqStoreHost& seqstore) {
       dev.kind[dev.missing_symbol] = PLANE_RUNS;
       return SILO_GPU_OK;
    }
-   if (dev.n_extra != 1 || dev.extra == nullptr || dev.kind[dev.missing_symbol] != PLANE_EXTRA || dev.positions == 0 || g_tune_missing_runs.load() < 0) {
+   if (dev.n_extra != 1 || dev.extra == nullptr || dev.kind[dev.missing_symbol] != PLANE_EXTRA || dev.positions == 0 || missingRunsOption(store) < 0) {
       return SILO_GPU_OK;
    }
    const size_t plane_bytes = static_cast<size_t>(dev.positions) * dev.row_words * sizeof(uint64_t);
@@ -3160,7 +3186,7 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
       dev.enc_counts = seqstore.d_totals;
       dev.build_mode = BUILD_COUNT;
       // the missing symbol, where it is the store's only extra plane, is counted (and then written) as runs right away
-      dev.runs_at_build = dev.n_extra == 1 && dev.kind[dev.missing_symbol] == PLANE_EXTRA && dev.index[dev.missing_symbol] == 0 && g_tune_missing_runs.load() >= 0 ? 1 : 0;
+      dev.runs_at_build = dev.n_extra == 1 && dev.kind[dev.missing_symbol] == PLANE_EXTRA && dev.index[dev.missing_symbol] == 0 && missingRunsOption(store) >= 0 ? 1 : 0;
       if (dev.runs_at_build != 0) {
          if (seqstore.d_run_count == nullptr) {
             HIP_TRY(hipMalloc(&seqstore.d_run_count, sizeof(unsigned long long)));
@@ -3203,7 +3229,7 @@ int silo_gpu_store_build_pass(silo_gpu_store* store, uint32_t seqstore_id, int p
       HIP_TRY(hipMemcpy(&n_runs, seqstore.d_run_count, sizeof(n_runs), hipMemcpyDeviceToHost));
    }
    // (the most numerous symbol of a position is derived only where the missing symbol is kept as runs)
-   if (const int rc = planLayout(seqstore, *work, true, runs_counted && n_runs < (1ull << 32) && seqstore.rows_filled == store->sequence_count, &fits); rc != SILO_GPU_OK) {
+   if (const int rc = planLayout(store, seqstore, *work, true, runs_counted && n_runs < (1ull << 32) && seqstore.rows_filled == store->sequence_count, &fits); rc != SILO_GPU_OK) {
       return rc;
    }
    if (!fits) {
@@ -4098,7 +4124,7 @@ int keepBuildPlanes(SeqStoreHost& seqstore) {
 bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev) {
    const bool nucleotide = dev.n_bits == 3 && dev.n_scan == 5;
    return (nucleotide || (dev.n_bits == 5 && dev.n_scan == 22)) && dev.row_words >= SCAN_THREADS * 4 && dev.positions != 0 && store->sequence_count != 0 &&
-          g_tune_compact_index.load() >= 0;
+          layoutOption(store) >= 0;
 }
 
 #define SILO_LAYOUT_TRY(expr)                                                       \
@@ -4113,7 +4139,7 @@ bool reencodes(const silo_gpu_store* store, const SeqStoreDev& dev) {
 /// From the totals of the store (seqstore.d_totals): the layout of every position, the tables that describe it and the device
 /// arrays of the finished store — the plane rows zeroed when `zero_planes` (an encoder that only sets bits).  *fits = false
 /// (nothing allocated) when no position would be re-encoded or the arrays do not fit.
-int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits) {
+int planLayout(const silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero_planes, bool allow_implicit, bool* fits) {
    SeqStoreDev& dev = seqstore.dev;
    const uint32_t positions = dev.positions;
    const size_t n_counters = static_cast<size_t>(positions) * dev.n_scan;
@@ -4124,12 +4150,12 @@ int planLayout(SeqStoreHost& seqstore, SeqStoreHost::LayoutWork& work, bool zero
    // SILO_GPU_TUNE_COMPACT_INDEX 2: code planes only, no one-hot rows; 3: one-hot rows with a row for the most numerous symbol
    // too (the layouts of round 2, for comparisons).  The most numerous symbol of a position is derived (LAYOUT_IMPLICIT) only where
    // the rows without a valid symbol can be counted without a plane: the missing symbol kept as runs.
-   const int tuned = g_tune_compact_index.load();
+   const int tuned = layoutOption(store);
    const int one_hot_mode = tuned == 2 ? silo_gpu_layout::ONE_HOT_OFF : (tuned == 3 || !allow_implicit ? silo_gpu_layout::ONE_HOT_ROWS : silo_gpu_layout::ONE_HOT_IMPLICIT);
    silo_gpu_layout::chooseLayouts(
       totals, dev.n_scan, dev.n_bits, positions, static_cast<uint64_t>(dev.row_words) * sizeof(uint64_t), one_hot_mode,
-      g_tune_key_cost.load() > 0 ? static_cast<uint64_t>(g_tune_key_cost.load()) : KEY_COST_BYTES, work.code_map, counts,
-      g_tune_launch_cost.load() == 0 ? silo_gpu_layout::LAUNCH_COST_BYTES : (g_tune_launch_cost.load() < 0 ? 0 : static_cast<uint64_t>(g_tune_launch_cost.load()) << 10)
+      keyCostOption(store) > 0 ? static_cast<uint64_t>(keyCostOption(store)) : KEY_COST_BYTES, work.code_map, counts,
+      launchCostOption(store) == 0 ? silo_gpu_layout::LAUNCH_COST_BYTES : (launchCostOption(store) < 0 ? 0 : static_cast<uint64_t>(launchCostOption(store)) << 10)
    );
    work.row_of.assign(positions + 1, 0);
    work.escape_first.assign(positions + 1, 0);
@@ -4408,7 +4434,7 @@ int buildLayout(silo_gpu_store* store, SeqStoreHost& seqstore) {
          return rc;
       }
    }
-   if (const int rc = planLayout(seqstore, work, false, complete, &fits); rc != SILO_GPU_OK) {
+   if (const int rc = planLayout(store, seqstore, work, false, complete, &fits); rc != SILO_GPU_OK) {
       return rc;
    }
    if (!fits) {

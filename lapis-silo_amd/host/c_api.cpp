@@ -388,11 +388,22 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
       engine->database.two_pass_build = value == 1;
       return 0;
    }
+   // How finalize lays THIS engine's stores out (silo_gpu_store_options; stores that are finalized already keep their layout):
+   //   compact_scan_index  1 (default) = every position re-encoded into its cheapest layout, 0 = the 3 / 5 identity planes kept
+   //   store_layout        the same choice in full: -1 identity planes, 0 cheapest layout with the most numerous symbol derived,
+   //                       2 without one-hot rows, 3 with a one-hot row for the most numerous symbol too
+   //   missing_symbol_runs 1 (default) = the missing symbol (N / X) kept as runs, 0 = as a plane
    if (std::strcmp(name, "compact_scan_index") == 0 && (value == 0 || value == 1)) {
-      // process-wide (the device library's knob): 0 before silo_engine_finalize = no index is built (saves a third of the
-      // sequence stores' HBM); 0 afterwards = built indexes are not scanned
-      (void)silo_gpu_tune(SILO_GPU_TUNE_COMPACT_INDEX, value == 1 ? 0 : -1);
-      return 0;
+      engine->database.store_options.layout = value == 1 ? 0 : -1;
+      return guarded([&] { engine->database.applyStoreOptions(); return 0; });
+   }
+   if (std::strcmp(name, "store_layout") == 0 && (value == -1 || value == 0 || value == 2 || value == 3)) {
+      engine->database.store_options.layout = static_cast<int32_t>(value);
+      return guarded([&] { engine->database.applyStoreOptions(); return 0; });
+   }
+   if (std::strcmp(name, "missing_symbol_runs") == 0 && (value == 0 || value == 1)) {
+      engine->database.store_options.missing_runs = value == 1 ? 0 : -1;
+      return guarded([&] { engine->database.applyStoreOptions(); return 0; });
    }
    return fail(SILO_GPU_ERR_INVALID_ARGUMENT, std::string("silo_engine_set_option: unknown option or bad value: ") + name);
 }

@@ -471,6 +471,12 @@ Database::Timings& Database::lastTimings() {
    return timings;
 }
 
+void Database::applyStoreOptions() {
+   for (DatabasePartition& partition : partitions) {
+      checkGpu(silo_gpu_store_set_options(partition.store, &store_options), "silo_gpu_store_set_options");
+   }
+}
+
 query_engine::QueryResult Database::executeQuery(const std::string& query) const {
    const query_engine::QueryEngine query_engine(*this);
    return query_engine.executeQuery(query);
@@ -584,6 +590,7 @@ DatabasePartition& Database::addPartition(uint32_t sequence_count) {
       partitions.pop_back();
       checkGpu(status, "silo_gpu_store_create");
    }
+   checkGpu(silo_gpu_store_set_options(partition.store, &store_options), "silo_gpu_store_set_options");
    uint32_t seqstore_id = 0;
    for (const auto& [name, store] : nuc_sequences) {
       const auto [window_begin, window_end] = positionWindow(store.reference_sequence.size());

@@ -343,6 +343,11 @@ class Database {
    /// Mutations selects its result rows on the device into a list of this many cells; a query that selects more
    /// (minProportion 0 over a large filter) fetches the whole count table instead. 0 = always fetch the table.
    uint32_t mutation_row_capacity = 4096;
+   /// How the stores of THIS database are laid out at finalize (silo_gpu_store_options): a field left at
+   /// SILO_GPU_OPTION_DEFAULT follows the process-wide probe knob (silo_gpu_tune).
+   silo_gpu_store_options store_options{SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT, SILO_GPU_OPTION_DEFAULT};
+   /// Hands store_options to every partition's device store (those not finalized yet take them up).
+   void applyStoreOptions();
    /// Option "two_pass_build": generated (and directory-loaded) sequence stores are streamed twice — counted, then written
    /// straight into their adaptive planes — instead of being built in 3 / 5 identity planes per position and re-encoded.
    bool two_pass_build = false;

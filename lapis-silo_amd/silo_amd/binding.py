@@ -97,7 +97,7 @@ class BitProg(ctypes.Structure):
 
 # every symbol include/silo_gpu.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = [
-    "silo_gpu_store_create", "silo_gpu_store_destroy", "silo_gpu_store_sequence_count",
+    "silo_gpu_store_create", "silo_gpu_store_destroy", "silo_gpu_store_set_options", "silo_gpu_store_sequence_count",
     "silo_gpu_store_row_words", "silo_gpu_store_device_bytes", "silo_gpu_store_append_sequences",
     "silo_gpu_store_finalize", "silo_gpu_store_generate_synthetic", "silo_gpu_bitset_alloc",
     "silo_gpu_bitset_upload", "silo_gpu_bitset_download", "silo_gpu_bitset_from_lineages", "silo_gpu_upload_u32",

@@ -434,7 +434,7 @@ def test_scan_timings_cover_every_plane_row(built):
         assert all(e["ms"] > 0 and e["blocks"] > 0 and e["filters"] == 1 and e["bytes"] > 0 for e in entries)
         assert any(e["kernel"] == "k_scan_sliced<2, 2, 8, 1, 2>" for e in planes)
         assert sum(e["plane_rows"] for e in planes) == store.scan_rows(0, 0, positions)
-        row_bytes = 8 * ((n + 63) // 64 + 31) // 32 * 32
+        row_bytes = 8 * (((n + 63) // 64 + 31) // 32 * 32)
         assert all(e["bytes"] == (e["plane_rows"] + 1) * row_bytes for e in planes)  # the launch's plane rows + the filter row
         # the escape-key pass is a launch of the scan as well: 8 bytes per key (+ the filter slices of its blocks)
         escapes = [e for e in entries if e["kernel"].startswith("k_scan_escapes_sliced<")]

@@ -137,30 +137,32 @@ def test_empty_database_and_empty_partition(built):
         assert got[3] == [{"count": 1, "mutation": "K2R", "proportion": 0.5, "sequenceName": "S"}]
 
 
-def test_compact_scan_index_option(built):
-    """silo_engine_set_option("compact_scan_index", 0) before finalize: the stores keep their 3 / 5 identity planes instead of
-    the re-encoded adaptive layout (about twice the HBM for a nucleotide store with its missing-symbol plane), same answers."""
+def test_store_layout_options_are_per_engine(built):
+    """silo_engine_set_option("compact_scan_index", 0) / ("store_layout", k) before finalize lays out the stores of THAT engine:
+    an engine that keeps its 3 identity planes, one with a one-hot row for every stored symbol and one with the default
+    layout (the most numerous symbol derived), built one after the other and alive together in one process — each has its
+    own layout, the same answers, and the process-wide probe knob (silo_gpu_tune) is untouched."""
     import bench
     from silo_amd import binding
-    from silo_amd.engine import Engine
 
     lib = binding.load_library()
     query = json.dumps({"action": {"type": "Mutations", "minProportion": 0.02},
                         "filterExpression": {"type": "PangoLineage", "column": "pango_lineage", "value": "B.2", "includeSublineages": True}}).encode()
-    answers, sizes = [], []
+    engines = []
     try:
-        for enabled in (1, 0):
-            with Engine({"nucleotideSequences": [{"name": "main", "sequence": "ACGT"}], "genes": []}) as any_engine:
-                any_engine.set_option("compact_scan_index", enabled)  # a process-wide setting of the device library
-            with bench.build_engine(200_000, 0, 1, None, 0)[0] as engine:
-                store = engine.partition_store(0)
-                sizes.append(store.device_bytes)
-                assert lib.silo_gpu_store_scan_planes(store.handle, 0) == (0 if enabled else 3)
-                answers.append(engine.execute_text(query))
+        for options, planes in (({"compact_scan_index": 0}, 3), ({"store_layout": 3}, 1), (None, 0), ({"missing_symbol_runs": 0}, 1)):
+            engines.append(bench.build_engine(200_000, 0, 1, None, 0, options=options)[0])
+            store = engines[-1].partition_store(0)
+            assert lib.silo_gpu_store_scan_planes(store.handle, 0) == planes, options
+            assert (int(lib.silo_gpu_store_scan_runs(store.handle, 0)) > 0) == (options is None)  # only the default layout derives symbols
+        assert lib.silo_gpu_tune(4, 0) == 0 and lib.silo_gpu_tune(8, 0) == 0  # the process-wide knobs were never touched
+        answers = [engine.execute_text(query) for engine in engines]
+        assert answers[0][0] == 200 and all(answer == answers[0] for answer in answers)
+        sizes = [engine.partition_store(0).device_bytes for engine in engines]
+        assert sizes[2] < sizes[1] < sizes[0]
     finally:
-        lib.silo_gpu_tune(4, 0)
-    assert answers[0] == answers[1] and answers[0][0] == 200
-    assert sizes[0] < 0.8 * sizes[1]
+        for engine in engines:
+            engine.close()
 
 
 def test_two_pass_build_option_gives_the_same_database(built):
