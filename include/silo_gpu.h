@@ -80,7 +80,8 @@ typedef struct silo_gpu_store_options {
 /* ---- lifetime ------------------------------------------------------------------------------- */
 
 /* Allocates zeroed planes in HBM.  Replaces SequenceStorePartition's constructor
- * (sequence_store.cpp:21-29).  Fails with SILO_GPU_ERR_NO_DEVICE when no GPU is present. */
+ * (sequence_store.cpp:21-29).  Fails with SILO_GPU_ERR_NO_DEVICE when no GPU is present, and with SILO_GPU_ERR_UNSUPPORTED for a
+ * device other than that of the process's first store: one process serves one GPU. */
 int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out);
 void silo_gpu_store_destroy(silo_gpu_store* store);
 

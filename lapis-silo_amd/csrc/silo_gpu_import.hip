@@ -185,13 +185,17 @@ __global__ void k_complement_rows(uint64_t* __restrict__ out, const uint64_t* __
 /// Merges the one-hot row of `symbol` at `position` into the build-time planes, where append_sequences would have put it.
 __global__ __launch_bounds__(256) void k_merge_symbol_row(
    const SeqStoreDev store, uint32_t position, uint32_t symbol, const uint64_t* __restrict__ row, uint64_t* __restrict__ seen, uint64_t* sparse,
-   uint32_t* sparse_count, uint32_t sparse_capacity
+   uint32_t* sparse_count, uint32_t sparse_capacity, uint32_t* overlap_flag
 ) {
    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
    if (w >= store.row_words) {
       return;
    }
    const uint64_t bits = row[w];
+   if ((seen[w] & bits) != 0) {  // a row that has a symbol at this position already (overlapping bitmaps, a position imported twice):
+      atomicOr(overlap_flag, 1u);  // refused — OR-ing two symbols' code bits would give the row the code of a third
+      return;
+   }
    seen[w] |= bits;
    if (bits == 0) {
       return;
@@ -200,6 +204,14 @@ __global__ __launch_bounds__(256) void k_merge_symbol_row(
    if (kind == PLANE_SCAN) {
       const uint32_t code = static_cast<uint32_t>(store.index[symbol]) + 1u;
       uint64_t* planes = store.scan + static_cast<size_t>(position) * store.n_bits * store.row_words + w;
+      uint64_t coded = 0;  // rows of this word that carry a code at the position already: the position was imported before
+      for (uint32_t bit = 0; bit < store.n_bits; ++bit) {
+         coded |= planes[static_cast<size_t>(bit) * store.row_words];
+      }
+      if ((coded & bits) != 0) {
+         atomicOr(overlap_flag, 1u);
+         return;
+      }
       for (uint32_t bit = 0; bit < store.n_bits; ++bit) {
          if (((code >> bit) & 1u) != 0) {
             planes[static_cast<size_t>(bit) * store.row_words] |= bits;
@@ -376,10 +388,17 @@ int silo_gpu_store_import_position(
          }
       }
       k_merge_symbol_row<<<blocks, 256>>>(
-         seqstore.dev, position, symbol, store->d_import_row, store->d_import_union, seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity
+         seqstore.dev, position, symbol, store->d_import_row, store->d_import_union, seqstore.d_sparse, seqstore.d_sparse_count, seqstore.sparse_capacity,
+         store->d_error_flag
       );
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipMemcpy(&count_before, seqstore.d_sparse_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      uint32_t overlap = 0;
+      HIP_TRY(hipMemcpy(&overlap, store->d_error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+      if (overlap != 0) {
+         HIP_TRY(hipMemset(store->d_error_flag, 0, sizeof(uint32_t)));
+         return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_store_import_position: the bitmaps of the position overlap (a row with two symbols) — or the position was imported before");
+      }
       return SILO_GPU_OK;
    };
    for (uint32_t k = 0; k < n_bitmaps; ++k) {

@@ -636,6 +636,18 @@ int silo_gpu_store_create(const silo_gpu_store_desc* desc, silo_gpu_store** out)
    if (int rc = ensureDevice(desc->device); rc != SILO_GPU_OK) {
       return rc;
    }
+   {
+      // ONE device per process (one process per GPU, as the engine is deployed): the per-thread side streams, the scratch
+      // pools and the kernels' shared-memory attributes are set up once, for the device of the first store
+      static std::atomic<int> process_device{-1};
+      int expected = -1;
+      if (!process_device.compare_exchange_strong(expected, desc->device) && expected != desc->device) {
+         return fail(
+            SILO_GPU_ERR_UNSUPPORTED, "silo_gpu_store_create: this process holds stores on device " + std::to_string(expected) +
+                                         " already; one process serves one GPU (start a process per device)"
+         );
+      }
+   }
    auto* store = new (std::nothrow) silo_gpu_store();
    if (store == nullptr) {
       return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "host allocation failed");

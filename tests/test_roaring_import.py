@@ -59,6 +59,12 @@ def test_device_expansion_of_the_committed_vectors(built):
             binding.import_position(store.handle, 0, 0, {1: rf.serialize(range(5000))[:-1]})  # container past the end
         with pytest.raises(binding.SiloGpuError):
             binding.import_position(store.handle, 0, 0, {15: rf.serialize([1])})  # the missing symbol is imported row-wise
+        # a row can have one symbol at a position: overlapping bitmaps of one call, and a second import of the same position, are refused
+        with pytest.raises(binding.SiloGpuError, match="overlap"):
+            binding.import_position(store.handle, 0, 1, {1: rf.serialize([3, 4, 5]), 2: rf.serialize([5, 6])})
+        binding.import_position(store.handle, 0, 0, {1: rf.serialize([3, 4, 5]), 2: rf.serialize([6, 7])})
+        with pytest.raises(binding.SiloGpuError, match="overlap"):
+            binding.import_position(store.handle, 0, 0, {3: rf.serialize([4])})
 
 
 def position_payloads(position):
