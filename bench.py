@@ -157,13 +157,13 @@ time_kernel.per_launch = []
 
 
 def scan_bytes(lib, handle, seqstore_id, positions, w8):
-    """Bytes one scan of a sequence store has to read, each once: plane rows + the filter row, 8 per escape key, 12 per run
+    """Bytes one scan of a sequence store has to read, each once: plane rows + the filter row, 4 per escape key, 12 per run
     of the missing symbol and 8 per sparse key (the last two only where the store derives a symbol)."""
     rows = int(lib.silo_gpu_store_scan_rows(handle, seqstore_id, 0, positions))
     keys = int(lib.silo_gpu_store_scan_escapes(handle, seqstore_id))
     runs = int(lib.silo_gpu_store_scan_runs(handle, seqstore_id))
     sparse = int(lib.silo_gpu_store_scan_sparse_keys(handle, seqstore_id))
-    return dict(plane_rows=rows, escape_keys=keys, missing_runs=runs, sparse_keys=sparse, bytes=rows * w8 + w8 + 8 * keys + 12 * runs + 8 * sparse)
+    return dict(plane_rows=rows, escape_keys=keys, missing_runs=runs, sparse_keys=sparse, bytes=rows * w8 + w8 + 4 * keys + 12 * runs + 8 * sparse)
 
 
 LAYOUT_TEXT = {

@@ -606,17 +606,18 @@ __global__ __launch_bounds__(256) void k_scan_escapes(
 }
 
 /// One launch for up to ESCAPE_MAX_RANGES position ranges (the 12 genes of an AminoAcidMutations query): grid =
-/// (blocks per slice, slice x range, filter).  Block j of a (range, slice) takes the chunks j, j + gridDim.x, ... of that
-/// slice's keys of the scanned positions; where those begin and end is read from the store's slice index on the device.
+/// (blocks per slice, slice x range, filters / FILTERS); where a slice's keys of the scanned positions begin and end is read
+/// from the store's slice index on the device.
 struct EscapeSliceArgs {
    const uint64_t* filters[SILO_GPU_MAX_SCAN_BATCH];
    uint32_t row_words;
    uint32_t n_slices;
    uint32_t out_symbols;
-   uint32_t block_keys;  // keys per block (even)
+   uint32_t block_keys;  // keys per block: whole granules
    struct Range {
-      const uint64_t* keys;          // slice-major keys of the store
-      const uint32_t* slice_first;   // [n_slices][positions + 1]
+      const uint32_t* keys;          // the packed slice-major keys of the store (SeqStoreHost::Layout::d_escapes_sliced)
+      const uint32_t* granule_base;  // counter of every granule's first key
+      const uint32_t* slice_first;   // [n_slices][positions + 1], in the packed numbering
       uint32_t positions;
       uint32_t pos_begin;
       uint32_t pos_end;
@@ -634,37 +635,38 @@ __device__ __forceinline__ void ldsBarrier() {
 /// FILTERS = filters a block serves with ONE pass over its keys (1, 2, 4 or 8: a batch of 8 filters keeps 8 x 16 KiB of filter
 /// slices in LDS and reads every key once, not once per filter); blockIdx.z = first filter / FILTERS.
 ///
-/// Counting.  The keys of a slice are sorted by (position, symbol), so the counters a chunk of keys adds to lie in a narrow
-/// window behind the chunk's first key: the block counts into a window of LDS counters per filter (one LDS atomic per selected
-/// key, no wave-level bookkeeping) and then adds the window to the table with CONTIGUOUS atomics — 64 consecutive counters per
-/// wave instruction, the shape the memory side takes at full rate; a lane per scattered counter, as the first version did, is
-/// an order of magnitude slower per add (MI355X guide, "Global float atomics": access shape).  A key past the window (sparse
-/// stretches of keys) goes to the table directly.
+/// Keys.  4 bytes each: row within the slice | (counter - counter of the granule's first key) << 17; a granule is 4 096
+/// consecutive keys of a slice, so ONE 16-byte load per lane of the block fetches a granule, four consecutive keys per lane,
+/// and the granule's base counter is a scalar.
+///
+/// Counting.  The keys of a slice are sorted by (position, symbol), so the counters a block's keys add to lie in a narrow
+/// window behind its first key: the block counts into a window of LDS counters per filter and then adds the window to the
+/// table with CONTIGUOUS atomics — 64 consecutive counters per wave instruction, the shape the memory side takes at full
+/// rate; a lane per scattered counter, as the first version did, is an order of magnitude slower per add (MI355X guide,
+/// "Global float atomics": access shape).  A lane first sums the selected keys of its own four per counter (they mostly share
+/// one), so neighbouring lanes meet on an LDS counter three at a time, not sixty-four (identical addresses do not combine for
+/// LDS atomics: 64 lanes on one counter are 64 LDS cycles).  A key past the window (stretches of positions almost without
+/// keys) goes to the table directly.  No barrier between a block's granules: its waves run on by themselves, one waits for its
+/// keys while another counts; two blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
 template <int FILTERS>
-constexpr uint32_t escapeKeysInFlight() {  // per thread: fewer for a batch, whose windows are narrower
-   return FILTERS >= 8 ? 4u : (FILTERS >= 4 ? 8u : 16u);
+constexpr uint32_t escapeLoadsInFlight() {  // 16-byte loads (granules) per thread: fewer for a batch, whose windows are narrower
+   return FILTERS >= 4 ? 1u : 2u;  // (and as many again prefetched for the next step)
 }
-constexpr uint32_t ESCAPE_CHUNKS_PER_BLOCK = 4;  // at most: consecutive chunks of IN_FLIGHT x 1024 keys a block counts into ONE window
+constexpr uint32_t ESCAPE_GRANULES_PER_BLOCK = 16;  // at most
 template <int FILTERS>
 constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them for 1-4 filters (two blocks per CU), 28 KiB for 8 (beside 128 KiB of filter slices)
    return FILTERS >= 8 ? 896u : 12288u / FILTERS;
 }
 template <int FILTERS>
 constexpr uint32_t escapeLdsBytes() {
-   return FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) * static_cast<uint32_t>(sizeof(uint32_t));
+   return (FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) + ESCAPE_GRANULES_PER_BLOCK) * static_cast<uint32_t>(sizeof(uint32_t));
 }
 
-/// grid = (blocks per slice, slice x range, filters / FILTERS).  Block j of a (range, slice) takes the keys [j, j + 1) x
-/// ESCAPE_CHUNKS_PER_BLOCK chunks of that slice's keys of the scanned positions (an even first index: 16-byte loads of two
-/// keys per lane — 8-byte loads stream at 0.54-0.70 of their rate); where the slice's keys begin and end is read from the
-/// store's slice index on the device.  No barrier between a block's chunks: its waves run on by themselves, one waits for
-/// its keys while another counts; two blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
-template <int FILTERS, bool AGGREGATE = true>
+template <int FILTERS>
 __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
-   constexpr uint32_t IN_FLIGHT = escapeKeysInFlight<FILTERS>();
-   constexpr uint32_t CHUNK_KEYS = ESCAPE_SLICE_THREADS * IN_FLIGHT;
+   constexpr uint32_t IN_FLIGHT = escapeLoadsInFlight<FILTERS>();
    constexpr uint32_t WINDOW = escapeWindow<FILTERS>();
-   const uint32_t BLOCK_KEYS = args.block_keys;  // even; chosen by the launcher so that a block's keys mostly fall into its window
+   static_assert(ESCAPE_GRANULE_KEYS == ESCAPE_SLICE_THREADS * 4u, "a granule is one 16-byte load per thread of the block");
    extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32], then the counters [FILTERS][WINDOW]
    uint32_t* s_count = s_filter + FILTERS * ESCAPE_SLICE_WORDS32;
    const uint32_t first_filter = blockIdx.z * FILTERS;
@@ -673,16 +675,27 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
    const uint32_t* first = range.slice_first + static_cast<size_t>(slice) * (range.positions + 1u);
    const uint32_t key_begin = first[range.pos_begin];
    const uint32_t key_end = first[range.pos_end];
-   const uint32_t block_begin = (key_begin & ~1u) + blockIdx.x * BLOCK_KEYS;
+   const uint32_t block_begin = key_begin / ESCAPE_GRANULE_KEYS * ESCAPE_GRANULE_KEYS + blockIdx.x * args.block_keys;  // whole granules
    if (block_begin >= key_end) {
       return;  // (uniform) no keys for this block
    }
-   const uint32_t block_end = min(block_begin + BLOCK_KEYS, key_end);
-   // the two keys that bound the block's window of counters (slice-major keys are recoded for this kernel: counter of the store
-   // << 32 | sequence, counter = position * symbols + symbol); the loads are under way while the filter slices come in
-   const uint64_t first_key = range.keys[max(block_begin, key_begin)];
-   const uint64_t last_key = range.keys[block_end - 1u];
+   const uint32_t block_end = min(block_begin + args.block_keys, key_end);
+   const uint32_t range_first = range.pos_begin * args.out_symbols;
+   // Everything the block reads is asked for at once, behind the one dependent load of the slice index: the filter slices,
+   // the first keys, the granules' base counters — a block lives for a few memory latencies, every one put in a row would show.
+   const auto loadKeys = [&](uint4 (&quad)[IN_FLIGHT], uint32_t base) {
+#pragma unroll
+      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
+         const uint32_t i = base + k * ESCAPE_GRANULE_KEYS + threadIdx.x * 4u;
+         quad[k] = make_uint4(ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID);
+         if (i < block_end) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(range.keys + i));
+            quad[k] = make_uint4(v.x, v.y, v.z, v.w);
+         }
+      }
+   };
    uint64_t any_bit = 0;
+   ulonglong2 filter_part[FILTERS][ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS];
 #pragma unroll
    for (int f = 0; f < FILTERS; ++f) {  // this slice of every filter: 16 bytes per thread, zeros past the end of the row (and for a filter past the last)
       const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
@@ -690,80 +703,90 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
       const uint64_t* filter = args.filters[present ? first_filter + f : first_filter];
 #pragma unroll
       for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS; ++j) {
-         const uint32_t chunk = j * ESCAPE_SLICE_THREADS + threadIdx.x;  // 16-byte chunk of the slice
-         const uint32_t word = first_word + chunk * 2u;
-         const ulonglong2 v = present && word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
-         *reinterpret_cast<ulonglong2*>(s_filter + f * ESCAPE_SLICE_WORDS32 + chunk * 4u) = v;
-         any_bit |= v.x | v.y;
+         const uint32_t word = first_word + (j * ESCAPE_SLICE_THREADS + threadIdx.x) * 2u;  // 16-byte chunk of the slice
+         filter_part[f][j] = present && word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
       }
    }
-   for (uint32_t j = threadIdx.x; j < FILTERS * WINDOW; j += ESCAPE_SLICE_THREADS) {
-      s_count[j] = 0;
+   uint4 next[IN_FLIGHT];
+   loadKeys(next, block_begin);
+   uint32_t* s_base = s_count + FILTERS * WINDOW;  // [ESCAPE_GRANULES_PER_BLOCK] the counter of every granule's first key
+   const uint32_t first_granule = block_begin / ESCAPE_GRANULE_KEYS;
+   if (threadIdx.x < ESCAPE_GRANULES_PER_BLOCK && (first_granule + threadIdx.x) * ESCAPE_GRANULE_KEYS < block_end) {
+      s_base[threadIdx.x] = range.granule_base[first_granule + threadIdx.x];
+   }
+   // the window of counters: from the block's first key on (the first key of the block's first granule, or the range's first
+   // position where the granule begins before it) to the position of its last key
+   const uint32_t first_counter = max(range.granule_base[first_granule], range_first);
+   const uint32_t last_key = range.keys[block_end - 1u];
+   const uint32_t last_counter = range.granule_base[(block_end - 1u) / ESCAPE_GRANULE_KEYS] + (last_key >> ESCAPE_SLICE_SHIFT);
+   const uint32_t window_first = first_counter / args.out_symbols * args.out_symbols - range_first;
+   const uint32_t window_used = min(WINDOW, (last_counter / args.out_symbols + 1u) * args.out_symbols - range_first - window_first);
+#pragma unroll
+   for (int f = 0; f < FILTERS; ++f) {  // (16 bytes per store; WINDOW is a multiple of 4)
+      for (uint32_t j = threadIdx.x * 4u; j < window_used; j += ESCAPE_SLICE_THREADS * 4u) {
+         *reinterpret_cast<uint4*>(s_count + f * WINDOW + j) = make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS; ++j) {
+         *reinterpret_cast<ulonglong2*>(s_filter + f * ESCAPE_SLICE_WORDS32 + (j * ESCAPE_SLICE_THREADS + threadIdx.x) * 4u) = filter_part[f][j];
+         any_bit |= filter_part[f][j].x | filter_part[f][j].y;
+      }
    }
    if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
       return;  // no row of this slice is selected: none of its keys counts
    }
-   const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
-   const uint32_t range_first = range.pos_begin * args.out_symbols;
-   // the window: the counters from the position of the block's first key on; what it reaches of the block's last key's position
-   const uint32_t window_first = static_cast<uint32_t>(first_key >> 32) / args.out_symbols * args.out_symbols - range_first;
-   const uint32_t window_used = min(WINDOW, (static_cast<uint32_t>(last_key >> 32) / args.out_symbols + 1u) * args.out_symbols - range_first - window_first);
-   for (uint32_t base = block_begin; base < block_end; base += CHUNK_KEYS) {  // uniform per block
-      uint64_t key[IN_FLIGHT];
+   for (uint32_t base = block_begin; base < block_end; base += ESCAPE_GRANULE_KEYS * IN_FLIGHT) {  // uniform per block
+      uint4 quad[IN_FLIGHT];
 #pragma unroll
-      for (uint32_t k = 0; k < IN_FLIGHT / 2u; ++k) {
-         const uint32_t i = base + (k * ESCAPE_SLICE_THREADS + threadIdx.x) * 2u;
-         ulonglong2 pair = make_ulonglong2(~0ull, ~0ull);
-         if (i < block_end) {
-            pair = loadPlane16<true>(range.keys + i);  // (the key before the slice's first and the key behind its last, read along, are masked out)
-         }
-         key[2 * k] = i >= key_begin && i < block_end ? pair.x : ~0ull;
-         key[2 * k + 1] = i + 1u < block_end ? pair.y : ~0ull;
+      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
+         quad[k] = next[k];
+      }
+      if (base + ESCAPE_GRANULE_KEYS * IN_FLIGHT < block_end) {  // (uniform) the next step's keys come in while this step counts
+         loadKeys(next, base + ESCAPE_GRANULE_KEYS * IN_FLIGHT);
       }
 #pragma unroll
       for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
-         const bool valid = key[k] != ~0ull;  // (no key is all ones: a store has fewer than 2^32 - 1 counters)
-         const uint32_t local = valid ? static_cast<uint32_t>(key[k]) - slice_first_row : 0u;
-         const uint32_t counter = valid ? static_cast<uint32_t>(key[k] >> 32) - range_first : 0xFFFFFFFFu;
-         const uint32_t in_window = counter - window_first;
-         // The lanes of a wave hold consecutive keys of the sorted list: the keys of one counter sit side by side, and 64 LDS atomics
-         // on ONE address take 64 LDS cycles (identical addresses do not combine for atomics).  So a stretch of lanes with one
-         // counter adds its selected keys with TWO atomics: with `below` = the selected lanes below a lane (v_mbcnt of the ballot:
-         // two instructions), the stretch's first lane adds -below, its last lane +below + its own key; the sum is the number of
-         // selected keys in between (uint32 wrap-around; the window is read after the barrier).
-         const uint32_t previous = __builtin_amdgcn_update_dpp(0xFFFFFFFEu, counter, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0 keeps the old value)
-         const uint32_t next = __builtin_amdgcn_update_dpp(0xFFFFFFFEu, counter, 0x130, 0xf, 0xf, false);      // wave_shl:1 (lane 63 keeps the old value)
-         const bool head = valid && counter != previous;
-         const bool tail = valid && counter != next;
+         const uint32_t granule_first = base + k * ESCAPE_GRANULE_KEYS;
+         if (granule_first >= block_end) {
+            continue;  // (uniform)
+         }
+         const uint32_t granule_counter = s_base[granule_first / ESCAPE_GRANULE_KEYS - first_granule] - range_first - window_first;  // (wraps below the window: such keys are masked)
+         const uint32_t i = granule_first + threadIdx.x * 4u;
+         const uint32_t keys4[4] = {quad[k].x, quad[k].y, quad[k].z, quad[k].w};
+         uint32_t in_window[4];
+         bool valid[4];
 #pragma unroll
-         for (int f = 0; f < FILTERS; ++f) {
-            const bool is_selected = valid && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (local >> 5)] >> (local & 31u)) & 1u) != 0;
-            uint32_t* __restrict__ window = s_count + f * WINDOW;
-            uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
-            if constexpr (!AGGREGATE) {  // (measurement: one LDS atomic per selected key)
-               if (is_selected && in_window < WINDOW) {
-                  atomicAdd(&window[in_window], 1u);
-               } else if (is_selected) {
-                  atomicAdd(&table[counter], 1u);
-               }
-               continue;
-            }
-            const uint64_t selected = __ballot(is_selected);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(selected >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(selected), 0u));
-            const uint32_t upto = below + (is_selected ? 1u : 0u);
-            if (in_window < WINDOW) {
-               if (head && below != 0) {
-                  atomicAdd(&window[in_window], 0u - below);
-               }
-               if (tail && upto != 0) {
-                  atomicAdd(&window[in_window], upto);
-               }
-            } else if (valid) {  // a key past the window: straight to the table
-               if (head && below != 0) {
-                  atomicAdd(&table[counter], 0u - below);
-               }
-               if (tail && upto != 0) {
-                  atomicAdd(&table[counter], upto);
+         for (uint32_t c = 0; c < 4; ++c) {  // the keys before the scanned positions' first and behind their last, read along, are masked out
+            valid[c] = keys4[c] != ESCAPE_KEY_INVALID && i + c >= key_begin && i + c < block_end;
+            in_window[c] = granule_counter + (keys4[c] >> ESCAPE_SLICE_SHIFT);
+         }
+         // Column c of the granule (the c-th key of every lane) is a sorted list by itself: lanes with the same counter form
+         // stretches, a stretch's first lane adds the number of selected keys of the whole stretch (a population count of the
+         // wave's ballot under the stretch's mask) — no two lanes of one instruction meet on an LDS counter.
+         const uint32_t lane = __lane_id();
+#pragma unroll
+         for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t previous = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(in_window[c]), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+            const bool head = lane == 0 || in_window[c] != previous;
+            const uint64_t heads = __ballot(head);
+            const uint64_t above = lane == 63 ? 0 : heads & (~uint64_t{0} << (lane + 1u));
+            const uint64_t below_end = above == 0 ? ~uint64_t{0} : (uint64_t{1} << __builtin_ctzll(above)) - 1u;
+            const uint64_t stretch = below_end & (~uint64_t{0} << lane);  // the lanes [this one, the next stretch's first)
+            const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
+#pragma unroll
+            for (int f = 0; f < FILTERS; ++f) {
+               const bool selected = valid[c] && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & 1u) != 0;
+               const uint64_t chosen = __ballot(selected);
+               if (head) {
+                  const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(chosen & stretch));
+                  if (n != 0) {
+                     if (in_window[c] < WINDOW) {
+                        atomicAdd(&s_count[f * WINDOW + in_window[c]], n);
+                     } else {  // a key past the window: straight to the table
+                        uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
+                        atomicAdd(&table[in_window[c] + window_first], n);
+                     }
+                  }
                }
             }
          }
@@ -780,6 +803,24 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
             atomicAdd(&counts[j], value);
          }
       }
+   }
+}
+
+/// The few keys of a store that do not fit the packed form (SeqStoreHost::Layout::d_escapes_overflow: counter << 32 | sequence),
+/// for the positions [pos_begin, pos_end): one global filter lookup and one atomic each; grid.y = filter.
+__global__ __launch_bounds__(256) void k_scan_escapes_overflow(
+   const uint64_t* __restrict__ keys, uint32_t n_keys, const ScanBatchArgs batch, uint32_t pos_begin, uint32_t pos_end
+) {
+   const uint32_t q = blockIdx.y;
+   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_keys) {
+      return;
+   }
+   const uint64_t key = keys[i];
+   const uint32_t counter = static_cast<uint32_t>(key >> 32);
+   const uint32_t sequence = static_cast<uint32_t>(key);
+   if (counter >= pos_begin * batch.out_symbols && counter < pos_end * batch.out_symbols && ((batch.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0) {
+      atomicAdd(&batch.counts[0][q][counter - pos_begin * batch.out_symbols], 1u);
    }
 }
 
@@ -1522,36 +1563,29 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       static std::once_flag lds_once;
       std::call_once(lds_once, [] {  // filter slices + counter windows: beyond what a kernel may ask for by default
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<1>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<1>());
-         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<1>());
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<2>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<2>());
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<4>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<4>());
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<8>());
       });
       const uint32_t per_block = q_count <= 1 ? 1 : (q_count <= 2 ? 2 : (q_count <= 4 ? 4 : 8));  // filters per pass over the keys
-      const uint32_t chunk_keys = ESCAPE_SLICE_THREADS * (per_block >= 8 ? escapeKeysInFlight<8>() : (per_block >= 4 ? escapeKeysInFlight<4>() : escapeKeysInFlight<1>()));
-      // keys per block: as many as mostly fall into the block's window of counters (3/4 of it at the average density of keys
-      // along the positions; a key beyond it still counts, with an atomic of its own), at most ESCAPE_CHUNKS_PER_BLOCK chunks
+      // keys per block: whole granules, as many as mostly fall into the block's window of counters (3/4 of it at the average
+      // density of keys along the positions; a key beyond it still counts, with an atomic of its own), at most ESCAPE_GRANULES_PER_BLOCK
       const uint32_t window = per_block >= 8 ? escapeWindow<8>() : (per_block >= 4 ? escapeWindow<4>() : (per_block >= 2 ? escapeWindow<2>() : escapeWindow<1>()));
       const double keys_per_counter = static_cast<double>(total_keys) / std::max<double>(1.0, static_cast<double>(total_positions) * sliced.n_slices * sliced.out_symbols);
       const double fitting = 0.75 * window * keys_per_counter;
-      const uint32_t block_keys = static_cast<uint32_t>(std::min<double>(chunk_keys * ESCAPE_CHUNKS_PER_BLOCK, std::max<double>(2048.0, fitting))) & ~1u;
+      const uint32_t block_granules = static_cast<uint32_t>(std::min<double>(ESCAPE_GRANULES_PER_BLOCK, std::max<double>(1.0, fitting / ESCAPE_GRANULE_KEYS)));
+      const uint32_t block_keys = block_granules * ESCAPE_GRANULE_KEYS;
       sliced.block_keys = block_keys;
       const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
       char name[64];
-      std::snprintf(name, sizeof(name), "k_scan_escapes_sliced<%u, true>", per_block);
-      // bytes: the keys once per pass of `per_block` filters, plus a 16 KiB filter slice per block and filter
+      std::snprintf(name, sizeof(name), "k_scan_escapes_sliced<%u>", per_block);
+      // bytes: the keys (4 each) once per pass of `per_block` filters, plus a 16 KiB filter slice per block and filter
       ScanLaunchTiming* timing = startLaunchTiming(
-         name, 0, total_keys * sizeof(uint64_t) * grid.z + static_cast<uint64_t>(grid.x) * grid.y * q_count * ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), q_count,
+         name, 0, total_keys * sizeof(uint32_t) * grid.z + static_cast<uint64_t>(grid.x) * grid.y * q_count * ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), q_count,
          grid.x * grid.y * grid.z, hip_stream
       );
       switch (per_block) {
-         case 1:
-            if (g_tune_scan_variant.load() == 30) {
-               k_scan_escapes_sliced<1, false><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<1>(), hip_stream>>>(sliced, q_count);
-            } else {
-               k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<1>(), hip_stream>>>(sliced, q_count);
-            }
-            break;
+         case 1: k_scan_escapes_sliced<1><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<1>(), hip_stream>>>(sliced, q_count); break;
          case 2: k_scan_escapes_sliced<2><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<2>(), hip_stream>>>(sliced, q_count); break;
          case 4: k_scan_escapes_sliced<4><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<4>(), hip_stream>>>(sliced, q_count); break;
          default: k_scan_escapes_sliced<8><<<grid, ESCAPE_SLICE_THREADS, escapeLdsBytes<8>(), hip_stream>>>(sliced, q_count); break;
@@ -1585,7 +1619,20 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          sliced.out_symbols = range.seqstore->dev.n_scan;
          EscapeSliceArgs::Range& entry = sliced.ranges[n_sliced++];
          entry.keys = layout.d_escapes_sliced;
+         entry.granule_base = layout.d_granule_base;
          entry.slice_first = layout.d_slice_first;
+         if (layout.n_overflow != 0) {  // the few keys that do not fit the packed form: a small launch of their own
+            ScanBatchArgs overflow{};
+            overflow.out_symbols = range.seqstore->dev.n_scan;
+            for (uint32_t q = 0; q < q_count; ++q) {
+               overflow.filters[q] = filters[q];
+               overflow.counts[0][q] = range.counts[q];
+            }
+            k_scan_escapes_overflow<<<dim3((layout.n_overflow + 255) / 256, q_count), 256, 0, hip_stream>>>(
+               layout.d_escapes_overflow, layout.n_overflow, overflow, range.pos_begin, range.pos_end
+            );
+            HIP_TRY(hipGetLastError());
+         }
          entry.positions = range.seqstore->dev.positions;
          entry.pos_begin = range.pos_begin;
          entry.pos_end = range.pos_end;
@@ -1598,7 +1645,7 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          const size_t stride = static_cast<size_t>(entry.positions) + 1;
          for (uint32_t slice = 0; slice < layout.n_slices; ++slice) {
             const uint32_t keys = layout.slice_first[slice * stride + range.pos_end] - layout.slice_first[slice * stride + range.pos_begin];
-            most_keys = std::max(most_keys, keys + 1u);  // (chunks start at an even key index)
+            most_keys = std::max(most_keys, keys + ESCAPE_GRANULE_KEYS - 1u);  // (blocks start at a granule boundary)
          }
          continue;
       }

@@ -126,14 +126,37 @@ __global__ __launch_bounds__(256) void k_encode_adaptive(
    }
 }
 
-/// The slice-major keys as k_scan_escapes_sliced reads them: (position * n_scan + symbol) << 32 | sequence — the counter a key
-/// adds to is a subtraction away, no shifts, no multiplication per key (the kernel is bound by its integer work per key).
-__global__ void k_recode_sliced_keys(uint64_t* __restrict__ keys, uint32_t n_keys, uint32_t n_scan) {
-   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i < n_keys) {
-      const uint64_t key = keys[i];
-      const uint32_t counter = static_cast<uint32_t>(key >> 37) * n_scan + (static_cast<uint32_t>(key >> 32) & 31u);
-      keys[i] = (static_cast<uint64_t>(counter) << 32) | (key & 0xFFFFFFFFull);
+/// The slice-major keys as k_scan_escapes_sliced reads them (SeqStoreHost::Layout::d_escapes_sliced): one block per granule of
+/// ESCAPE_GRANULE_KEYS keys of one slice.  `unpacked_first[g]` = index of the granule's first key in the sorted 8-byte list,
+/// `unpacked_end[g]` = one past its last (a slice's last granule is short: the rest is padding).
+__global__ __launch_bounds__(256) void k_pack_sliced_keys(
+   const uint64_t* __restrict__ keys, const uint32_t* __restrict__ unpacked_first, const uint32_t* __restrict__ unpacked_end, uint32_t n_scan,
+   uint32_t* __restrict__ packed, uint32_t* __restrict__ granule_base, uint64_t* __restrict__ overflow, uint32_t* __restrict__ overflow_count,
+   uint32_t overflow_capacity
+) {
+   const uint32_t granule = blockIdx.x;
+   const uint32_t begin = unpacked_first[granule];
+   const uint32_t end = unpacked_end[granule];
+   const auto counter_of = [n_scan](uint64_t key) { return static_cast<uint32_t>(key >> 37) * n_scan + (static_cast<uint32_t>(key >> 32) & 31u); };
+   const uint32_t base = begin < end ? counter_of(keys[begin]) : 0u;
+   if (threadIdx.x == 0) {
+      granule_base[granule] = base;
+   }
+   for (uint32_t k = threadIdx.x; k < ESCAPE_GRANULE_KEYS; k += blockDim.x) {
+      uint32_t value = ESCAPE_KEY_INVALID;
+      if (begin + k < end) {
+         const uint64_t key = keys[begin + k];
+         const uint32_t relative = counter_of(key) - base;
+         if (relative <= ESCAPE_MAX_RELATIVE) {
+            value = (relative << ESCAPE_SLICE_SHIFT) | (static_cast<uint32_t>(key) & ESCAPE_ROW_MASK);
+         } else {
+            const uint32_t slot = atomicAdd(overflow_count, 1u);
+            if (slot < overflow_capacity) {
+               overflow[slot] = (static_cast<uint64_t>(counter_of(key)) << 32) | (key & 0xFFFFFFFFull);
+            }
+         }
+      }
+      packed[static_cast<size_t>(granule) * ESCAPE_GRANULE_KEYS + k] = value;
    }
 }
 
@@ -766,6 +789,8 @@ void silo_gpu_store_destroy(silo_gpu_store* store) {
       (void)hipFree(seqstore.layout.d_code_map);
       (void)hipFree(seqstore.layout.d_escapes);
       (void)hipFree(seqstore.layout.d_escapes_sliced);
+      (void)hipFree(seqstore.layout.d_granule_base);
+      (void)hipFree(seqstore.layout.d_escapes_overflow);
       (void)hipFree(seqstore.layout.d_slice_first);
       (void)hipFree(seqstore.layout.d_run_slice_first);
       (void)hipFree(seqstore.layout.d_escape_first);
@@ -1499,39 +1524,103 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
       work.discard();
       return rc;
    }
-   // the slice-major copy of the keys for the scan's escape pass, and where each position's keys begin in every slice
-   uint64_t* d_escapes_sliced = nullptr;
+   // the slice-major copy of the keys for the scan's escape pass — packed to 4 bytes per key — and where each position's keys
+   // begin in every slice
+   uint32_t* d_escapes_sliced = nullptr;
+   uint32_t* d_granule_base = nullptr;
+   uint64_t* d_escapes_overflow = nullptr;
+   uint32_t n_overflow = 0;
+   uint64_t packed_keys = 0;
    uint32_t* d_slice_first = nullptr;
    std::vector<uint32_t> slice_first;
    const uint32_t n_slices = (store->sequence_count + (1u << ESCAPE_SLICE_SHIFT) - 1) >> ESCAPE_SLICE_SHIFT;
    if (work.total_escapes > 0 && n_slices <= ESCAPE_MAX_SLICES) {
       const size_t n_entries = static_cast<size_t>(n_slices) * (positions + 1);
+      uint64_t* d_sorted = nullptr;  // the keys slice-major, 8 bytes wide: what the packed list is made from
+      uint32_t* d_unpacked = nullptr;
+      uint32_t* d_overflow_count = nullptr;
       const auto discardSliced = [&]() {
+         (void)hipFree(d_sorted);
+         (void)hipFree(d_unpacked);
+         (void)hipFree(d_overflow_count);
          (void)hipFree(d_escapes_sliced);
+         (void)hipFree(d_granule_base);
+         (void)hipFree(d_escapes_overflow);
          (void)hipFree(d_slice_first);
       };
-      hipError_t status = hipMalloc(&d_escapes_sliced, work.escape_bytes + 16);  // (the scan loads the keys in pairs: one key of slack)
+      hipError_t status = hipMalloc(&d_sorted, work.escape_bytes);
       status = status != hipSuccess ? status : hipMalloc(&d_slice_first, n_entries * sizeof(uint32_t));
-      status = status != hipSuccess ? status : hipMemcpy(d_escapes_sliced, work.d_escapes, work.total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+      status = status != hipSuccess ? status : hipMemcpy(d_sorted, work.d_escapes, work.total_escapes * sizeof(uint64_t), hipMemcpyDeviceToDevice);
       if (status != hipSuccess) {
          discardSliced();
          SILO_LAYOUT_TRY(status);
       }
-      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_escapes_sliced, work.total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + ESCAPE_SLICE_BITS); rc != SILO_GPU_OK) {
+      if (const int rc = silo_gpu_internal_sort_keys_by_bits(d_sorted, work.total_escapes, ESCAPE_SLICE_SHIFT, ESCAPE_SLICE_SHIFT + ESCAPE_SLICE_BITS); rc != SILO_GPU_OK) {
          discardSliced();
          work.discard();
          return rc;
       }
       k_slice_index<<<static_cast<uint32_t>((n_entries + 255) / 256), 256>>>(
-         d_escapes_sliced, static_cast<uint32_t>(work.total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
+         d_sorted, static_cast<uint32_t>(work.total_escapes), ESCAPE_SLICE_SHIFT, n_slices, positions, d_slice_first
       );
-      k_recode_sliced_keys<<<static_cast<uint32_t>((work.total_escapes + 255) / 256), 256>>>(d_escapes_sliced, static_cast<uint32_t>(work.total_escapes), dev.n_scan);
       slice_first.resize(n_entries);
       status = hipGetLastError();
       status = status != hipSuccess ? status : hipMemcpy(slice_first.data(), d_slice_first, n_entries * sizeof(uint32_t), hipMemcpyDeviceToHost);
       if (status != hipSuccess) {
          discardSliced();
          SILO_LAYOUT_TRY(status);
+      }
+      // every slice's keys padded to whole granules; the index [slice][position] moves to the packed numbering
+      std::vector<uint32_t> unpacked_first, unpacked_end;
+      for (uint32_t slice = 0; slice < n_slices; ++slice) {
+         uint32_t* first = slice_first.data() + static_cast<size_t>(slice) * (positions + 1);
+         const uint32_t slice_begin = first[0];
+         const uint32_t slice_end = first[positions];
+         const auto packed_begin = static_cast<uint32_t>(unpacked_first.size()) * ESCAPE_GRANULE_KEYS;
+         for (uint32_t at = slice_begin; at < slice_end; at += ESCAPE_GRANULE_KEYS) {
+            unpacked_first.push_back(at);
+            unpacked_end.push_back(std::min(slice_end, at + ESCAPE_GRANULE_KEYS));
+         }
+         for (uint32_t p = 0; p <= positions; ++p) {
+            first[p] = packed_begin + (first[p] - slice_begin);
+         }
+      }
+      const size_t n_granules = unpacked_first.size();
+      packed_keys = static_cast<uint64_t>(n_granules) * ESCAPE_GRANULE_KEYS;
+      const uint32_t overflow_capacity = static_cast<uint32_t>(std::min<uint64_t>(work.total_escapes, uint64_t{1} << 26));
+      if (packed_keys >= (uint64_t{1} << 32)) {
+         discardSliced();
+         work.discard();
+         return fail(SILO_GPU_ERR_UNSUPPORTED, "more than 2^32 packed escape keys in one sequence store");
+      }
+      status = hipMalloc(&d_escapes_sliced, packed_keys * sizeof(uint32_t) + 16);  // (16-byte loads: a quad of slack)
+      status = status != hipSuccess ? status : hipMalloc(&d_granule_base, std::max<size_t>(n_granules, 1) * sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMalloc(&d_unpacked, std::max<size_t>(n_granules, 1) * 2 * sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMalloc(&d_overflow_count, sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMalloc(&d_escapes_overflow, std::max<size_t>(overflow_capacity, 1) * sizeof(uint64_t));
+      status = status != hipSuccess ? status : hipMemset(d_overflow_count, 0, sizeof(uint32_t));
+      status = status != hipSuccess ? status : hipMemcpy(d_unpacked, unpacked_first.data(), n_granules * sizeof(uint32_t), hipMemcpyHostToDevice);
+      status = status != hipSuccess ? status : hipMemcpy(d_unpacked + n_granules, unpacked_end.data(), n_granules * sizeof(uint32_t), hipMemcpyHostToDevice);
+      status = status != hipSuccess ? status : hipMemcpy(d_slice_first, slice_first.data(), n_entries * sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (status == hipSuccess && n_granules > 0) {
+         k_pack_sliced_keys<<<static_cast<uint32_t>(n_granules), 256>>>(
+            d_sorted, d_unpacked, d_unpacked + n_granules, dev.n_scan, d_escapes_sliced, d_granule_base, d_escapes_overflow, d_overflow_count, overflow_capacity
+         );
+         status = hipGetLastError();
+      }
+      status = status != hipSuccess ? status : hipMemcpy(&n_overflow, d_overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (status != hipSuccess || n_overflow > overflow_capacity) {
+         discardSliced();
+         SILO_LAYOUT_TRY(status);
+         work.discard();
+         return fail(SILO_GPU_ERR_UNSUPPORTED, "too many escape keys outside their granule's counter range");
+      }
+      (void)hipFree(d_sorted);
+      (void)hipFree(d_unpacked);
+      (void)hipFree(d_overflow_count);
+      if (n_overflow == 0) {
+         (void)hipFree(d_escapes_overflow);
+         d_escapes_overflow = nullptr;
       }
    }
    (void)hipFree(work.d_first);
@@ -1550,6 +1639,10 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
    layout.d_code_map = work.d_code_map;
    layout.d_escapes = work.d_escapes;
    layout.d_escapes_sliced = d_escapes_sliced;
+   layout.d_granule_base = d_granule_base;
+   layout.d_escapes_overflow = d_escapes_overflow;
+   layout.n_overflow = n_overflow;
+   layout.packed_keys = packed_keys;
    layout.d_slice_first = d_slice_first;
    layout.slice_shift = ESCAPE_SLICE_SHIFT;
    layout.n_slices = d_escapes_sliced != nullptr ? n_slices : 0;
@@ -1561,7 +1654,8 @@ int finishLayout(silo_gpu_store* store, SeqStoreHost& seqstore, SeqStoreHost::La
    layout.escape_first_symbol = std::move(work.escape_first_symbol);
    layout.runs = std::move(work.runs);
    layout.has_implicit = work.has_implicit;
-   layout.device_bytes = work.plane_bytes + work.escape_bytes * (d_escapes_sliced != nullptr ? 2 : 1) + static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
+   layout.device_bytes = work.plane_bytes + work.escape_bytes + packed_keys * sizeof(uint32_t) + static_cast<size_t>(n_overflow) * sizeof(uint64_t) +
+                         static_cast<size_t>(positions) * (CODE_MAP_STRIDE + 8) +
                          work.total_rows * sizeof(uint32_t);
    store->device_bytes += layout.device_bytes;
    dev.planes = layout.planes;

@@ -272,7 +272,15 @@ struct SeqStoreHost {
       uint32_t* d_escape_first = nullptr;
       // the same keys once more, SLICE-major: slice = sequence >> slice_shift, (position, symbol, sequence) order within a
       // slice — what the scan's escape pass streams, a slice of the filter in LDS (k_scan_escapes_sliced)
-      uint64_t* d_escapes_sliced = nullptr;
+      // PACKED, 4 bytes per key: row within the slice (17 bits) | counter relative to the key's granule << 17, where a granule is
+      // ESCAPE_GRANULE_KEYS consecutive keys of one slice (a slice's keys are padded to whole granules with 0xFFFFFFFF) and
+      // granule_base[g] = the counter (position * n_scan + symbol) of the granule's first key.  A key whose relative counter does
+      // not fit 15 bits (a stretch of positions almost without keys) goes, 8 bytes wide, to the overflow list instead.
+      uint32_t* d_escapes_sliced = nullptr;
+      uint32_t* d_granule_base = nullptr;          // [packed keys / ESCAPE_GRANULE_KEYS]
+      uint64_t* d_escapes_overflow = nullptr;      // counter << 32 | sequence
+      uint32_t n_overflow = 0;
+      uint64_t packed_keys = 0;                    // slots of d_escapes_sliced (keys + padding)
       uint32_t slice_shift = 0;
       uint32_t n_slices = 0;
       uint32_t* d_slice_first = nullptr;          // [n_slices][P + 1] first key of a position within a slice
@@ -418,6 +426,10 @@ constexpr uint32_t ESCAPE_SLICE_BITS = 9;                      // sequence bits 
 constexpr uint32_t ESCAPE_MAX_SLICES = 1u << ESCAPE_SLICE_BITS;  // 67 M rows
 constexpr uint32_t ESCAPE_SLICE_THREADS = 1024;
 constexpr uint32_t ESCAPE_MAX_RANGES = 16;
+constexpr uint32_t ESCAPE_GRANULE_KEYS = 4096;                 // keys that share a base counter: one 16-byte load per lane of a 1024-thread block
+constexpr uint32_t ESCAPE_ROW_MASK = (1u << ESCAPE_SLICE_SHIFT) - 1u;
+constexpr uint32_t ESCAPE_KEY_INVALID = 0xFFFFFFFFu;           // padding / a key that went to the overflow list
+constexpr uint32_t ESCAPE_MAX_RELATIVE = (1u << (32 - ESCAPE_SLICE_SHIFT)) - 2u;  // largest relative counter a packed key holds
 
 /// A position range of one sequence store with the count tables of every filter of the launch.
 struct ScanRange {
