@@ -276,11 +276,12 @@ int silo_gpu_filter_eval_batch(
 );
 
 /* ---- K2: cardinality (aggregated.cpp:61, mutations.cpp:45) ---------------------------------------- */
-/* Count slot: the cardinality of a filter without a copy or a stream synchronisation.  The last block of the K3
- * launch sums the count shards, stores the total into page-locked host memory (system-scope store) and re-arms the
- * slot; silo_gpu_count_slot_wait spins on that word (and checks the stream from time to time, so a failed launch is an
- * error, not a hang).  One slot serves one launch at a time; a host thread keeps its own.  Replaces
- * roaring::cardinality() at the end of Operator::evaluate for Aggregated (aggregated.cpp:61). */
+/* Count slot: the cardinality of a filter without a copy, a device-side reduction or a stream synchronisation.  Every block
+ * of the K3 launch stores the rows IT selected into page-locked host memory (one posted 8-byte system-scope store, tagged
+ * with the launch's epoch); silo_gpu_count_slot_wait spins on those words and adds them up (after a spin budget of tens of
+ * milliseconds it synchronises the stream once, so a failed launch is an error, not a hang).  One slot serves one launch at
+ * a time; a host thread keeps its own.  Replaces roaring::cardinality() at the end of Operator::evaluate for Aggregated
+ * (aggregated.cpp:61). */
 typedef struct silo_gpu_count_slot silo_gpu_count_slot;
 int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot);
 void silo_gpu_count_slot_destroy(silo_gpu_count_slot* slot);

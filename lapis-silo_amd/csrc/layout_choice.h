@@ -19,9 +19,10 @@ constexpr uint8_t LAYOUT_IMPLICIT = 0x20;
 constexpr uint8_t LAYOUT_ROWS_MASK = 0x0F;  // the plane rows of the position
 constexpr uint32_t CODE_MAP_STRIDE = 8;    // bytes of code_map per position: [0] = layout, [c] = scan symbol of code c (1..7), 0xFF = unused
 constexpr uint32_t IMPLICIT_SLOT = 7;      // code_map[p][7] of a LAYOUT_IMPLICIT position: the symbol that is derived (one-hot rows use 1..3)
-// what an escape key costs a scan, in plane bytes (the escape pass streams its 8-byte keys beside the plane scans and shares
-// the HBM with them; the optimum is flat between 10 and 24 — profiles/r02_one_hot_rows.md)
-constexpr uint32_t KEY_COST_BYTES = 16;
+// what an escape key costs a scan, in plane bytes: the escape pass takes its 4-byte keys at ~0.4 of the rate at which the row
+// kernel streams planes (60 M keys in 81 us beside 6.4 TB/s: ~9 plane bytes per key); the optimum is flat between 6 and 12
+// (profiles/r03_notes.md; round 2's 8-byte keys: 16, flat between 10 and 24)
+constexpr uint32_t KEY_COST_BYTES = 10;
 // what a further kind of plane-scan launch costs a scan (pipeline ramp, tail, the launch boundary: 20-40 us), in plane bytes
 constexpr uint64_t LAUNCH_COST_BYTES = 192ull << 20;
 // one-hot rows: not at all / a row for every stored symbol / the most numerous symbol derived (LAYOUT_IMPLICIT)

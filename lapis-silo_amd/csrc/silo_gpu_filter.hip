@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -66,8 +67,9 @@ struct FilterEvalArgs {
    uint32_t n_slots;
    uint64_t* out;
    unsigned long long* out_count;
-   uint32_t* ticket;                 // count slot: blocks done so far
-   unsigned long long* host_total;   // count slot: page-locked host word the last block stores the total into
+   unsigned long long* host_parts;   // count slot: page-locked host words, one per block: epoch << 32 | rows the block selected
+   uint32_t epoch;                   // count slot: of this launch
+   uint32_t n_tiles;                 // 128-word tiles of the row (k_filter_eval_parts)
    const uint64_t* leaves[SILO_GPU_MAX_LEAVES];
    uint32_t code[2 * SILO_GPU_MAX_INSTRUCTIONS];
 };
@@ -77,50 +79,11 @@ struct FilterEvalArgs {
 // no spill) — neither moved the kernel time of the 32-column program (19-21 us at 10 M sequences either way).  Round 3:
 // blocks of 4 waves that fetch ALL leaves of a 128-word tile into LDS at once (32 loads in flight per tile) before wave 0
 // evaluates: 30 us instead of 20 (profiles/r03_notes.md) — the kernel is not waiting for its loads.
-/// The end of a filter kernel's wave (64 lanes, one per pair of result words): the popcount of the result goes to the count
-/// shards, and with a count slot the last block hands the total to the host.
-__device__ __forceinline__ void deliverFilterCount(const FilterEvalArgs& args, silo_gpu::Word2 result, uint32_t lane) {
-   if (args.out_count != nullptr && args.ticket == nullptr) {
+/// The end of a filter kernel's wave (64 lanes, one per pair of result words): the popcount of the result goes to the count shards.
+__device__ __forceinline__ void deliverFilterCount(const FilterEvalArgs& args, silo_gpu::Word2 result) {
+   if (args.out_count != nullptr) {
       const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
       addToCountShard(args.out_count, waveSumToLane63(bits));
-   }
-   if (args.ticket != nullptr) {
-      // Count slot: the last block to get here sums the shards, hands the total to the host through page-locked
-      // memory (no copy, no stream synchronisation on the host side) and re-arms shards and tickets for the next
-      // launch.  Atomics on one word serialise at ~12 ns each, so "last" is found in two levels: a ticket per shard
-      // class (blocks b with b % 64 == c), and a main ticket taken by the block that completes its class.
-      // Ordering uses only the atomics themselves (all performed at device scope, i.e. at the memory side): the shard
-      // add is a RETURNING atomic, so it has been performed when its result arrives, and the ticket is taken after
-      // that.  A __threadfence() here would be a release fence = an L2 write-back per block (the L2s of the 8 XCDs are
-      // not coherent with each other), which doubled the kernel time when tried.
-      const uint32_t bits = static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
-      const uint32_t wave_total = waveSumToLane63(bits);
-      uint32_t last = 0;
-      if (lane == 63) {
-         const uint32_t shard_class = blockIdx.x % SILO_GPU_COUNT_SHARDS;
-         unsigned long long before = 0;
-         if (wave_total != 0) {
-            before = atomicAdd(args.out_count + shard_class, static_cast<unsigned long long>(wave_total));
-         }
-         // the ticket increment is made to depend on the value the shard add returned
-         const uint32_t one = 1u + static_cast<uint32_t>((before >> 63) & 1ull);  // a shard never reaches 2^63: always 1
-         const uint32_t blocks_in_class = (gridDim.x - 1 - shard_class) / SILO_GPU_COUNT_SHARDS + 1;
-         const uint32_t class_ticket = atomicAdd(args.ticket + 1 + shard_class, one);
-         if (class_ticket == blocks_in_class - 1) {
-            const uint32_t classes = min(gridDim.x, static_cast<uint32_t>(SILO_GPU_COUNT_SHARDS));
-            const uint32_t cleared = atomicExch(args.ticket + 1 + shard_class, 0u);
-            last = atomicAdd(args.ticket, 1u + (cleared >> 31)) == classes - 1 ? 1u : 0u;
-         }
-      }
-      last = __shfl(last, 63);
-      if (last != 0) {
-         const unsigned long long shard = atomicExch(args.out_count + lane, 0ull);  // EVAL_THREADS == SILO_GPU_COUNT_SHARDS
-         const uint32_t total = waveSumToLane63(static_cast<uint32_t>(shard));      // a cardinality fits 32 bits
-         if (lane == 63) {
-            atomicExch(args.ticket, 0u);
-            __hip_atomic_store(args.host_total, static_cast<unsigned long long>(total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-         }
-      }
    }
 }
 
@@ -154,7 +117,98 @@ __global__ __launch_bounds__(EVAL_THREADS) void k_filter_eval(const FilterEvalAr
    if (active && args.out != nullptr) {
       *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
    }
-   deliverFilterCount(args, result, lane);
+   deliverFilterCount(args, result);
+}
+
+/// The filter of ONE query whose cardinality the host waits for (count slot).  Round 2 found the launch's last block on the
+/// device — a returning atomic on a count shard, a ticket per shard class, a main ticket, the sum of the shards, then the
+/// store to the host: five dependent round trips to the memory side (device-scope atomics are performed there, the L2s of the
+/// 8 XCDs not being coherent with each other), ~10 us of a 20 us kernel.  Here a block hands ITS count straight to the
+/// host — one posted 8-byte store into page-locked memory, tagged with the launch's epoch — and the host adds the parts up
+/// as they arrive: no atomic, no ticket, nothing to re-arm.  Blocks of several waves, every wave on its own tiles of the
+/// row (slots in LDS per wave, no barrier but the one before the block's store), at most COUNT_MAX_PARTS blocks.
+constexpr uint32_t COUNT_MAX_PARTS = 2048;
+/// WAVES per block; WORDS per lane: 2 (16-byte accesses) or 1.  One word per lane — twice the waves for a row — was tried
+/// for the query on its own (10 M rows are only 1 221 waves of 2 words on 1 024 SIMDs): no difference, 29.7 against 29.0 us
+/// end to end for configs[2] (profiles/r03_notes.md); the launches use 2.
+template <uint32_t BATCH, uint32_t WAVES, uint32_t WORDS>
+__global__ __launch_bounds__(WAVES * 64) void k_filter_eval_parts(const FilterEvalArgs args) {
+   using silo_gpu::Word2;
+   using Word = std::conditional_t<WORDS == 2, Word2, uint64_t>;
+   using Stored = std::conditional_t<WORDS == 2, ulonglong2, uint64_t>;
+   extern __shared__ ulonglong2 s_slots[];  // [wave][n_slots][64] of Stored
+   __shared__ uint32_t s_part[WAVES];
+   const uint32_t lane = threadIdx.x & 63u;
+   const uint32_t wave = threadIdx.x >> 6;
+   Stored* slots = reinterpret_cast<Stored*>(s_slots) + static_cast<size_t>(wave) * args.n_slots * 64u;
+   uint32_t selected = 0;
+   for (uint32_t tile = blockIdx.x * WAVES + wave; tile < args.n_tiles; tile += gridDim.x * WAVES) {  // (uniform per wave)
+      const uint32_t w = (tile * 64u + lane) * WORDS;  // row_words is a multiple of 32
+      const bool active = w < args.row_words;
+      const uint32_t w_safe = active ? w : 0;
+      Word valid = silo_gpu::zeroOf<Word>();
+      if (active) {
+         if constexpr (WORDS == 2) {
+            valid = {silo_gpu::valid_mask(w, args.sequence_count), silo_gpu::valid_mask(w + 1, args.sequence_count)};
+         } else {
+            valid = silo_gpu::valid_mask(w, args.sequence_count);
+         }
+      }
+      const auto leaf = [&](uint32_t index) -> Word {
+         if constexpr (WORDS == 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(args.leaves[index] + w_safe);
+            return {v.x, v.y};
+         } else {
+            return args.leaves[index][w_safe];
+         }
+      };
+      const auto get = [&](uint32_t index) -> Word {
+         if (index >= SILO_GPU_LEAF_OPERAND) {
+            return leaf(index - SILO_GPU_LEAF_OPERAND);
+         }
+         if constexpr (WORDS == 2) {
+            const ulonglong2 v = slots[index * 64u + lane];
+            return {v.x, v.y};
+         } else {
+            return slots[index * 64u + lane];
+         }
+      };
+      const auto set = [&](uint32_t index, Word value) {
+         if constexpr (WORDS == 2) {
+            slots[index * 64u + lane] = make_ulonglong2(value.x, value.y);
+         } else {
+            slots[index * 64u + lane] = value;
+         }
+      };
+      Word result = silo_gpu::bitprog_run<Word, BATCH>(args.code, args.n_instructions, valid, get, set, leaf);
+      result = result & valid;
+      if constexpr (WORDS == 2) {
+         if (active && args.out != nullptr) {
+            *reinterpret_cast<ulonglong2*>(args.out + w) = make_ulonglong2(result.x, result.y);
+         }
+         selected += static_cast<uint32_t>(__popcll(result.x)) + static_cast<uint32_t>(__popcll(result.y));
+      } else {
+         if (active && args.out != nullptr) {
+            args.out[w] = result;
+         }
+         selected += static_cast<uint32_t>(__popcll(result));
+      }
+   }
+   selected = waveSumToLane63(selected);
+   if (lane == 63u) {
+      s_part[wave] = selected;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < WAVES; ++k) {
+         total += s_part[k];
+      }
+      __hip_atomic_store(
+         args.host_parts + blockIdx.x, (static_cast<unsigned long long>(args.epoch) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+      );
+   }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,22 +676,20 @@ int silo_gpu_store_sparse_plane(const silo_gpu_store* store, uint32_t seqstore_i
 }
 
 struct silo_gpu_count_slot {
-   unsigned long long* d_shards = nullptr;  // SILO_GPU_COUNT_SHARDS words + the tickets behind them
-   uint32_t* d_ticket = nullptr;
-   unsigned long long* host_total = nullptr;    // page-locked, written by the kernel
-   unsigned long long* host_total_dev = nullptr;  // its device address
+   unsigned long long* host_parts = nullptr;      // page-locked, COUNT_MAX_PARTS words: epoch << 32 | the block's count
+   unsigned long long* host_parts_dev = nullptr;  // their device address
+   uint32_t epoch = 0;                            // of the launch in flight (never 0: the words start out as 0)
+   uint32_t n_parts = 0;                          // blocks of the launch in flight
 };
 
 namespace {
-constexpr unsigned long long COUNT_PENDING = ~0ull;
 int filterEvalLaunch(
-   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
-   unsigned long long* host_total_dev, void* stream
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, silo_gpu_count_slot* slot, void* stream
 );
 }  // namespace
 
 int silo_gpu_filter_eval(const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, void* stream) {
-   return filterEvalLaunch(store, program, out_bitset_dev, out_count_dev, nullptr, nullptr, stream);
+   return filterEvalLaunch(store, program, out_bitset_dev, out_count_dev, nullptr, stream);
 }
 
 int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot) {
@@ -648,25 +700,10 @@ int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot) {
    if (slot == nullptr) {
       return fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of host memory");
    }
-   // 64 count shards (64-bit), then the main ticket and one ticket per shard class (32-bit)
-   const size_t device_bytes = SILO_GPU_COUNT_SHARDS * sizeof(unsigned long long) + (1 + SILO_GPU_COUNT_SHARDS) * sizeof(uint32_t);
-   hipError_t err = hipMalloc(&slot->d_shards, device_bytes);
+   hipError_t err = hipHostMalloc(&slot->host_parts, COUNT_MAX_PARTS * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
    if (err == hipSuccess) {
-      err = hipMemset(slot->d_shards, 0, device_bytes);
-   }
-   if (err == hipSuccess) {
-      // hipMemset of device memory only ENQUEUES a fill on the null stream, and the slot's first launch comes on a
-      // non-blocking stream, which does not wait for the null stream: on a busy device the fill could land in the middle of
-      // that launch and wipe tickets already taken ("the kernel finished without delivering its total")
-      err = hipStreamSynchronize(nullptr);
-   }
-   if (err == hipSuccess) {
-      slot->d_ticket = reinterpret_cast<uint32_t*>(slot->d_shards + SILO_GPU_COUNT_SHARDS);
-      err = hipHostMalloc(&slot->host_total, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
-   }
-   if (err == hipSuccess) {
-      *slot->host_total = COUNT_PENDING;
-      err = hipHostGetDevicePointer(reinterpret_cast<void**>(&slot->host_total_dev), slot->host_total, 0);
+      memset(slot->host_parts, 0, COUNT_MAX_PARTS * sizeof(unsigned long long));
+      err = hipHostGetDevicePointer(reinterpret_cast<void**>(&slot->host_parts_dev), slot->host_parts, 0);
    }
    if (err != hipSuccess) {
       silo_gpu_count_slot_destroy(slot);
@@ -678,9 +715,8 @@ int silo_gpu_count_slot_create(silo_gpu_count_slot** out_slot) {
 
 void silo_gpu_count_slot_destroy(silo_gpu_count_slot* slot) {
    if (slot != nullptr) {
-      (void)hipFree(slot->d_shards);
-      if (slot->host_total != nullptr) {
-         (void)hipHostFree(slot->host_total);
+      if (slot->host_parts != nullptr) {
+         (void)hipHostFree(slot->host_parts);
       }
       delete slot;
    }
@@ -692,38 +728,45 @@ int silo_gpu_filter_eval_count(
    if (slot == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval_count: null slot");
    }
-   __atomic_store_n(slot->host_total, COUNT_PENDING, __ATOMIC_RELEASE);
-   return filterEvalLaunch(
-      store, program, out_bitset_dev, reinterpret_cast<uint64_t*>(slot->d_shards), slot->d_ticket, slot->host_total_dev, stream
-   );
+   slot->epoch = slot->epoch == 0xFFFFFFFFu ? 1u : slot->epoch + 1u;  // a part counts only when it carries this launch's epoch
+   slot->n_parts = 0;
+   return filterEvalLaunch(store, program, out_bitset_dev, nullptr, slot, stream);
 }
 
 int silo_gpu_count_slot_wait(silo_gpu_count_slot* slot, uint64_t* out_count, void* stream) {
    if (slot == nullptr || out_count == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_count_slot_wait: null argument");
    }
-   // The kernel's last block stores the total with system scope.  The wait is a pure spin on that word — no HIP call from
-   // the polling threads (round 1 polled hipStreamQuery from every request thread; under rocprofv3's kernel tracing that run
-   // segfaulted, and whether the fault was the profiler's or the polling's was never established, so the polling is gone).
-   // A launch that does not deliver within the spin budget (tens of milliseconds: a failed or wedged launch, or a very busy
-   // device) is waited for with ONE blocking hipStreamSynchronize, which also reports a broken stream.
-   constexpr uint64_t SPIN_BUDGET = uint64_t{1} << 20;
-   for (uint64_t spin = 0; spin < SPIN_BUDGET; ++spin) {
-      const unsigned long long value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
-      if (value != COUNT_PENDING) {
-         *out_count = value;
-         return SILO_GPU_OK;
-      }
+   // Every block stores its part with system scope.  The wait is a pure spin on those words — no HIP call from the polling
+   // threads (round 1 polled hipStreamQuery from every request thread; under rocprofv3's kernel tracing that run segfaulted,
+   // and whether the fault was the profiler's or the polling's was never established, so the polling is gone).  A launch that
+   // does not deliver within the spin budget (tens of milliseconds: a failed or wedged launch, or a very busy device) is
+   // waited for with ONE blocking hipStreamSynchronize, which also reports a broken stream.
+   constexpr uint64_t SPIN_BUDGET = uint64_t{1} << 22;
+   uint64_t spins = 0;
+   uint64_t total = 0;
+   bool synchronised = false;
+   for (uint32_t part = 0; part < slot->n_parts; ++part) {
+      for (;;) {
+         const unsigned long long value = __atomic_load_n(slot->host_parts + part, __ATOMIC_ACQUIRE);
+         if (static_cast<uint32_t>(value >> 32) == slot->epoch) {
+            total += static_cast<uint32_t>(value);
+            break;
+         }
+         if (synchronised) {
+            return fail(SILO_GPU_ERR_HIP, "count slot: the kernel finished without delivering its total");
+         }
+         if (++spins >= SPIN_BUDGET) {
+            HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+            synchronised = true;
+            continue;
+         }
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+         __builtin_ia32_pause();
 #endif
+      }
    }
-   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-   const unsigned long long value = __atomic_load_n(slot->host_total, __ATOMIC_ACQUIRE);
-   if (value == COUNT_PENDING) {
-      return fail(SILO_GPU_ERR_HIP, "count slot: the kernel finished without delivering its total");
-   }
-   *out_count = value;
+   *out_count = total;
    return SILO_GPU_OK;
 }
 
@@ -797,8 +840,7 @@ int validateProgram(const silo_gpu_bitprog* program) {
 }
 
 int filterEvalLaunch(
-   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, uint32_t* ticket_dev,
-   unsigned long long* host_total_dev, void* stream
+   const silo_gpu_store* store, const silo_gpu_bitprog* program, uint64_t* out_bitset_dev, uint64_t* out_count_dev, silo_gpu_count_slot* slot, void* stream
 ) {
    if (store == nullptr || program == nullptr || program->code == nullptr) {
       return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_gpu_filter_eval: bad arguments");
@@ -814,15 +856,37 @@ int filterEvalLaunch(
    args.n_slots = program->n_slots;
    args.out = out_bitset_dev;
    args.out_count = reinterpret_cast<unsigned long long*>(out_count_dev);
-   args.ticket = ticket_dev;
-   args.host_total = host_total_dev;
    for (uint32_t k = 0; k < program->n_leaves; ++k) {
       args.leaves[k] = program->leaves[k];
    }
    memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
+   const bool wide = g_tune_eval_leaf_batch.load() == 16;
+   if (slot != nullptr) {  // the host waits for the cardinality: a part per block, straight into page-locked memory
+      constexpr uint32_t WAVES = 4;
+      args.n_tiles = (store->row_words + 127u) / 128u;
+      const uint32_t blocks = std::min<uint32_t>((args.n_tiles + WAVES - 1) / WAVES, COUNT_MAX_PARTS);
+      args.host_parts = slot->host_parts_dev;
+      args.epoch = slot->epoch;
+      const size_t lds_bytes = static_cast<size_t>(program->n_slots) * WAVES * 64 * sizeof(ulonglong2);  // <= 128 KiB
+      static std::once_flag lds_once;
+      std::call_once(lds_once, [] {
+         const int most = SILO_GPU_MAX_SLOTS * WAVES * 64 * static_cast<int>(sizeof(ulonglong2));
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<8, WAVES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<16, WAVES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+      });
+      const auto hip_stream = static_cast<hipStream_t>(stream);
+      if (wide) {
+         k_filter_eval_parts<16, WAVES, 2><<<blocks, WAVES * 64, lds_bytes, hip_stream>>>(args);
+      } else {
+         k_filter_eval_parts<8, WAVES, 2><<<blocks, WAVES * 64, lds_bytes, hip_stream>>>(args);
+      }
+      HIP_TRY(hipGetLastError());
+      slot->n_parts = blocks;
+      return SILO_GPU_OK;
+   }
    const uint32_t blocks = (store->row_words + EVAL_WORDS_PER_BLOCK - 1) / EVAL_WORDS_PER_BLOCK;
    const size_t lds_bytes = static_cast<size_t>(program->n_slots) * EVAL_THREADS * sizeof(ulonglong2);  // <= 32 KiB
-   if (g_tune_eval_leaf_batch.load() == 16) {
+   if (wide) {
       k_filter_eval<16><<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);
    } else {
       k_filter_eval<8><<<blocks, EVAL_THREADS, lds_bytes, static_cast<hipStream_t>(stream)>>>(args);

@@ -886,24 +886,41 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
    if (run_begin + blockIdx.x * (DERIVED_THREADS * RUNS_IN_FLIGHT) >= run_end) {
       return;  // (uniform) no chunk of runs for this block
    }
+   // the slice's runs are dealt to the gridDim.x blocks of the slice in chunks of RUNS_IN_FLIGHT x 1024; a chunk's loads are
+   // in flight together, and the next chunk's while this one is counted (the first beside the filter slice)
+   const uint32_t chunk_runs = DERIVED_THREADS * RUNS_IN_FLIGHT;
+   const auto loadRuns = [&](uint64_t (&key)[RUNS_IN_FLIGHT], uint32_t (&run_last)[RUNS_IN_FLIGHT], uint32_t base) {
+#pragma unroll
+      for (uint32_t k = 0; k < RUNS_IN_FLIGHT; ++k) {
+         const uint32_t i = base + k * DERIVED_THREADS + threadIdx.x;
+         key[k] = i < run_end ? range.run_keys[i] : 0;
+         run_last[k] = i < run_end ? range.run_ends[i] : 0;  // (an empty run: start >= end below)
+      }
+   };
    uint64_t any_bit = 0;
+   ulonglong2 filter_part[ESCAPE_SLICE_WORDS32 / 4u / DERIVED_THREADS];
    {
       const uint64_t* filter = args.filters[q];
       const uint32_t first_word = slice * (ESCAPE_SLICE_WORDS32 / 2u);
 #pragma unroll
       for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / DERIVED_THREADS; ++j) {
-         const uint32_t chunk = j * DERIVED_THREADS + threadIdx.x;  // 16-byte chunk of the slice
-         const uint32_t word = first_word + chunk * 2u;
-         const ulonglong2 v = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
-         *reinterpret_cast<ulonglong2*>(s_runs + chunk * 4u) = v;
-         any_bit |= v.x | v.y;
+         const uint32_t word = first_word + (j * DERIVED_THREADS + threadIdx.x) * 2u;  // 16-byte chunk of the slice
+         filter_part[j] = word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
       }
    }
+   uint64_t next_key[RUNS_IN_FLIGHT];
+   uint32_t next_last[RUNS_IN_FLIGHT];
+   loadRuns(next_key, next_last, run_begin + blockIdx.x * chunk_runs);
    const uint32_t n = range.n_positions;
    if constexpr (LDS_DIFF) {
-      for (uint32_t j = threadIdx.x; j <= n; j += DERIVED_THREADS) {
-         s_diff[j] = 0;
+      for (uint32_t j = threadIdx.x * 4u; j <= n; j += DERIVED_THREADS * 4u) {  // (16 bytes per store; the array is rounded up to them)
+         *reinterpret_cast<uint4*>(s_diff + j) = make_uint4(0, 0, 0, 0);
       }
+   }
+#pragma unroll
+   for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / DERIVED_THREADS; ++j) {
+      *reinterpret_cast<ulonglong2*>(s_runs + (j * DERIVED_THREADS + threadIdx.x) * 4u) = filter_part[j];
+      any_bit |= filter_part[j].x | filter_part[j].y;
    }
    if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
       return;  // no row of this slice is selected
@@ -911,15 +928,17 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
    uint32_t* __restrict__ diff = range.scratch + static_cast<size_t>(q) * range.stride + static_cast<size_t>(n) * range.n_scan;
    const uint32_t slice_first_row = slice << ESCAPE_SLICE_SHIFT;
    const uint32_t pos_end = range.pos_begin + n;
-   // the slice's runs are dealt to the gridDim.x blocks of the slice in chunks of RUNS_IN_FLIGHT x 1024 (loads of a chunk in flight together)
-   for (uint32_t base = run_begin + blockIdx.x * (DERIVED_THREADS * RUNS_IN_FLIGHT); base < run_end; base += gridDim.x * (DERIVED_THREADS * RUNS_IN_FLIGHT)) {
+   uint32_t from_the_first = 0;  // selected runs that begin at or before the range's first position (sequences that begin with the missing symbol: every lane on one counter otherwise)
+   for (uint32_t base = run_begin + blockIdx.x * chunk_runs; base < run_end; base += gridDim.x * chunk_runs) {
       uint64_t key[RUNS_IN_FLIGHT];
       uint32_t run_last[RUNS_IN_FLIGHT];
 #pragma unroll
       for (uint32_t k = 0; k < RUNS_IN_FLIGHT; ++k) {
-         const uint32_t i = base + k * DERIVED_THREADS + threadIdx.x;
-         key[k] = i < run_end ? range.run_keys[i] : 0;
-         run_last[k] = i < run_end ? range.run_ends[i] : 0;  // (an empty run: start >= end below)
+         key[k] = next_key[k];
+         run_last[k] = next_last[k];
+      }
+      if (base + gridDim.x * chunk_runs < run_end) {  // (uniform)
+         loadRuns(next_key, next_last, base + gridDim.x * chunk_runs);
       }
 #pragma unroll
       for (uint32_t k = 0; k < RUNS_IN_FLIGHT; ++k) {
@@ -928,14 +947,29 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
          const uint32_t start = max(static_cast<uint32_t>(key[k]), range.pos_begin);
          const uint32_t end = min(run_last[k], pos_end);
          if (selected && start < end) {
-            if constexpr (LDS_DIFF) {
+            if (start == range.pos_begin) {
+               from_the_first += 1;
+            } else if constexpr (LDS_DIFF) {
                atomicAdd(&s_diff[start - range.pos_begin], 1u);
-               atomicAdd(&s_diff[end - range.pos_begin], 0xFFFFFFFFu);
             } else {
                atomicAdd(&diff[start - range.pos_begin], 1u);
-               atomicAdd(&diff[end - range.pos_begin], 0xFFFFFFFFu);
+            }
+            if (end < pos_end) {  // (the entry behind the last position is never summed)
+               if constexpr (LDS_DIFF) {
+                  atomicAdd(&s_diff[end - range.pos_begin], 0xFFFFFFFFu);
+               } else {
+                  atomicAdd(&diff[end - range.pos_begin], 0xFFFFFFFFu);
+               }
             }
          }
+      }
+   }
+   from_the_first = waveSumToLane63(from_the_first);
+   if ((threadIdx.x & 63u) == 63u && from_the_first != 0) {
+      if constexpr (LDS_DIFF) {
+         atomicAdd(&s_diff[0], from_the_first);
+      } else {
+         atomicAdd(&diff[0], from_the_first);
       }
    }
    if constexpr (LDS_DIFF) {
@@ -1740,7 +1774,7 @@ int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_s
          continue;
       }
       // the diff of a range in LDS beside the filter slice, while it fits
-      const size_t lds_bytes = (ESCAPE_SLICE_WORDS32 + static_cast<size_t>(plan.most_positions) + 1) * sizeof(uint32_t);
+      const size_t lds_bytes = (ESCAPE_SLICE_WORDS32 + (static_cast<size_t>(plan.most_positions) + 4) / 4 * 4) * sizeof(uint32_t);
       const bool lds_diff = lds_bytes <= 152 * 1024;
       static std::once_flag lds_once;
       std::call_once(lds_once, [] {

