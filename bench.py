@@ -378,30 +378,15 @@ def filter_workload(engine, model, tree, n_sequences, sync, seconds=2.0):
     for _ in range(5):
         engine.execute_text(wire)
     sync()
-    n = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        engine.execute_text(wire)
-        n += 1
-    sequential = (time.perf_counter() - t0) / n
-
-    done = []
-
-    def client():
-        k = 0
-        end = time.perf_counter() + seconds
-        while time.perf_counter() < end:
-            engine.execute_text(wire)
-            k += 1
-        done.append(k)
-
-    threads = [threading.Thread(target=client) for _ in range(8)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    concurrent = sum(done) / (time.perf_counter() - t0)
+    # native request threads (silo_engine_run_clients), one query at a time each: the interpreter's lock is not in the figure
+    expected = engine.execute_text(wire)[1]
+    per_second, body = engine.run_clients(wire, 1, seconds)
+    if body != expected:
+        raise AssertionError("a client's response differs")
+    sequential = 1.0 / per_second
+    concurrent, body = engine.run_clients(wire, 8, seconds)
+    if body != expected:
+        raise AssertionError("a client's response differs")
     w8 = 8 * ((n_sequences + 63) // 64)
 
     # SURVEY.md §8(d) C3 "batched throughput, >= 64 in flight": 64 DIFFERENT queries of this shape (disjoint leaf sets:

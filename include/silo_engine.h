@@ -137,6 +137,16 @@ int silo_engine_set_option(silo_engine* engine, const char* name, int64_t value)
  * themselves are invalid.  Re-entrant: may be called from many threads on one engine. */
 int silo_engine_execute_query(const silo_engine* engine, const char* query_json, char** out_json, int* out_http_status);
 
+/* Measurement helper (bench.py, tools/): `n_clients` request threads — what silo_api's request handler threads are to the
+ * reference — each call silo_engine_execute_query with the same query, one query at a time, for `seconds`; *out_queries =
+ * queries answered with status 200 by all of them, *out_seconds = the wall time they took, *out_response (malloc'ed, may be
+ * NULL to ignore) = the last response of client 0.  Any other status stops the run and is returned as an error.  The clients
+ * are native threads: a Python caller's interpreter lock is not part of the figure. */
+int silo_engine_run_clients(
+   const silo_engine* engine, const char* query_json, uint32_t n_clients, double seconds, uint64_t* out_queries, double* out_seconds,
+   char** out_response
+);
+
 /* The inner seam of SURVEY.md §8(b): Expression::compile + Operator::evaluate of ONE filter for ONE partition
  * (query_engine.cpp:40-49; operator.h:32 `evaluate() -> OperatorResult`), handing back what the reference's
  * OperatorResult holds — the set of sequence ids — as a bitset in host memory (bit i of word w = row 64 * w + i of the

@@ -862,23 +862,35 @@ int filterEvalLaunch(
    memcpy(args.code, program->code, static_cast<size_t>(program->n_instructions) * 2 * sizeof(uint32_t));
    const bool wide = g_tune_eval_leaf_batch.load() == 16;
    if (slot != nullptr) {  // the host waits for the cardinality: a part per block, straight into page-locked memory
-      constexpr uint32_t WAVES = 4;
+      // Waves per block: 8 while the slots of 8 waves fit the LDS, else 4.  Fewer, fatter blocks = fewer parts: the posted
+      // 8-byte stores to the host are the scarce thing when several clients query at once (8 one-by-one clients with a part per
+      // 4 waves: 306 stores per query, 23 M/s, and throughput fell to 76 k queries/s — profiles/r03_notes.md).
+      const bool fat = program->n_slots <= 16;
+      const uint32_t waves = fat ? 8u : 4u;
       args.n_tiles = (store->row_words + 127u) / 128u;
-      const uint32_t blocks = std::min<uint32_t>((args.n_tiles + WAVES - 1) / WAVES, COUNT_MAX_PARTS);
+      const uint32_t blocks = std::min<uint32_t>((args.n_tiles + waves - 1) / waves, COUNT_MAX_PARTS);
       args.host_parts = slot->host_parts_dev;
       args.epoch = slot->epoch;
-      const size_t lds_bytes = static_cast<size_t>(program->n_slots) * WAVES * 64 * sizeof(ulonglong2);  // <= 128 KiB
+      const size_t lds_bytes = static_cast<size_t>(program->n_slots) * waves * 64 * sizeof(ulonglong2);  // <= 128 KiB
       static std::once_flag lds_once;
       std::call_once(lds_once, [] {
-         const int most = SILO_GPU_MAX_SLOTS * WAVES * 64 * static_cast<int>(sizeof(ulonglong2));
-         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<8, WAVES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<16, WAVES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         const int most = 128 * 1024;
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<8, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<16, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<8, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_eval_parts<16, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
       });
       const auto hip_stream = static_cast<hipStream_t>(stream);
-      if (wide) {
-         k_filter_eval_parts<16, WAVES, 2><<<blocks, WAVES * 64, lds_bytes, hip_stream>>>(args);
+      if (fat) {
+         if (wide) {
+            k_filter_eval_parts<16, 8, 2><<<blocks, 8 * 64, lds_bytes, hip_stream>>>(args);
+         } else {
+            k_filter_eval_parts<8, 8, 2><<<blocks, 8 * 64, lds_bytes, hip_stream>>>(args);
+         }
+      } else if (wide) {
+         k_filter_eval_parts<16, 4, 2><<<blocks, 4 * 64, lds_bytes, hip_stream>>>(args);
       } else {
-         k_filter_eval_parts<8, WAVES, 2><<<blocks, WAVES * 64, lds_bytes, hip_stream>>>(args);
+         k_filter_eval_parts<8, 4, 2><<<blocks, 4 * 64, lds_bytes, hip_stream>>>(args);
       }
       HIP_TRY(hipGetLastError());
       slot->n_parts = blocks;

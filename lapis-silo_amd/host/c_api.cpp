@@ -1,7 +1,12 @@
 // c_api.cpp — extern "C" surface of the C++ host (include/silo_engine.h).
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <new>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "dataset_loader.h"
 #include "query_engine.h"
@@ -428,6 +433,53 @@ int silo_engine_execute_query(const silo_engine* engine, const char* query_json,
       *out_http_status = 500;
    }
    return *out_json != nullptr ? 0 : fail(SILO_GPU_ERR_OUT_OF_MEMORY, "out of memory");
+}
+
+int silo_engine_run_clients(
+   const silo_engine* engine, const char* query_json, uint32_t n_clients, double seconds, uint64_t* out_queries, double* out_seconds,
+   char** out_response
+) {
+   if (engine == nullptr || query_json == nullptr || n_clients == 0 || n_clients > 256 || out_queries == nullptr || out_seconds == nullptr) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_run_clients: bad arguments");
+   }
+   std::atomic<uint64_t> answered{0};
+   std::atomic<bool> failed{false};
+   std::string last_response;
+   const auto begin = std::chrono::steady_clock::now();
+   const auto end = begin + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
+   std::vector<std::thread> clients;
+   clients.reserve(n_clients);
+   for (uint32_t client = 0; client < n_clients; ++client) {
+      clients.emplace_back([&, client] {
+         uint64_t mine = 0;
+         while (!failed.load(std::memory_order_relaxed) && std::chrono::steady_clock::now() < end) {
+            char* response = nullptr;
+            int status = 0;
+            if (silo_engine_execute_query(engine, query_json, &response, &status) != 0 || status != 200) {
+               failed.store(true);
+            } else {
+               ++mine;
+            }
+            if (client == 0 && response != nullptr) {
+               last_response = response;
+            }
+            free(response);
+         }
+         answered.fetch_add(mine);
+      });
+   }
+   for (std::thread& client : clients) {
+      client.join();
+   }
+   *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
+   *out_queries = answered.load();
+   if (out_response != nullptr) {
+      *out_response = duplicate(last_response);
+   }
+   if (failed.load()) {
+      return fail(SILO_GPU_ERR_INVALID_ARGUMENT, "silo_engine_run_clients: a query was not answered with status 200: " + last_response);
+   }
+   return 0;
 }
 
 int silo_engine_evaluate_filter(

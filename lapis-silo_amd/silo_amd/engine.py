@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(binding._LIB_DIR, "libsilo_engine.so")
 EXPORTED_SYMBOLS = [
     "silo_engine_create", "silo_engine_create_from_directory", "silo_engine_destroy", "silo_engine_add_partition", "silo_engine_append_sequences",
     "silo_engine_generate_synthetic", "silo_engine_build_pass", "silo_engine_set_lineage_column", "silo_engine_set_lineage_column_ids",
-    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_comm", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_evaluate_filter", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
+    "silo_engine_set_schema", "silo_engine_append_metadata", "silo_engine_append_unaligned_sequences", "silo_engine_finalize", "silo_engine_set_sharding", "silo_engine_set_comm", "silo_engine_set_broadcast", "silo_engine_set_option", "silo_engine_execute_query", "silo_engine_run_clients", "silo_engine_evaluate_filter", "silo_engine_execute_batch", "silo_engine_free_string", "silo_engine_data_version",
     "silo_engine_last_timings", "silo_engine_last_trace", "silo_engine_partition_store", "silo_engine_seqstore_id", "silo_engine_position_window",
     "silo_engine_last_error",
 ]
@@ -60,6 +60,8 @@ def load_library():
     lib.silo_engine_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     lib.silo_engine_execute_query.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
     lib.silo_engine_execute_batch.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]
+    lib.silo_engine_run_clients.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(vp)]
     lib.silo_engine_free_string.argtypes = [vp]
     lib.silo_engine_free_string.restype = None
     lib.silo_engine_last_timings.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
@@ -277,6 +279,19 @@ class Engine:
         finally:
             self.lib.silo_engine_free_string(out)
         return status.value, body
+
+    def run_clients(self, query, n_clients, seconds):
+        """silo_engine_run_clients: native request threads, one query at a time each -> (queries per second, last response body)."""
+        text = query if isinstance(query, (str, bytes)) else json.dumps(query)
+        if isinstance(text, str):
+            text = text.encode()
+        answered, elapsed, out = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_void_p()
+        _check(self.lib.silo_engine_run_clients(self.handle, text, n_clients, float(seconds), ctypes.byref(answered), ctypes.byref(elapsed), ctypes.byref(out)))
+        try:
+            body = ctypes.string_at(out)
+        finally:
+            self.lib.silo_engine_free_string(out)
+        return answered.value / elapsed.value, body
 
     def evaluate_filter(self, expression, partition=0, n_rows=None):
         """Operator::evaluate for one partition: (bitset as uint64 words, cardinality).  n_rows = the partition's row count."""
