@@ -643,9 +643,8 @@ __device__ __forceinline__ void ldsBarrier() {
 /// window behind its first key: the block counts into a window of LDS counters per filter and then adds the window to the
 /// table with CONTIGUOUS atomics — 64 consecutive counters per wave instruction, the shape the memory side takes at full
 /// rate; a lane per scattered counter, as the first version did, is an order of magnitude slower per add (MI355X guide,
-/// "Global float atomics": access shape).  A lane first sums the selected keys of its own four per counter (they mostly share
-/// one), so neighbouring lanes meet on an LDS counter three at a time, not sixty-four (identical addresses do not combine for
-/// LDS atomics: 64 lanes on one counter are 64 LDS cycles).  A key past the window (stretches of positions almost without
+/// "Global float atomics": access shape).  Lanes whose keys share a counter add through the stretch's first and last lane only
+/// (identical addresses do not combine for LDS atomics).  A key past the window (stretches of positions almost without
 /// keys) goes to the table directly.  No barrier between a block's granules: its waves run on by themselves, one waits for its
 /// keys while another counts; two blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
 template <int FILTERS>
@@ -760,34 +759,55 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
             valid[c] = keys4[c] != ESCAPE_KEY_INVALID && i + c >= key_begin && i + c < block_end;
             in_window[c] = granule_counter + (keys4[c] >> ESCAPE_SLICE_SHIFT);
          }
-         // Column c of the granule (the c-th key of every lane) is a sorted list by itself: lanes with the same counter form
-         // stretches, a stretch's first lane adds the number of selected keys of the whole stretch (a population count of the
-         // wave's ballot under the stretch's mask) — no two lanes of one instruction meet on an LDS counter.
+         // A lane's four keys are consecutive keys of the sorted list.  Those on the counter of its first key are summed in the
+         // lane (n0 <= 4); across the lanes these first counters ascend, lanes on the same one form a stretch, and a stretch adds
+         // ONCE, through its last lane: the selected keys of the lanes up to and including it (population counts of the wave's
+         // ballots of the bits of n0) minus those before the stretch's first lane (fetched from that lane) — no 64 lanes on one
+         // LDS counter (identical addresses do not combine: ~12 cycles per lane), no add at all for a stretch without a selected
+         // key (the keys read along outside the block's share lie in such stretches), and ~80 instructions per four keys where a
+         // stretch mask per key column took 300.  A key on another counter than the lane's first (a lane on a boundary) adds by itself.
          const uint32_t lane = __lane_id();
+         const uint32_t counter0 = in_window[0];
+         const uint32_t previous = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(counter0), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+         const uint32_t following = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(counter0), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+         const bool head = lane == 0 || counter0 != previous;
+         const bool tail = lane == 63 || counter0 != following;
+         const uint64_t heads_at_or_below = __ballot(head) & (~uint64_t{0} >> (63u - lane));  // (lane 0 is one: never empty)
+         const uint32_t first_of_stretch = 63u - static_cast<uint32_t>(__builtin_clzll(heads_at_or_below));
 #pragma unroll
-         for (uint32_t c = 0; c < 4; ++c) {
-            const uint32_t previous = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(in_window[c]), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
-            const bool head = lane == 0 || in_window[c] != previous;
-            const uint64_t heads = __ballot(head);
-            const uint64_t above = lane == 63 ? 0 : heads & (~uint64_t{0} << (lane + 1u));
-            const uint64_t below_end = above == 0 ? ~uint64_t{0} : (uint64_t{1} << __builtin_ctzll(above)) - 1u;
-            const uint64_t stretch = below_end & (~uint64_t{0} << lane);  // the lanes [this one, the next stretch's first)
-            const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
-#pragma unroll
-            for (int f = 0; f < FILTERS; ++f) {
-               const bool selected = valid[c] && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & 1u) != 0;
-               const uint64_t chosen = __ballot(selected);
-               if (head) {
-                  const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(chosen & stretch));
-                  if (n != 0) {
-                     if (in_window[c] < WINDOW) {
-                        atomicAdd(&s_count[f * WINDOW + in_window[c]], n);
-                     } else {  // a key past the window: straight to the table
-                        uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter];
-                        atomicAdd(&table[in_window[c] + window_first], n);
-                     }
-                  }
+         for (int f = 0; f < FILTERS; ++f) {
+            uint32_t* __restrict__ window = s_count + f * WINDOW;
+            uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
+            const auto add = [&](uint32_t counter, uint32_t value) {
+               if (counter < WINDOW) {
+                  atomicAdd(&window[counter], value);
+               } else {  // a key past the window: straight to the table
+                  atomicAdd(&table[counter], value);
                }
+            };
+            uint32_t n0 = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+               const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
+               const bool selected = valid[c] && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & 1u) != 0;
+               if (c == 0 || in_window[c] == counter0) {
+                  n0 += selected ? 1u : 0u;
+               } else if (selected) {
+                  add(in_window[c], 1u);
+               }
+            }
+            // selected keys of the lanes below this one, from the ballots of the three bits of n0
+            const uint64_t bit0 = __ballot((n0 & 1u) != 0);
+            const uint64_t bit1 = __ballot((n0 & 2u) != 0);
+            const uint64_t bit2 = __ballot((n0 & 4u) != 0);
+            const auto below = [](uint64_t mask) {
+               return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            };
+            const uint32_t before = below(bit0) + 2u * below(bit1) + 4u * below(bit2);
+            const uint32_t before_stretch = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(first_of_stretch * 4u), static_cast<int>(before)));
+            const uint32_t value = before + n0 - before_stretch;
+            if (tail && value != 0) {
+               add(counter0, value);
             }
          }
       }
@@ -865,6 +885,12 @@ struct DerivedArgs {
    uint32_t n_run_slices;
    uint32_t n_ranges;
    uint32_t first_unit[DERIVED_MAX_RANGES + 1];  // blocks per range (k_count_sparse_keys, k_finish_scan: each their own)
+   // k_scan_missing_runs with the diff in LDS: a block hands its diff over as a part — [filter][range][slice][block of the slice]
+   // x part_stride words, plain stores — and raises its flag (zeroed by the prepare step); k_sum_run_parts adds the parts up
+   uint32_t* run_parts;
+   uint32_t* run_flags;
+   uint32_t part_stride;
+   uint32_t run_blocks_per_slice;
    DerivedRange ranges[DERIVED_MAX_RANGES];
 };
 
@@ -973,12 +999,67 @@ __global__ __launch_bounds__(DERIVED_THREADS) void k_scan_missing_runs(const Der
       }
    }
    if constexpr (LDS_DIFF) {
+      // The block's diff leaves as a part of its own, in plain 16-byte stores; k_sum_run_parts adds the parts up.  (Adding it
+      // to the range's diff with atomics from here — 231 blocks x 30 000 entries at 10 M rows, device-scope atomics are
+      // performed at the memory side — took 30 of this kernel's 43 us: profiles/r03_notes.md.)
       __syncthreads();
-      for (uint32_t j = threadIdx.x; j <= n; j += DERIVED_THREADS) {
-         const uint32_t value = s_diff[j];
-         if (value != 0) {
-            atomicAdd(&diff[j], value);
+      const uint32_t part = ((q * args.n_ranges + blockIdx.y / args.n_run_slices) * args.n_run_slices + slice) * gridDim.x + blockIdx.x;
+      uint32_t* __restrict__ out = args.run_parts + static_cast<size_t>(part) * args.part_stride;
+      for (uint32_t j = threadIdx.x * 4u; j <= n; j += DERIVED_THREADS * 4u) {
+         *reinterpret_cast<uint4*>(out + j) = *reinterpret_cast<const uint4*>(s_diff + j);
+      }
+      if (threadIdx.x == 0) {
+         args.run_flags[part] = 1u;
+      }
+   }
+}
+
+/// diff[j] of a range and filter += the parts of the blocks of k_scan_missing_runs that raised their flag.  grid = (blocks of
+/// 1024 entries, range x RUN_PART_GROUPS, filter): a thread owns 4 consecutive entries and a group of parts.
+constexpr uint32_t RUN_PART_GROUPS = 16;
+__global__ __launch_bounds__(256) void k_sum_run_parts(const DerivedArgs args) {
+   const uint32_t q = blockIdx.z;
+   const uint32_t r = blockIdx.y / RUN_PART_GROUPS;
+   const uint32_t group = blockIdx.y % RUN_PART_GROUPS;
+   const DerivedRange& range = args.ranges[r];
+   const uint32_t n = range.n_positions;
+   const uint32_t j = (blockIdx.x * 256u + threadIdx.x) * 4u;
+   if (range.code_map == nullptr || blockIdx.x * 1024u > n) {
+      return;  // (uniform)
+   }
+   const uint32_t parts_of_range = args.n_run_slices * args.run_blocks_per_slice;
+   const uint32_t per_group = (parts_of_range + RUN_PART_GROUPS - 1) / RUN_PART_GROUPS;
+   const uint32_t first = (q * args.n_ranges + r) * parts_of_range;
+   const uint32_t begin = first + group * per_group;
+   const uint32_t end = min(begin + per_group, first + parts_of_range);
+   const uint32_t j_safe = j <= n ? j : 0;
+   uint4 sum = make_uint4(0, 0, 0, 0);
+   for (uint32_t part = begin; part < end; part += 8) {  // (uniform) eight parts' loads in flight
+      uint4 v[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+         v[k] = make_uint4(0, 0, 0, 0);
+         if (part + k < end && args.run_flags[part + k] != 0) {
+            v[k] = *reinterpret_cast<const uint4*>(args.run_parts + static_cast<size_t>(part + k) * args.part_stride + j_safe);
          }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+         sum.x += v[k].x;
+         sum.y += v[k].y;
+         sum.z += v[k].z;
+         sum.w += v[k].w;
+      }
+   }
+   if (j > n) {
+      return;
+   }
+   uint32_t* __restrict__ diff = range.scratch + static_cast<size_t>(q) * range.stride + static_cast<size_t>(n) * range.n_scan;
+   const uint32_t values[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+   for (uint32_t c = 0; c < 4; ++c) {
+      if (values[c] != 0 && j + c <= n) {
+         atomicAdd(&diff[j + c], values[c]);
       }
    }
 }
@@ -1703,9 +1784,16 @@ struct DerivedPlan {
    std::vector<DerivedArgs> launches;     // ranges [16 k, 16 k + 16) of the scan
    std::vector<ScanRange> private_ranges;  // the ranges with their count tables replaced by the private ones
    std::vector<std::array<uint64_t, DERIVED_MAX_RANGES>> run_counts;  // [launch][range] runs of the missing symbol of the range's store (for the timing log)
-   size_t table_words = 0;
+   size_t table_words = 0;       // zeroed by the prepare step: the tables, then the flags of the run parts
+   size_t part_words = 0;        // behind them, not zeroed: the run parts (k_scan_missing_runs -> k_sum_run_parts)
    uint32_t most_positions = 0;  // of a range with derived symbols
 };
+
+/// Blocks per slice of k_scan_missing_runs: one block per CU fits (its LDS), about one round of the 256 CUs over all (slice, range, filter).
+uint32_t runBlocksPerSlice(const DerivedArgs& launch, uint32_t q_count) {
+   const uint32_t run_units = std::max<uint32_t>(1, launch.n_run_slices * launch.n_ranges * q_count);
+   return std::min<uint32_t>(8, std::max<uint32_t>(1, 240 / run_units));
+}
 
 /// Lays the private tables of `ranges` out (offsets only: `tables` may still be null) .
 void planDerived(const silo_gpu_store* store, const std::vector<ScanRange>& ranges, const uint64_t* const* filters, uint32_t q_count, DerivedPlan& plan) {
@@ -1745,7 +1833,20 @@ void planDerived(const silo_gpu_store* store, const std::vector<ScanRange>& rang
       }
       launch.row_words = store->row_words;
    }
+   // the parts of the blocks of k_scan_missing_runs: flags in the zeroed area, the parts behind it (offsets until bindDerived)
+   const uint32_t part_stride = (plan.most_positions + 4) / 4 * 4;
+   size_t part_offset = 0;
+   for (DerivedArgs& launch : plan.launches) {
+      launch.run_blocks_per_slice = runBlocksPerSlice(launch, q_count);
+      launch.part_stride = part_stride;
+      const size_t parts = static_cast<size_t>(q_count) * launch.n_ranges * launch.n_run_slices * launch.run_blocks_per_slice;
+      launch.run_flags = reinterpret_cast<uint32_t*>(offset * sizeof(uint32_t));
+      offset += (parts + 3) / 4 * 4;
+      launch.run_parts = reinterpret_cast<uint32_t*>(part_offset * sizeof(uint32_t));
+      part_offset += parts * part_stride;
+   }
    plan.table_words = offset;
+   plan.part_words = part_offset;
 }
 
 /// The tables get their place in the scratch block; the private ranges point at them.
@@ -1753,6 +1854,8 @@ void bindDerived(DerivedPlan& plan, const SparseScratch& scratch, uint32_t q_cou
    size_t r = 0;
    for (DerivedArgs& launch : plan.launches) {
       launch.counters = scratch.counters[scratch.set];
+      launch.run_flags = scratch.tables + reinterpret_cast<size_t>(launch.run_flags) / sizeof(uint32_t);
+      launch.run_parts = scratch.tables + plan.table_words + reinterpret_cast<size_t>(launch.run_parts) / sizeof(uint32_t);
       for (uint32_t k = 0; k < launch.n_ranges; ++k, ++r) {
          DerivedRange& entry = launch.ranges[k];
          entry.scratch = scratch.tables + reinterpret_cast<size_t>(entry.scratch) / sizeof(uint32_t);
@@ -1780,9 +1883,7 @@ int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_s
       std::call_once(lds_once, [] {
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_missing_runs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
       });
-      // one block per CU fits (its LDS): about one round of the 256 CUs over all (slice, range, filter)
-      const uint32_t run_units = std::max<uint32_t>(1, launch.n_run_slices * launch.n_ranges * q_count);
-      const dim3 run_grid(std::min<uint32_t>(8, std::max<uint32_t>(1, 240 / run_units)), launch.n_run_slices * launch.n_ranges, q_count);
+      const dim3 run_grid(launch.run_blocks_per_slice, launch.n_run_slices * launch.n_ranges, q_count);
       uint64_t run_bytes = 0, sparse_bytes = 0;
       for (uint32_t k = 0; k < launch.n_ranges; ++k) {
          if (launch.ranges[k].code_map != nullptr) {
@@ -1793,6 +1894,7 @@ int scanRowsWithoutSymbol(DerivedPlan& plan, uint32_t q_count, hipStream_t hip_s
       ScanLaunchTiming* run_timing = startLaunchTiming(lds_diff ? "k_scan_missing_runs<true>" : "k_scan_missing_runs<false>", 0, run_bytes * q_count, q_count, run_grid.x * run_grid.y * run_grid.z, hip_stream);
       if (lds_diff) {
          k_scan_missing_runs<true><<<run_grid, DERIVED_THREADS, lds_bytes, hip_stream>>>(launch);
+         k_sum_run_parts<<<dim3(plan.most_positions / 1024 + 1, launch.n_ranges * RUN_PART_GROUPS, q_count), 256, 0, hip_stream>>>(launch);
       } else {
          k_scan_missing_runs<false><<<run_grid, DERIVED_THREADS, ESCAPE_SLICE_WORDS32 * sizeof(uint32_t), hip_stream>>>(launch);
       }
@@ -1919,7 +2021,7 @@ int scanRangesImpl(
    }
    const uint32_t capacity = std::max<uint32_t>(4, any_store.row_words / static_cast<uint32_t>(divisor <= 0 ? 16 : divisor));
    SparseScratch* scratch = nullptr;
-   const int acquired = acquireSparseScratch(store->device, capacity, plan.table_words, &scratch);
+   const int acquired = acquireSparseScratch(store->device, capacity, plan.table_words + plan.part_words, &scratch);
    if (acquired != SILO_GPU_OK) {
       return acquired;
    }
