@@ -613,7 +613,7 @@ struct EscapeSliceArgs {
    uint32_t row_words;
    uint32_t n_slices;
    uint32_t out_symbols;
-   uint32_t block_keys;  // keys per block: whole granules
+   uint32_t block_keys;  // keys of a block's share: whole granules, at most ESCAPE_GRANULES_PER_BLOCK
    struct Range {
       const uint32_t* keys;          // the packed slice-major keys of the store (SeqStoreHost::Layout::d_escapes_sliced)
       const uint32_t* granule_base;  // counter of every granule's first key
@@ -639,59 +639,60 @@ __device__ __forceinline__ void ldsBarrier() {
 /// consecutive keys of a slice, so ONE 16-byte load per lane of the block fetches a granule, four consecutive keys per lane,
 /// and the granule's base counter is a scalar.
 ///
-/// Counting.  The keys of a slice are sorted by (position, symbol), so the counters a block's keys add to lie in a narrow
+/// Counting.  The keys of a slice are sorted by (position, symbol), so the counters a run of keys adds to lie in a narrow
 /// window behind its first key: the block counts into a window of LDS counters per filter and then adds the window to the
 /// table with CONTIGUOUS atomics — 64 consecutive counters per wave instruction, the shape the memory side takes at full
 /// rate; a lane per scattered counter, as the first version did, is an order of magnitude slower per add (MI355X guide,
-/// "Global float atomics": access shape).  Lanes whose keys share a counter add through the stretch's first and last lane only
-/// (identical addresses do not combine for LDS atomics).  A key past the window (stretches of positions almost without
-/// keys) goes to the table directly.  No barrier between a block's granules: its waves run on by themselves, one waits for its
-/// keys while another counts; two blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
-template <int FILTERS>
-constexpr uint32_t escapeLoadsInFlight() {  // 16-byte loads (granules) per thread: fewer for a batch, whose windows are narrower
-   return FILTERS >= 4 ? 1u : 2u;  // (and as many again prefetched for the next step)
-}
-constexpr uint32_t ESCAPE_GRANULES_PER_BLOCK = 16;  // at most
+/// "Global float atomics": access shape).  The block's share of keys is cut into chunks where the window is full: as many
+/// granules as end within WINDOW counters of the chunk's first (the granules' base counters tell) — thousands of keys per
+/// chunk where a position has many, one granule where private substitutions lie thirteen to a position; the window is
+/// flushed and reused chunk by chunk, the filter slices stay.  (A fixed number of keys per block, sized for the average
+/// density, sent most keys of the thin stretches PAST the window to the table one by one: 86 us for 73 M keys.)  Lanes whose
+/// keys share a counter add through the stretch's last lane only (identical addresses do not combine for LDS atomics).  No
+/// barrier between a chunk's granules: the waves run on by themselves, one waits for its keys while another counts; two
+/// blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
+constexpr uint32_t ESCAPE_GRANULES_PER_BLOCK = 64;  // of a block's share, at most
 template <int FILTERS>
 constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them for 1-4 filters (two blocks per CU), 28 KiB for 8 (beside 128 KiB of filter slices)
    return FILTERS >= 8 ? 896u : 12288u / FILTERS;
 }
 template <int FILTERS>
 constexpr uint32_t escapeLdsBytes() {
-   return (FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) + ESCAPE_GRANULES_PER_BLOCK) * static_cast<uint32_t>(sizeof(uint32_t));
+   return (FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) + ESCAPE_GRANULES_PER_BLOCK + 4u) * static_cast<uint32_t>(sizeof(uint32_t));
 }
 
 template <int FILTERS>
 __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_scan_escapes_sliced(const EscapeSliceArgs args, uint32_t n_filters) {
-   constexpr uint32_t IN_FLIGHT = escapeLoadsInFlight<FILTERS>();
    constexpr uint32_t WINDOW = escapeWindow<FILTERS>();
    static_assert(ESCAPE_GRANULE_KEYS == ESCAPE_SLICE_THREADS * 4u, "a granule is one 16-byte load per thread of the block");
-   extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32], then the counters [FILTERS][WINDOW]
+   extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32], then the counters [FILTERS][WINDOW], the granules' bases, the chunks' last keys
    uint32_t* s_count = s_filter + FILTERS * ESCAPE_SLICE_WORDS32;
+   uint32_t* s_base = s_count + FILTERS * WINDOW;  // [ESCAPE_GRANULES_PER_BLOCK + 1] the counter of every granule's first key, then one past the share's last key's
    const uint32_t first_filter = blockIdx.z * FILTERS;
    const uint32_t slice = blockIdx.y % args.n_slices;
    const EscapeSliceArgs::Range& range = args.ranges[blockIdx.y / args.n_slices];
    const uint32_t* first = range.slice_first + static_cast<size_t>(slice) * (range.positions + 1u);
    const uint32_t key_begin = first[range.pos_begin];
    const uint32_t key_end = first[range.pos_end];
-   const uint32_t block_begin = key_begin / ESCAPE_GRANULE_KEYS * ESCAPE_GRANULE_KEYS + blockIdx.x * args.block_keys;  // whole granules
-   if (block_begin >= key_end) {
+   // the block's share: args.block_keys keys (whole granules)
+   const uint32_t share_begin = key_begin / ESCAPE_GRANULE_KEYS * ESCAPE_GRANULE_KEYS + blockIdx.x * args.block_keys;
+   if (share_begin >= key_end) {
       return;  // (uniform) no keys for this block
    }
-   const uint32_t block_end = min(block_begin + args.block_keys, key_end);
+   const uint32_t share_end = min(share_begin + args.block_keys, key_end);
    const uint32_t range_first = range.pos_begin * args.out_symbols;
-   // Everything the block reads is asked for at once, behind the one dependent load of the slice index: the filter slices,
-   // the first keys, the granules' base counters — a block lives for a few memory latencies, every one put in a row would show.
-   const auto loadKeys = [&](uint4 (&quad)[IN_FLIGHT], uint32_t base) {
-#pragma unroll
-      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
-         const uint32_t i = base + k * ESCAPE_GRANULE_KEYS + threadIdx.x * 4u;
-         quad[k] = make_uint4(ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID, ESCAPE_KEY_INVALID);
-         if (i < block_end) {
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(range.keys + i));
-            quad[k] = make_uint4(v.x, v.y, v.z, v.w);
-         }
-      }
+   // Everything the block reads first is asked for at once, behind the one dependent load of the slice index: the filter
+   // slices, the first keys, the granules' base counters, the share's last key — every memory latency put in a row would
+   // show; the keys of the granule after the next are asked for while a granule is counted, across the chunks.
+   const uint32_t first_granule = share_begin / ESCAPE_GRANULE_KEYS;
+   const uint32_t n_granules = (share_end - share_begin + ESCAPE_GRANULE_KEYS - 1u) / ESCAPE_GRANULE_KEYS;  // <= ESCAPE_GRANULES_PER_BLOCK
+   // (unconditional: a load under a condition, or a loaded register handed on by a move, makes the compiler wait for ALL loads
+   // in flight where the first is used — vmcnt(0) in the loop took a memory latency per granule: 86 us for 73 M keys.  A granule
+   // past the share's last reads that one again; the whole granule exists, padded, past the slice's last key.)
+   const auto loadKeys = [&](uint32_t granule) {
+      const uint32_t g = min(granule, n_granules - 1u);
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(range.keys + share_begin + g * ESCAPE_GRANULE_KEYS + threadIdx.x * 4u));
+      return make_uint4(v.x, v.y, v.z, v.w);
    };
    uint64_t any_bit = 0;
    ulonglong2 filter_part[FILTERS][ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS];
@@ -706,23 +707,16 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          filter_part[f][j] = present && word < args.row_words ? *reinterpret_cast<const ulonglong2*>(filter + word) : make_ulonglong2(0, 0);
       }
    }
-   uint4 next[IN_FLIGHT];
-   loadKeys(next, block_begin);
-   uint32_t* s_base = s_count + FILTERS * WINDOW;  // [ESCAPE_GRANULES_PER_BLOCK] the counter of every granule's first key
-   const uint32_t first_granule = block_begin / ESCAPE_GRANULE_KEYS;
-   if (threadIdx.x < ESCAPE_GRANULES_PER_BLOCK && (first_granule + threadIdx.x) * ESCAPE_GRANULE_KEYS < block_end) {
+   uint4 quad0 = loadKeys(0), quad1 = loadKeys(1), quad2 = loadKeys(2);  // three granules in flight per wave, in registers of their own
+   if (threadIdx.x < n_granules) {
       s_base[threadIdx.x] = range.granule_base[first_granule + threadIdx.x];
    }
-   // the window of counters: from the block's first key on (the first key of the block's first granule, or the range's first
-   // position where the granule begins before it) to the position of its last key
-   const uint32_t first_counter = max(range.granule_base[first_granule], range_first);
-   const uint32_t last_key = range.keys[block_end - 1u];
-   const uint32_t last_counter = range.granule_base[(block_end - 1u) / ESCAPE_GRANULE_KEYS] + (last_key >> ESCAPE_SLICE_SHIFT);
-   const uint32_t window_first = first_counter / args.out_symbols * args.out_symbols - range_first;
-   const uint32_t window_used = min(WINDOW, (last_counter / args.out_symbols + 1u) * args.out_symbols - range_first - window_first);
+   if (threadIdx.x == 64u) {  // (a key that went to the overflow list reads as the largest relative counter: a wider window, nothing else)
+      s_base[n_granules] = range.granule_base[first_granule + n_granules - 1u] + (range.keys[share_end - 1u] >> ESCAPE_SLICE_SHIFT) + 1u;
+   }
 #pragma unroll
-   for (int f = 0; f < FILTERS; ++f) {  // (16 bytes per store; WINDOW is a multiple of 4)
-      for (uint32_t j = threadIdx.x * 4u; j < window_used; j += ESCAPE_SLICE_THREADS * 4u) {
+   for (int f = 0; f < FILTERS; ++f) {
+      for (uint32_t j = threadIdx.x * 4u; j < WINDOW; j += ESCAPE_SLICE_THREADS * 4u) {  // (16 bytes per store; WINDOW is a multiple of 4)
          *reinterpret_cast<uint4*>(s_count + f * WINDOW + j) = make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
@@ -734,29 +728,59 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
    if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
       return;  // no row of this slice is selected: none of its keys counts
    }
-   for (uint32_t base = block_begin; base < block_end; base += ESCAPE_GRANULE_KEYS * IN_FLIGHT) {  // uniform per block
-      uint4 quad[IN_FLIGHT];
-#pragma unroll
-      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
-         quad[k] = next[k];
+   const uint32_t lane = __lane_id();
+   // the chunk being counted: the granules up to chunk_granules, its window of counters
+   uint32_t window_first = 0, window_used = 0, chunk_granules = 0, chunk_end = 0;
+   const auto beginChunk = [&](uint32_t g) {
+      // the window begins at the chunk's first key's position (the range's first position where the granule begins before it)
+      // and takes the granules that end within WINDOW counters of that, one at least
+      const uint32_t first_counter = max(s_base[g], range_first);
+      window_first = first_counter / args.out_symbols * args.out_symbols - range_first;
+      uint32_t h = g + 1u;
+      while (h < n_granules && s_base[h + 1u] - range_first - window_first < WINDOW) {  // (a granule's last key may sit on the next one's first counter)
+         ++h;
       }
-      if (base + ESCAPE_GRANULE_KEYS * IN_FLIGHT < block_end) {  // (uniform) the next step's keys come in while this step counts
-         loadKeys(next, base + ESCAPE_GRANULE_KEYS * IN_FLIGHT);
-      }
+      chunk_granules = h;
+      chunk_end = min(share_begin + h * ESCAPE_GRANULE_KEYS, share_end);
+      window_used = min(WINDOW, (s_base[h] / args.out_symbols + 1u) * args.out_symbols - range_first - window_first);
+   };
+   // the chunk's window goes to the table — contiguous atomics, 64 consecutive counters per wave instruction — and is zero
+   // again for the next chunk
+   const auto flushChunk = [&]() {
+      ldsBarrier();
 #pragma unroll
-      for (uint32_t k = 0; k < IN_FLIGHT; ++k) {
-         const uint32_t granule_first = base + k * ESCAPE_GRANULE_KEYS;
-         if (granule_first >= block_end) {
-            continue;  // (uniform)
+      for (int f = 0; f < FILTERS; ++f) {
+         uint32_t* __restrict__ counts = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
+         for (uint32_t j = threadIdx.x; j < window_used; j += ESCAPE_SLICE_THREADS) {
+            const uint32_t value = s_count[f * WINDOW + j];
+            if (value != 0) {
+               s_count[f * WINDOW + j] = 0;
+               atomicAdd(&counts[j], value);
+            }
          }
-         const uint32_t granule_counter = s_base[granule_first / ESCAPE_GRANULE_KEYS - first_granule] - range_first - window_first;  // (wraps below the window: such keys are masked)
+      }
+      ldsBarrier();
+   };
+   const auto countGranule = [&](uint4& in_flight, uint32_t g) {  // (g is uniform)
+      if (g >= n_granules) {
+         return;
+      }
+      if (g == chunk_granules) {
+         flushChunk();
+         beginChunk(g);
+      }
+      const uint4 quad = in_flight;
+      in_flight = loadKeys(g + 3u);
+      const uint32_t granule_first = share_begin + g * ESCAPE_GRANULE_KEYS;
+      {
+         const uint32_t granule_counter = s_base[g] - range_first - window_first;  // (wraps below the window: such keys are masked)
          const uint32_t i = granule_first + threadIdx.x * 4u;
-         const uint32_t keys4[4] = {quad[k].x, quad[k].y, quad[k].z, quad[k].w};
+         const uint32_t keys4[4] = {quad.x, quad.y, quad.z, quad.w};
          uint32_t in_window[4];
          bool valid[4];
 #pragma unroll
          for (uint32_t c = 0; c < 4; ++c) {  // the keys before the scanned positions' first and behind their last, read along, are masked out
-            valid[c] = keys4[c] != ESCAPE_KEY_INVALID && i + c >= key_begin && i + c < block_end;
+            valid[c] = keys4[c] != ESCAPE_KEY_INVALID && i + c >= key_begin && i + c < chunk_end;
             in_window[c] = granule_counter + (keys4[c] >> ESCAPE_SLICE_SHIFT);
          }
          // A lane's four keys are consecutive keys of the sorted list.  Those on the counter of its first key are summed in the
@@ -764,9 +788,8 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          // ONCE, through its last lane: the selected keys of the lanes up to and including it (population counts of the wave's
          // ballots of the bits of n0) minus those before the stretch's first lane (fetched from that lane) — no 64 lanes on one
          // LDS counter (identical addresses do not combine: ~12 cycles per lane), no add at all for a stretch without a selected
-         // key (the keys read along outside the block's share lie in such stretches), and ~80 instructions per four keys where a
-         // stretch mask per key column took 300.  A key on another counter than the lane's first (a lane on a boundary) adds by itself.
-         const uint32_t lane = __lane_id();
+         // key (the keys read along outside the chunk lie in such stretches), and ~80 instructions per four keys where a stretch
+         // mask per key column took 300.  A key on another counter than the lane's first (a lane on a boundary) adds by itself.
          const uint32_t counter0 = in_window[0];
          const uint32_t previous = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(counter0), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
          const uint32_t following = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(counter0), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
@@ -811,19 +834,14 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
             }
          }
       }
+   };
+   beginChunk(0);
+   for (uint32_t g = 0; g < n_granules; g += 3u) {  // (uniform)
+      countGranule(quad0, g);
+      countGranule(quad1, g + 1u);
+      countGranule(quad2, g + 2u);
    }
-   // the window goes to the table: contiguous atomics, 64 consecutive counters per wave instruction
-   ldsBarrier();
-#pragma unroll
-   for (int f = 0; f < FILTERS; ++f) {
-      uint32_t* __restrict__ counts = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
-      for (uint32_t j = threadIdx.x; j < window_used; j += ESCAPE_SLICE_THREADS) {
-         const uint32_t value = s_count[f * WINDOW + j];
-         if (value != 0) {
-            atomicAdd(&counts[j], value);
-         }
-      }
-   }
+   flushChunk();
 }
 
 /// The few keys of a store that do not fit the packed form (SeqStoreHost::Layout::d_escapes_overflow: counter << 32 | sequence),
@@ -1683,15 +1701,14 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_escapes_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, escapeLdsBytes<8>());
       });
       const uint32_t per_block = q_count <= 1 ? 1 : (q_count <= 2 ? 2 : (q_count <= 4 ? 4 : 8));  // filters per pass over the keys
-      // keys per block: whole granules, as many as mostly fall into the block's window of counters (3/4 of it at the average
-      // density of keys along the positions; a key beyond it still counts, with an atomic of its own), at most ESCAPE_GRANULES_PER_BLOCK
-      const uint32_t window = per_block >= 8 ? escapeWindow<8>() : (per_block >= 4 ? escapeWindow<4>() : (per_block >= 2 ? escapeWindow<2>() : escapeWindow<1>()));
-      const double keys_per_counter = static_cast<double>(total_keys) / std::max<double>(1.0, static_cast<double>(total_positions) * sliced.n_slices * sliced.out_symbols);
-      const double fitting = 0.75 * window * keys_per_counter;
-      const uint32_t block_granules = static_cast<uint32_t>(std::min<double>(ESCAPE_GRANULES_PER_BLOCK, std::max<double>(1.0, fitting / ESCAPE_GRANULE_KEYS)));
+      // a block's share of a slice's keys: whole granules, about five shares to each of the 512 places of the chip (the slices
+      // differ in their keys, and a share's time in how its keys lie), at most ESCAPE_GRANULES_PER_BLOCK
+      const uint32_t passes = (q_count + per_block - 1) / per_block;
+      const uint64_t granules = (total_keys + ESCAPE_GRANULE_KEYS - 1) / ESCAPE_GRANULE_KEYS * passes;
+      const uint32_t block_granules = static_cast<uint32_t>(std::min<uint64_t>(ESCAPE_GRANULES_PER_BLOCK, std::max<uint64_t>(1, granules / 2560)));
       const uint32_t block_keys = block_granules * ESCAPE_GRANULE_KEYS;
       sliced.block_keys = block_keys;
-      const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, (q_count + per_block - 1) / per_block);
+      const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, passes);
       char name[64];
       std::snprintf(name, sizeof(name), "k_scan_escapes_sliced<%u>", per_block);
       // bytes: the keys (4 each) once per pass of `per_block` filters, plus a 16 KiB filter slice per block and filter
