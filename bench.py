@@ -150,10 +150,26 @@ def time_kernel(engine, tree, window, reps):
         lib.silo_gpu_tune(7, previous)
     per_launch = sorted(({**v, "launches": len(v["ms"]), "ms": sum(v["ms"]) / len(v["ms"])} for v in launches.values()), key=lambda v: -v["ms"])
     time_kernel.per_launch = per_launch
+    # the same once more with every pass on the caller's stream (SILO_GPU_TUNE_SIDE_STREAM = 2): the launches one behind the
+    # other, each with the device to itself — a launch's own rate, where the figures above are its rate while it shares the
+    # HBM with the passes on the side streams
+    alone = {}
+    previous_side = lib.silo_gpu_tune(5, 2)
+    previous = lib.silo_gpu_tune(7, 1)
+    try:
+        for _ in range(reps):
+            binding._check(lib.silo_gpu_mutations_scan(store.handle, 0, filt, 0, n_positions, counts, None))
+            for entry in binding.scan_timings():
+                alone.setdefault(entry["kernel"], []).append(entry["ms"])
+    finally:
+        lib.silo_gpu_tune(7, previous)
+        lib.silo_gpu_tune(5, previous_side)
+    time_kernel.alone_ms = {kernel: sum(v) / len(v) for kernel, v in alone.items()}
     return ms, kernel, store, filt, counts
 
 
 time_kernel.per_launch = []
+time_kernel.alone_ms = {}
 
 
 def scan_bytes(lib, handle, seqstore_id, positions, w8):
@@ -185,7 +201,9 @@ def roofline_of(lib, store, window, sequences, kernel_ms, ceiling_gbps):
     n_local = window[1] - window[0]
     physical = scan_bytes(lib, store.handle, 0, n_local, w8)
     alg_bytes = n_local * 5 * w8 + w8
-    launches = [dict(kernel=v["kernel"], ms=v["ms"], bytes=v["bytes"], GBps=v["bytes"] / (v["ms"] * 1e-3) / 1e9, plane_rows=v["plane_rows"], blocks=v["blocks"])
+    launches = [dict(kernel=v["kernel"], ms=v["ms"], bytes=v["bytes"], GBps=v["bytes"] / (v["ms"] * 1e-3) / 1e9, plane_rows=v["plane_rows"], blocks=v["blocks"],
+                     ms_alone=time_kernel.alone_ms.get(v["kernel"]),
+                     GBps_alone=v["bytes"] / (time_kernel.alone_ms[v["kernel"]] * 1e-3) / 1e9 if time_kernel.alone_ms.get(v["kernel"]) else None)
                 for v in time_kernel.per_launch]
     # the dominant launch = the one that moves the most bytes (a launch on the side stream may LAST longer beside the others without being the work)
     dominant = max(time_kernel.per_launch, key=lambda v: v["bytes"]) if time_kernel.per_launch else dict(
@@ -217,6 +235,9 @@ def roofline_of(lib, store, window, sequences, kernel_ms, ceiling_gbps):
         "frac_of_ceiling": achieved / ceiling_gbps if ceiling_gbps else None,
         "kernel": dominant["kernel"],
         "kernel_ms": dominant["ms"],
+        "kernel_ms_alone": time_kernel.alone_ms.get(dominant["kernel"]),
+        "frac_alone": (dominant["bytes"] / (time_kernel.alone_ms[dominant["kernel"]] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                       if time_kernel.alone_ms.get(dominant["kernel"]) else None),
         "kernel_launches_timed": dominant.get("launches", 0),
         "kernel_bytes_per_launch": dominant["bytes"],
         "launches_per_scan": launches,
@@ -229,7 +250,9 @@ def roofline_of(lib, store, window, sequences, kernel_ms, ceiling_gbps):
         "byte_reduction": alg_bytes / physical["bytes"],
         "plane_rows_per_position": physical["plane_rows"] / max(1, n_local),
         "layout": LAYOUT_TEXT.get(scan_planes, LAYOUT_TEXT[3]),
-        "note": "frac = the dominant launch's own bytes / its own duration / peak; algorithmic bytes / time exceeds the peak precisely because the "
+        "note": "frac = the dominant launch's own bytes / its own duration / peak, in the product's configuration: the escape-key pass and the passes for "
+                "derived symbols run beside it on side streams and share the HBM (frac_alone / ms_alone: the same launches one behind the other on one "
+                "stream); scan_frac = all bytes of the scan / the scan's duration; algorithmic bytes / time exceeds the peak precisely because the "
                 "scan moves `byte_reduction` x fewer bytes than the one-hot model of SURVEY.md section 8(d); `also_identity_planes` is the same "
                 "query where nothing of that applies (the floor)",
     }
