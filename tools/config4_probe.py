@@ -12,7 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 6_250_000
 engine, _, tree, _, _ = bench.build_engine(n, 0, 1, None, 0, with_genes=True)
 reference_text = bench.load_reference_genomes(False)["nucleotideSequences"][0]["sequence"]
 genes = bench.load_reference_genomes(True)["genes"]
-out = bench.config4_workload(engine, tree, reference_text, 29903, sum(len(g["sequence"]) for g in genes), n, lambda: None)
+out = bench.config4_workload(engine, tree, reference_text, 29903, sum(len(g["sequence"]) for g in genes), n, 1, lambda: None)
 print(json.dumps({k: v for k, v in out.items() if k != "workload"}))
 print(json.dumps(engine.last_trace()))
 engine.close()
