@@ -658,7 +658,7 @@ constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them 
 }
 template <int FILTERS>
 constexpr uint32_t escapeLdsBytes() {
-   return (FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) + ESCAPE_GRANULES_PER_BLOCK + 4u) * static_cast<uint32_t>(sizeof(uint32_t));
+   return (FILTERS * (ESCAPE_SLICE_WORDS32 + escapeWindow<FILTERS>()) + ESCAPE_GRANULES_PER_BLOCK + 4u + 64u) * static_cast<uint32_t>(sizeof(uint32_t));
 }
 
 template <int FILTERS>
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
    extern __shared__ uint32_t s_filter[];  // [FILTERS][ESCAPE_SLICE_WORDS32], then the counters [FILTERS][WINDOW], the granules' bases, the chunks' last keys
    uint32_t* s_count = s_filter + FILTERS * ESCAPE_SLICE_WORDS32;
    uint32_t* s_base = s_count + FILTERS * WINDOW;  // [ESCAPE_GRANULES_PER_BLOCK + 1] the counter of every granule's first key, then one past the share's last key's
+   uint32_t* s_nowhere = s_base + ESCAPE_GRANULES_PER_BLOCK + 4u;  // [64] a word per lane: where an add of nothing goes
    const uint32_t first_filter = blockIdx.z * FILTERS;
    const uint32_t slice = blockIdx.y % args.n_slices;
    const EscapeSliceArgs::Range& range = args.ranges[blockIdx.y / args.n_slices];
@@ -778,9 +779,14 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          const uint32_t keys4[4] = {quad.x, quad.y, quad.z, quad.w};
          uint32_t in_window[4];
          bool valid[4];
+         // the keys before the scanned positions' first and behind their last, read along in the first and the last granule, are masked out
+         // (one unsigned comparison per key: index - first valid index < number of valid indices; every index where the granule lies inside)
+         const bool inside = granule_first >= key_begin && granule_first + ESCAPE_GRANULE_KEYS <= chunk_end;  // (uniform)
+         const uint32_t first_valid = inside ? 0u : key_begin;
+         const uint32_t n_valid = inside ? 0xFFFFFFFFu : chunk_end - key_begin;
 #pragma unroll
-         for (uint32_t c = 0; c < 4; ++c) {  // the keys before the scanned positions' first and behind their last, read along, are masked out
-            valid[c] = keys4[c] != ESCAPE_KEY_INVALID && i + c >= key_begin && i + c < chunk_end;
+         for (uint32_t c = 0; c < 4; ++c) {
+            valid[c] = static_cast<bool>(static_cast<uint32_t>(keys4[c] != ESCAPE_KEY_INVALID) & static_cast<uint32_t>(i + c - first_valid < n_valid));
             in_window[c] = granule_counter + (keys4[c] >> ESCAPE_SLICE_SHIFT);
          }
          // A lane's four keys are consecutive keys of the sorted list.  Those on the counter of its first key are summed in the
@@ -797,41 +803,52 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          const bool tail = lane == 63 || counter0 != following;
          const uint64_t heads_at_or_below = __ballot(head) & (~uint64_t{0} >> (63u - lane));  // (lane 0 is one: never empty)
          const uint32_t first_of_stretch = 63u - static_cast<uint32_t>(__builtin_clzll(heads_at_or_below));
+         // The body has no per-key branch: an add that has nothing to add goes to a word of the lane's own (64 lanes adding zero
+         // to one counter would still serialise) — 4 LDS atomics per granule and filter whatever the keys.  Where a granule by
+         // itself always fits the window (FILTERS <= 2: ESCAPE_MAX_RELATIVE) every selected key of a chunk lies inside it and
+         // there is no second path either.  With per-key branches and a table path through a merged (flat) address the body
+         // took 250 instructions per granule and wave, half of them exec-mask traffic, and the kernel was bound by them
+         // (profiles/r03_notes.md): 151 now.
+         constexpr bool EVERY_KEY_IN_WINDOW = WINDOW >= ESCAPE_MAX_RELATIVE + 64u;
 #pragma unroll
          for (int f = 0; f < FILTERS; ++f) {
             uint32_t* __restrict__ window = s_count + f * WINDOW;
-            uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
+            const auto below = [](uint64_t mask) {
+               return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            };
+            // (an add of nothing goes to the lane's own word; where a key may lie past the window it goes to the table by itself)
+            [[maybe_unused]] uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
             const auto add = [&](uint32_t counter, uint32_t value) {
-               if (counter < WINDOW) {
-                  atomicAdd(&window[counter], value);
-               } else {  // a key past the window: straight to the table
-                  atomicAdd(&table[counter], value);
+               const bool here = EVERY_KEY_IN_WINDOW ? value != 0 : value != 0 && counter < WINDOW;
+               if (__ballot(here) != 0) {  // (uniform: where the keys are many to a counter most of these adds have nothing in any lane)
+                  atomicAdd(here ? &window[counter] : &s_nowhere[lane], here ? value : 0u);
+               }
+               if constexpr (!EVERY_KEY_IN_WINDOW) {
+                  if (value != 0 && counter >= WINDOW) {
+                     atomicAdd(&table[counter], value);
+                  }
                }
             };
             uint32_t n0 = 0;
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
                const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
-               const bool selected = valid[c] && ((s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & 1u) != 0;
-               if (c == 0 || in_window[c] == counter0) {
-                  n0 += selected ? 1u : 0u;
-               } else if (selected) {
-                  add(in_window[c], 1u);
+               const uint32_t selected = (s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & (valid[c] ? 1u : 0u);  // (the read itself is always inside the slice)
+               if (c == 0) {
+                  n0 = selected;
+               } else {
+                  const bool same = in_window[c] == counter0;
+                  n0 += same ? selected : 0u;
+                  add(in_window[c], same ? 0u : selected);
                }
             }
             // selected keys of the lanes below this one, from the ballots of the three bits of n0
             const uint64_t bit0 = __ballot((n0 & 1u) != 0);
             const uint64_t bit1 = __ballot((n0 & 2u) != 0);
             const uint64_t bit2 = __ballot((n0 & 4u) != 0);
-            const auto below = [](uint64_t mask) {
-               return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-            };
             const uint32_t before = below(bit0) + 2u * below(bit1) + 4u * below(bit2);
             const uint32_t before_stretch = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(first_of_stretch * 4u), static_cast<int>(before)));
-            const uint32_t value = before + n0 - before_stretch;
-            if (tail && value != 0) {
-               add(counter0, value);
-            }
+            add(counter0, tail ? before + n0 - before_stretch : 0u);
          }
       }
    };
@@ -1101,10 +1118,15 @@ __global__ __launch_bounds__(256) void k_count_sparse_keys(const DerivedArgs arg
       const uint32_t i = first + k * 256u;
       key[k] = i < range.sparse_end ? range.sparse_keys[i] : 0;
    }
+   uint64_t word[SPARSE_KEYS_PER_THREAD];
+#pragma unroll
+   for (uint32_t k = 0; k < SPARSE_KEYS_PER_THREAD; ++k) {  // the filter lookups of all keys of the thread in flight together
+      word[k] = args.filters[q][static_cast<uint32_t>(key[k]) >> 6];
+   }
 #pragma unroll
    for (uint32_t k = 0; k < SPARSE_KEYS_PER_THREAD; ++k) {
       const uint32_t sequence = static_cast<uint32_t>(key[k]);
-      bool pending = first + k * 256u < range.sparse_end && ((args.filters[q][sequence >> 6] >> (sequence & 63u)) & 1ull) != 0;
+      bool pending = first + k * 256u < range.sparse_end && ((word[k] >> (sequence & 63u)) & 1ull) != 0;
       const uint32_t counter = static_cast<uint32_t>(key[k] >> 37) - range.pos_begin;
       for (uint64_t open = __ballot(pending); open != 0; open = __ballot(pending)) {
          const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(open));
@@ -1705,7 +1727,7 @@ int scanEscapes(const std::vector<ScanRange>& ranges, const uint64_t* const* fil
       // differ in their keys, and a share's time in how its keys lie), at most ESCAPE_GRANULES_PER_BLOCK
       const uint32_t passes = (q_count + per_block - 1) / per_block;
       const uint64_t granules = (total_keys + ESCAPE_GRANULE_KEYS - 1) / ESCAPE_GRANULE_KEYS * passes;
-      const uint32_t block_granules = static_cast<uint32_t>(std::min<uint64_t>(ESCAPE_GRANULES_PER_BLOCK, std::max<uint64_t>(1, granules / 2560)));
+      const uint32_t block_granules = static_cast<uint32_t>(std::min<uint64_t>(ESCAPE_GRANULES_PER_BLOCK, std::max<uint64_t>(1, granules / 1280)));  // (flat between 640 and 2 560: profiles/r03_notes.md)
       const uint32_t block_keys = block_granules * ESCAPE_GRANULE_KEYS;
       sliced.block_keys = block_keys;
       const dim3 grid((most_keys + block_keys - 1) / block_keys, sliced.n_slices * n_sliced, passes);

@@ -429,7 +429,10 @@ constexpr uint32_t ESCAPE_MAX_RANGES = 16;
 constexpr uint32_t ESCAPE_GRANULE_KEYS = 4096;                 // keys that share a base counter: one 16-byte load per lane of a 1024-thread block
 constexpr uint32_t ESCAPE_ROW_MASK = (1u << ESCAPE_SLICE_SHIFT) - 1u;
 constexpr uint32_t ESCAPE_KEY_INVALID = 0xFFFFFFFFu;           // padding / a key that went to the overflow list
-constexpr uint32_t ESCAPE_MAX_RELATIVE = (1u << (32 - ESCAPE_SLICE_SHIFT)) - 2u;  // largest relative counter a packed key holds
+// largest relative counter a packed key holds (15 bits would allow 32 766): small enough that a granule by itself always fits the
+// window of LDS counters of k_scan_escapes_sliced<1> and <2> (6 144 counters less a position's worth), so that those count without
+// a path for keys past the window; the few keys further behind their granule's first go to the overflow list
+constexpr uint32_t ESCAPE_MAX_RELATIVE = 6000u;
 
 /// A position range of one sequence store with the count tables of every filter of the launch.
 struct ScanRange {
