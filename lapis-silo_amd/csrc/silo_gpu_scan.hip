@@ -715,15 +715,41 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
    if (threadIdx.x == 64u) {  // (a key that went to the overflow list reads as the largest relative counter: a wider window, nothing else)
       s_base[n_granules] = range.granule_base[first_granule + n_granules - 1u] + (range.keys[share_end - 1u] >> ESCAPE_SLICE_SHIFT) + 1u;
    }
+   // Eight filters: their slices are kept as ONE BYTE PER ROW — bit f = filter f has the row — so that a key's lookup is one
+   // LDS read for all eight (a read per filter and key made the eight-filter pass LDS-bound: 32 of its ~70 LDS instructions
+   // per granule and wave).  A thread holds the 128 rows of its 16-byte part of every filter and writes their 128 bytes.
+   constexpr bool BYTE_PER_ROW = FILTERS == 8;
+   static_assert(ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS == 1u, "a thread holds one 16-byte part of a filter slice");
 #pragma unroll
    for (int f = 0; f < FILTERS; ++f) {
       for (uint32_t j = threadIdx.x * 4u; j < WINDOW; j += ESCAPE_SLICE_THREADS * 4u) {  // (16 bytes per store; WINDOW is a multiple of 4)
          *reinterpret_cast<uint4*>(s_count + f * WINDOW + j) = make_uint4(0, 0, 0, 0);
       }
+      if constexpr (!BYTE_PER_ROW) {
+         *reinterpret_cast<ulonglong2*>(s_filter + f * ESCAPE_SLICE_WORDS32 + threadIdx.x * 4u) = filter_part[f][0];
+      }
+      any_bit |= filter_part[f][0].x | filter_part[f][0].y;
+   }
+   if constexpr (BYTE_PER_ROW) {
 #pragma unroll
-      for (uint32_t j = 0; j < ESCAPE_SLICE_WORDS32 / 4u / ESCAPE_SLICE_THREADS; ++j) {
-         *reinterpret_cast<ulonglong2*>(s_filter + f * ESCAPE_SLICE_WORDS32 + (j * ESCAPE_SLICE_THREADS + threadIdx.x) * 4u) = filter_part[f][j];
-         any_bit |= filter_part[f][j].x | filter_part[f][j].y;
+      for (uint32_t quarter = 0; quarter < 4; ++quarter) {  // 32 rows of the thread's 128: 32 bytes
+         uint32_t bytes[8];
+#pragma unroll
+         for (uint32_t k = 0; k < 8; ++k) {
+            bytes[k] = 0;
+         }
+#pragma unroll
+         for (int f = 0; f < FILTERS; ++f) {
+            const uint64_t half = quarter < 2 ? filter_part[f][0].x : filter_part[f][0].y;
+            const uint32_t rows32 = static_cast<uint32_t>(half >> (32u * (quarter & 1u)));
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {  // four rows -> the low bits of four bytes
+               bytes[k] |= ((((rows32 >> (4u * k)) & 0xFu) * 0x00204081u) & 0x01010101u) << f;
+            }
+         }
+         uint32_t* out = s_filter + threadIdx.x * 32u + quarter * 8u;  // (row r of the slice = byte r)
+         *reinterpret_cast<uint4*>(out) = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+         *reinterpret_cast<uint4*>(out + 4) = make_uint4(bytes[4], bytes[5], bytes[6], bytes[7]);
       }
    }
    if (__syncthreads_or(any_bit != 0 ? 1 : 0) == 0) {
@@ -810,6 +836,62 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          // took 250 instructions per granule and wave, half of them exec-mask traffic, and the kernel was bound by them
          // (profiles/r03_notes.md): 151 now.
          constexpr bool EVERY_KEY_IN_WINDOW = WINDOW >= ESCAPE_MAX_RELATIVE + 64u;
+         [[maybe_unused]] uint32_t filters_with[4] = {0, 0, 0, 0};  // (one byte per row: bit f = filter f has the key's row)
+         if constexpr (BYTE_PER_ROW) {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+               filters_with[c] = reinterpret_cast<const uint8_t*>(s_filter)[keys4[c] & ESCAPE_ROW_MASK] & (valid[c] ? 0xFFu : 0u);  // (the read itself is always inside the slice)
+            }
+         }
+         if constexpr (BYTE_PER_ROW) {
+            // Eight filters at once.  The lane's sums per filter (<= 4) sit two to a register in 16-bit fields, so ONE inclusive
+            // scan over the lanes (6 DPP adds per register) gives every filter's prefix, and one ds_bpermute per register the
+            // prefixes at the stretch's first lane; only the final adds are per filter.  (Filter by filter — ballots, mbcnt,
+            // a bpermute each — the pass cost eight times the one-filter kernel per key: 2/3 of the configs[4] batch.)
+            const auto add8 = [&](uint32_t counter, uint32_t value, int f) {
+               const bool here = value != 0 && counter < WINDOW;
+               if (__ballot(here) != 0) {
+                  atomicAdd(here ? &s_count[f * WINDOW + counter] : &s_nowhere[lane], here ? value : 0u);
+               }
+               if (value != 0 && counter >= WINDOW) {  // a key past the window: straight to the table
+                  atomicAdd(&range.counts[first_filter + f < n_filters ? first_filter + f : first_filter][window_first + counter], value);
+               }
+            };
+            uint32_t on_first = filters_with[0];          // per key: the filters that have it, if it sits on the lane's first counter
+            uint32_t sums[4] = {0, 0, 0, 0};              // [k]: filters 2k (low field) and 2k + 1 (high field)
+            uint32_t elsewhere[4] = {0, 0, 0, 0};         // per key: the filters that have it, if it sits on another counter
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+               if (c != 0) {
+                  const bool same = in_window[c] == counter0;
+                  on_first = same ? filters_with[c] : 0u;
+                  elsewhere[c] = same ? 0u : filters_with[c];
+               }
+#pragma unroll
+               for (uint32_t k = 0; k < 4; ++k) {
+                  sums[k] += ((on_first >> (2u * k)) & 1u) | (((on_first >> (2u * k + 1u)) & 1u) << 16);
+               }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+               const uint32_t through = waveSumToLane63(sums[k]);  // (inclusive scan over the lanes: <= 256 per field)
+               const uint32_t before = through - sums[k];
+               const uint32_t before_stretch = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(first_of_stretch * 4u), static_cast<int>(before)));
+               const uint32_t stretch = through - before_stretch;  // (field by field: no borrow, a prefix never exceeds a later one)
+               add8(counter0, tail ? stretch & 0xFFFFu : 0u, static_cast<int>(2u * k));
+               add8(counter0, tail ? stretch >> 16 : 0u, static_cast<int>(2u * k + 1u));
+            }
+#pragma unroll
+            for (uint32_t c = 1; c < 4; ++c) {
+               if (__ballot(elsewhere[c] != 0) != 0) {  // (uniform) a lane on a boundary of counters
+#pragma unroll
+                  for (int f = 0; f < FILTERS; ++f) {
+                     add8(in_window[c], (elsewhere[c] >> f) & 1u, f);
+                  }
+               }
+            }
+            return;
+         }
 #pragma unroll
          for (int f = 0; f < FILTERS; ++f) {
             uint32_t* __restrict__ window = s_count + f * WINDOW;
@@ -832,8 +914,13 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
             uint32_t n0 = 0;
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
-               const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
-               const uint32_t selected = (s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & (valid[c] ? 1u : 0u);  // (the read itself is always inside the slice)
+               uint32_t selected;
+               if constexpr (BYTE_PER_ROW) {
+                  selected = (filters_with[c] >> f) & 1u;
+               } else {
+                  const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
+                  selected = (s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & (valid[c] ? 1u : 0u);  // (the read itself is always inside the slice)
+               }
                if (c == 0) {
                   n0 = selected;
                } else {
