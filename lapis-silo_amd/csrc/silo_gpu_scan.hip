@@ -806,13 +806,20 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
          uint32_t in_window[4];
          bool valid[4];
          // the keys before the scanned positions' first and behind their last, read along in the first and the last granule, are masked out
-         // (one unsigned comparison per key: index - first valid index < number of valid indices; every index where the granule lies inside)
-         const bool inside = granule_first >= key_begin && granule_first + ESCAPE_GRANULE_KEYS <= chunk_end;  // (uniform)
-         const uint32_t first_valid = inside ? 0u : key_begin;
-         const uint32_t n_valid = inside ? 0xFFFFFFFFu : chunk_end - key_begin;
+         // (one unsigned comparison per key: index - first valid index < number of valid indices)
+         if (granule_first >= key_begin && granule_first + ESCAPE_GRANULE_KEYS <= chunk_end) {  // (uniform) the granule lies inside: nearly all do
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+               valid[c] = keys4[c] != ESCAPE_KEY_INVALID;
+            }
+         } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+               valid[c] = static_cast<bool>(static_cast<uint32_t>(keys4[c] != ESCAPE_KEY_INVALID) & static_cast<uint32_t>(i + c - key_begin < chunk_end - key_begin));
+            }
+         }
 #pragma unroll
          for (uint32_t c = 0; c < 4; ++c) {
-            valid[c] = static_cast<bool>(static_cast<uint32_t>(keys4[c] != ESCAPE_KEY_INVALID) & static_cast<uint32_t>(i + c - first_valid < n_valid));
             in_window[c] = granule_counter + (keys4[c] >> ESCAPE_SLICE_SHIFT);
          }
          // A lane's four keys are consecutive keys of the sorted list.  Those on the counter of its first key are summed in the
@@ -895,16 +902,11 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
 #pragma unroll
          for (int f = 0; f < FILTERS; ++f) {
             uint32_t* __restrict__ window = s_count + f * WINDOW;
-            const auto below = [](uint64_t mask) {
-               return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-            };
             // (an add of nothing goes to the lane's own word; where a key may lie past the window it goes to the table by itself)
             [[maybe_unused]] uint32_t* __restrict__ table = range.counts[first_filter + f < n_filters ? first_filter + f : first_filter] + window_first;
             const auto add = [&](uint32_t counter, uint32_t value) {
                const bool here = EVERY_KEY_IN_WINDOW ? value != 0 : value != 0 && counter < WINDOW;
-               if (__ballot(here) != 0) {  // (uniform: where the keys are many to a counter most of these adds have nothing in any lane)
-                  atomicAdd(here ? &window[counter] : &s_nowhere[lane], here ? value : 0u);
-               }
+               atomicAdd(here ? &window[counter] : &s_nowhere[lane], here ? value : 0u);
                if constexpr (!EVERY_KEY_IN_WINDOW) {
                   if (value != 0 && counter >= WINDOW) {
                      atomicAdd(&table[counter], value);
@@ -912,30 +914,29 @@ __global__ __launch_bounds__(ESCAPE_SLICE_THREADS, FILTERS <= 4 ? 8 : 4) void k_
                }
             };
             uint32_t n0 = 0;
+            uint32_t elsewhere[4] = {0, 0, 0, 0};  // a key of the lane on another counter than its first, selected
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
-               uint32_t selected;
-               if constexpr (BYTE_PER_ROW) {
-                  selected = (filters_with[c] >> f) & 1u;
-               } else {
-                  const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
-                  selected = (s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & (valid[c] ? 1u : 0u);  // (the read itself is always inside the slice)
-               }
+               const uint32_t row = keys4[c] & ESCAPE_ROW_MASK;
+               const uint32_t selected = (s_filter[f * ESCAPE_SLICE_WORDS32 + (row >> 5)] >> (row & 31u)) & (valid[c] ? 1u : 0u);  // (the read itself is always inside the slice)
                if (c == 0) {
                   n0 = selected;
                } else {
                   const bool same = in_window[c] == counter0;
                   n0 += same ? selected : 0u;
-                  add(in_window[c], same ? 0u : selected);
+                  elsewhere[c] = same ? 0u : selected;
                }
             }
-            // selected keys of the lanes below this one, from the ballots of the three bits of n0
-            const uint64_t bit0 = __ballot((n0 & 1u) != 0);
-            const uint64_t bit1 = __ballot((n0 & 2u) != 0);
-            const uint64_t bit2 = __ballot((n0 & 4u) != 0);
-            const uint32_t before = below(bit0) + 2u * below(bit1) + 4u * below(bit2);
-            const uint32_t before_stretch = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(first_of_stretch * 4u), static_cast<int>(before)));
-            add(counter0, tail ? before + n0 - before_stretch : 0u);
+            if (__ballot((elsewhere[1] | elsewhere[2] | elsewhere[3]) != 0) != 0) {  // (uniform: where the keys are many to a counter no lane has one)
+#pragma unroll
+               for (uint32_t c = 1; c < 4; ++c) {
+                  add(in_window[c], elsewhere[c]);
+               }
+            }
+            // the stretch's sum at its last lane: an inclusive scan of the lanes' sums (6 DPP adds) less the prefix at its first lane
+            const uint32_t through = waveSumToLane63(n0);
+            const uint32_t before_stretch = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(first_of_stretch * 4u), static_cast<int>(through - n0)));
+            add(counter0, tail ? through - before_stretch : 0u);
          }
       }
    };
