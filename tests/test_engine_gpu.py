@@ -197,6 +197,22 @@ def test_concurrent_clients_get_sequential_results(engines):
             assert got == expected[k], json.dumps(queries[k])
 
 
+def test_native_client_threads_answer_like_one_call(engines):
+    """silo_engine_run_clients (the load generator behind bench.py's one-by-one client figures): every client's answers are
+    those of a single silo_engine_execute_query; a query that is not answered with 200 ends the run with an error."""
+    engine, _ = engines
+    rng = random.Random(11)
+    for query in ({"action": {"type": "Aggregated"}, "filterExpression": random_expression(rng, 3)},
+                  {"action": {"type": "Mutations", "minProportion": 0.05}, "filterExpression": {"type": "True"}}):
+        status, body = engine.execute_text(json.dumps(query))
+        assert status == 200
+        for clients in (1, 4):
+            per_second, last = engine.run_clients(json.dumps(query), clients, 0.2)
+            assert per_second > 0 and last == body
+    with pytest.raises(Exception):
+        engine.run_clients(json.dumps({"action": {"type": "Aggregated"}, "filterExpression": {"type": "NoSuchFilter"}}), 2, 0.1)
+
+
 def test_first_count_queries_of_new_threads_on_a_busy_device(engines):
     """A thread's count slot (k_filter_eval hands its total to the host through it) is created by the thread's first filter ->
     count query.  Its counters are zeroed by a fill on the null stream, which the thread's own non-blocking stream does not
