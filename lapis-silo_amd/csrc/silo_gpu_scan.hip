@@ -646,14 +646,14 @@ __device__ __forceinline__ void ldsBarrier() {
 /// "Global float atomics": access shape).  The block's share of keys is cut into chunks where the window is full: as many
 /// granules as end within WINDOW counters of the chunk's first (the granules' base counters tell) — thousands of keys per
 /// chunk where a position has many, one granule where private substitutions lie thirteen to a position; the window is
-/// flushed and reused chunk by chunk, the filter slices stay.  (A fixed number of keys per block, sized for the average
-/// density, sent most keys of the thin stretches PAST the window to the table one by one: 86 us for 73 M keys.)  Lanes whose
-/// keys share a counter add through the stretch's last lane only (identical addresses do not combine for LDS atomics).  No
+/// flushed and reused chunk by chunk, the filter slices stay.  Lanes whose keys share a counter add through the stretch's last
+/// lane only (identical addresses do not combine for LDS atomics), and the loop body has no per-key branch (see there).  No
 /// barrier between a chunk's granules: the waves run on by themselves, one waits for its keys while another counts; two
-/// blocks per CU (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.
+/// blocks per CU for one and two filters (<= 64 VGPRs, 64 KiB of LDS) cover each other's first and last steps.  Eight filters:
+/// the slices as one byte per row and the lanes' sums in packed fields (see there), one block per CU.
 constexpr uint32_t ESCAPE_GRANULES_PER_BLOCK = 64;  // of a block's share, at most
 template <int FILTERS>
-constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them for 1-4 filters (two blocks per CU), 28 KiB for 8 (beside 128 KiB of filter slices)
+constexpr uint32_t escapeWindow() {  // LDS counters per filter: 48 KiB of them for 1-4 filters, 28 KiB for 8 (beside 128 KiB of filter slices)
    return FILTERS >= 8 ? 896u : 12288u / FILTERS;
 }
 template <int FILTERS>
